@@ -1,0 +1,125 @@
+/* libmmd - C ABI of the MI355X-native MM-Diffusion denoising hot path.
+ *
+ * One shared library (mm-diffusion_amd/lib/libmmd.so, built by hipcc --offload-arch=gfx950) loaded with
+ * ctypes by the Python host mirror (mm-diffusion_amd/mm_diffusion/_hip.py).  The reference has no native
+ * layer (pure PyTorch), so each entry point replaces a GROUP of ATen calls of the reference hot path; the
+ * reference interface it replaces is cited per function (paths relative to /root/reference/mm_diffusion).
+ *
+ * Conventions
+ *   - raw DEVICE pointers + sizes; row-major "channels-last" activations X[rows, C] with a row stride `ld`
+ *     in ELEMENTS (so a column slice of a wider buffer is a valid tensor: skip concats are free views);
+ *     video rows are ordered (n, f, h, w), audio rows (n, l)
+ *   - dtype: MMD_F32 (0) or MMD_BF16 (1) = element type of activations / GEMM weights; all statistics,
+ *     accumulation, softmax and bias arithmetic are fp32
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t); no allocation, no sync, no global state:
+ *     the caller owns all buffers including workspaces; calls are re-entrant and graph-capturable
+ *   - return 0 on success, <0 on error (MMD_ERR_*); mmd_last_error() gives the message (thread local)
+ */
+#ifndef MMD_H
+#define MMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMD_F32 0
+#define MMD_BF16 1
+#define MMD_OK 0
+#define MMD_ERR_ARG (-1)
+#define MMD_ERR_LAUNCH (-2)
+#define MMD_ERR_UNSUPPORTED (-3)
+
+int mmd_version(void);
+const char* mmd_last_error(void);
+
+/* --- HIP graph capture of one denoising step + stream-ordered timing (bench roofline leg) --- */
+int mmd_graph_begin(void* stream);
+int mmd_graph_end(void* stream, void** exec_out);
+int mmd_graph_launch(void* exec, void* stream);
+int mmd_graph_destroy(void* exec);
+int mmd_event_create(void** ev);
+int mmd_event_record(void* ev, void* stream);
+int mmd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int mmd_event_destroy(void* ev);
+
+/* timestep_embedding + time_embed MLP (nn.py:192-210; multimodal_unet.py:791-795,1075).
+ * t_kind: 0 int64, 1 int32, 2 float32.  out_silu[N,dim] = SiLU(time_embed(emb(t))) (the input every
+ * ResBlock emb_layers applies its Linear to, unet:366-372); out_raw (nullable) = time_embed output. */
+int mmd_temb_fwd(const void* t, int t_kind, int N, int dim, const float* W0, const float* b0, const float* W2,
+                 const float* b2, float* out_silu, float* out_raw, void* stream);
+
+/* y[N,J] = x[N,K] W[J,K]^T + b : all ResBlock emb_layers Linear(128 -> 2*Cout) batched into one call
+ * over the row-concatenated weights (unet:366-372,454). */
+int mmd_linear_fwd(const float* x, const float* W, const float* b, float* y, int N, int K, int J, void* stream);
+
+/* GroupNorm32 statistics -> fused per-(slice,channel) affine (nn.py:16-33; FiLM unet:457-470).
+ * Slice s normalises rows base(s) + j*tstride (j < Tn), base(s) = (s/inner)*outer_stride + (s%inner)*inner_stride.
+ * a_out/b_out [S, C] fp32: y = x*a + b.  film (nullable) [S, >=2C] rows (scale | shift), row stride film_ld.
+ * workspace: mmd_gn_workspace_bytes(S, Tn) bytes. */
+int64_t mmd_gn_workspace_bytes(int S, int Tn);
+int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int inner, int64_t outer_stride,
+                 int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, const float* film,
+                 int64_t film_ld, float eps, float* a_out, float* b_out, void* workspace, void* stream);
+/* y = act(x*a[slice(row)] + b[slice(row)]), act: 0 none, 1 SiLU (nn.SiLU after every GroupNorm32). */
+int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn, int inner,
+                 int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a, const float* b, int act,
+                 void* stream);
+/* x[m, :] += e[m / rows_per_sample, :]  (non-FiLM ResBlock h + emb_out, unet:473-477). */
+int mmd_add_rowbias(int dtype, void* x, int64_t ld, int64_t rows, int C, int64_t rows_per_sample, const float* e,
+                    int64_t e_ld, void* stream);
+
+/* Implicit-GEMM convolution on the matrix cores:
+ *   Y[m, co] = bias[co] + sum_tap sum_ci A[src(m,tap), ci] * W[co, tap*Cin + ci] (+ R[m, co])
+ * rows m decompose as (n, p0, p1, p2) over (D0, D1, D2); tap t = taps[3t..3t+2] offsets (p0,p1,p2), out of
+ * range -> zero padding.  Covers VideoConv 2d+1d spatial (D=(1,H,W), 9 taps) and temporal (D=(F,HW,1), 3 taps),
+ * VideoConv '3d' k=1, AudioConv k=3 dilated (D=(L,1,1), taps (+-d,0,0)) and k=1, and every qkv/proj 1x1 conv
+ * (unet:83-131,272,275,378,401,605-610).  W is [Cout][ntaps*Cin] in `dtype`; bias fp32 (nullable);
+ * R (nullable) residual in `dtype`.  taps is a HOST pointer.  tile: 0 auto, 64 or 128. */
+int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
+                  void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
+                  void* stream);
+
+/* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
+ * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).
+ * For batch n, group g (< G): queries = Q rows n*q_rows_per_batch + g*q_per_group + [0, q_per_group) (the last
+ * group extends to q_rows_per_batch); keys = KV rows n*k_rows_per_batch + ((g + shift)*k_per_group + j) mod
+ * k_rows_per_batch, j < win*k_per_group.  shift_dev: device int (nullable = 0) so a captured graph can be
+ * replayed with a new shift.  Head h uses columns {q,k,v}_off + h*ch.  impl: 0 auto, 1 force the VALU kernel. */
+int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off, int v_off, void* O,
+                 int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch, int q_per_group,
+                 int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev, int impl, void* stream);
+/* Self-attention over short strided slices (temporal attention '(b h w) c f', unet:489-490): rows hold
+ * [q(C)|k(C)|v(C)]; slice geometry as mmd_gn_stats; Tn <= 32. */
+int mmd_attn_small_fwd(int dtype, const void* QKV, int64_t ld, void* O, int64_t ldo, int C, int heads, int S, int Tn, int inner,
+                       int64_t outer_stride, int64_t inner_stride, int64_t tstride, void* stream);
+
+/* Downsample (avg-pool, mode 0) / Upsample (nearest, mode 1) by (1, fh, fw) on rows (nf, h, w)
+ * (unet:133-208: video (1,2,2); audio F=1,H=1,W=L, fw=4).  H, W describe the INPUT. */
+int mmd_resample(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int NF, int H, int W, int fh, int fw,
+                 int mode, void* stream);
+/* 2-D strided copy (skip-connection concat th.cat, unet:1093-1094). */
+int mmd_copy2d(const void* x, int64_t ldx_bytes, void* y, int64_t ldy_bytes, int64_t rows, int64_t row_bytes, void* stream);
+
+/* Stem: API layout fp32 x[N,F,Cin,H,W] (audio F=1,H=1,W=L) -> channels-last rows; W fp32 [ntaps][Cin][Cout]
+ * (InitialBlock, unet:680-694: spatial 3x3 half of the 2d+1d conv, and the audio k=3 conv). */
+int mmd_stem_conv(int dtype, const float* x, const float* w, const float* bias, void* y, int64_t ldy, int N, int F, int Cin,
+                  int H, int W, int Cout, int ntaps, const int* taps, void* stream);
+/* Head: channels-last rows (after GN+SiLU) -> API layout fp32 y[N,F,Co,H,W]; W fp32 [ntaps][Cin][Co], Co <= 8
+ * (video_out Conv3d 3x3x3 / audio_out Conv1d k3, unet:1003-1012). */
+int mmd_head_conv(int dtype, const void* x, int64_t ldx, const float* w, const float* bias, float* y, int N, int F, int Cin,
+                  int H, int W, int Co, int ntaps, const int* taps, void* stream);
+
+/* One DDPM ancestral step for one stream (p_mean_variance + p_sample, multimodal_gaussian_diffusion.py:231-343,
+ * 415-474) on API-layout fp32 tensors x/noise/out [N,F,C,HW], model_out [N,F,Cm,HW] (Cm = 2C with flag 4).
+ * tables fp32 [7][T]: sqrt_recip_ac, sqrt_recipm1_ac, post_c1, post_c2, fixed logvar, min_log, max_log;
+ * t int64[N] device.  flags: 1 clip x0, 2 model predicts x0, 4 learned-range variance.  x0_out nullable. */
+int mmd_ddpm_update(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, const float* tables,
+                    const int64_t* t, int T, int N, int F, int C, int HW, int flags, void* stream);
+/* q_sample (gd:187-205): out = tab2[0][t] x0 + tab2[1][t] eps. */
+int mmd_q_sample(const float* x0, const float* eps, float* out, const float* tab2, const int64_t* t, int T, int N,
+                 int64_t per_sample, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,565 @@
+// Attention kernels on channels-last qkv rows.
+//
+// One problem description covers every attention of the reference hot path:
+//   * SingleModalQKVAttention spatial / audio self-attention   (multimodal_unet.py:212-240)
+//   * QKVAttention = random-shift windowed cross-modal attention (RS-MMA), both directions
+//     (multimodal_unet.py:507-564) with the window addressed arithmetically
+//     keys(group i) = rows k_batch + ((i + shift) * k_per_group + j) mod k_mod, j < win * k_per_group
+//     (the reference materialises [F*HW x win*L/F] int64 index matrices, unet:614-647, to read F rows)
+//   * the last query group owns the remainder rows (unet:547-548)
+// q/k/v live in the qkv GEMM output rows: q at column q_off + h*ch, k at k_off + h*ch, v at v_off + h*ch.
+//
+// attn_mfma_kernel (bf16, ch in {16,32,48,64,96,128}): flash-style, 4 waves x 32 queries, 64-key tiles.
+//   S^T = K Q^T on v_mfma_f32_32x32x16_bf16 (keys = D rows, queries = D cols: every lane owns ONE query,
+//   so running max / sum / rescale are lane-local plus one lane^32 exchange), P stays in registers and is
+//   the B operand of O^T = V^T P^T (the 32x32 C layout of S^T is exactly the k-slot order we feed, with V^T
+//   staged key-permuted to match), K row-major / V transposed in LDS with conflict-free strides.
+// attn_generic_kernel (fp32 math, any ch <= 128): LDS-tiled VALU flash attention - fp32 mode and odd shapes.
+// attn_small_kernel: one wave per (slice, head) for short sequences (temporal attention, T = F <= 32).
+#include "mmd_common.h"
+
+struct AttnParams {
+  const char* Q; int64_t ldq;
+  const char* KV; int64_t ldkv;
+  char* O; int64_t ldo;
+  int q_off, k_off, v_off;
+  int heads, ch;
+  int nb, G;
+  int64_t q_rows_per_batch;
+  int q_per_group;
+  int64_t k_rows_per_batch;   // = k_mod
+  int k_per_group, win;
+  const int* shift_ptr;
+  float scale;                // ch^-1/2  (= (ch^-1/4)^2, reference scales q and k separately)
+};
+
+struct GroupInfo {
+  int64_t q_row0, k_row0;
+  int q_count, k_count, k_start;
+  int k_mod;
+};
+
+__device__ __forceinline__ GroupInfo group_info(const AttnParams& p, int bg) {
+  GroupInfo gi;
+  const int n = bg / p.G, g = bg % p.G;
+  gi.q_row0 = (int64_t)n * p.q_rows_per_batch + (int64_t)g * p.q_per_group;
+  gi.q_count = (g == p.G - 1) ? (int)(p.q_rows_per_batch - (int64_t)g * p.q_per_group) : p.q_per_group;
+  gi.k_row0 = (int64_t)n * p.k_rows_per_batch;
+  gi.k_mod = (int)p.k_rows_per_batch;
+  gi.k_count = p.win * p.k_per_group;
+  const int shift = p.shift_ptr ? *p.shift_ptr : 0;
+  gi.k_start = (int)(((int64_t)(g + shift) * p.k_per_group) % gi.k_mod);
+  return gi;
+}
+__device__ __forceinline__ int64_t key_row(const GroupInfo& gi, int kk) {
+  int r = gi.k_start + kk;
+  if (r >= gi.k_mod) r -= gi.k_mod;
+  return gi.k_row0 + r;
+}
+
+// ============================================================================= MFMA flash attention (bf16)
+#define SVT_STRIDE 136   // bytes per V^T row (64 keys * 2 B + 8): (stride/8) odd -> conflict-free ds_read_b64
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+  constexpr int DV = D / 8;            // 16-byte vecs per row
+  constexpr int SK = D * 2 + 16;       // bytes per K row in LDS ((SK/16) odd)
+  constexpr int KST = D / 16;          // k-steps of the S MFMA
+  constexpr int DT = (D + 31) / 32;    // 32-wide d tiles of O^T
+  constexpr int NK = (64 * DV + 255) / 256;   // staged vecs per thread per operand
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                     // [64][SK]
+  char* sVt = smem + 64 * SK;          // [DT*32][SVT_STRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  const GroupInfo gi = group_info(p, blockIdx.z);
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= gi.q_count) return;        // uniform per block
+
+  // zero the V^T rows beyond D once (D=16/48: upper half of a 32-row tile is never staged)
+  if (D % 32 != 0) {
+    for (int i = tid; i < (DT * 32 - D) * SVT_STRIDE / 4; i += 256) ((uint32_t*)(sVt + D * SVT_STRIDE))[i] = 0u;
+  }
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l31, half) holds d = 16*s + 8*half + [0,8)
+  const int qi = q0 + wave * 32 + l31;
+  const bool qok = qi < gi.q_count;
+  u32x4 qf[KST];
+  {
+    const char* qp = p.Q + ((gi.q_row0 + qi) * p.ldq + p.q_off + h * D) * 2;
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qok) v = *(const u32x4*)(qp + (s * 16 + half * 8) * 2);
+      qf[s] = v;
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
+
+  u32x4 rk[NK], rv[NK];
+  const int ntiles = (gi.k_count + 63) >> 6;
+
+  auto load_kv = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const int id = tid + 256 * i;
+      // K: row-major, DV lanes per key row (coalesced)
+      {
+        const int j = id / DV, v = id % DV;
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (id < 64 * DV && kt0 + j < gi.k_count)
+          x = *(const u32x4*)(p.KV + (key_row(gi, kt0 + j) * p.ldkv + p.k_off + h * D + v * 8) * 2);
+        rk[i] = x;
+      }
+      // V: 32 keys x 2 d-vecs per wave instruction (conflict-free transposed ds_write_b16)
+      {
+        const int j = (id & 31) + 32 * ((id >> 6) & 1);
+        const int v = 2 * (id >> 7) + ((id >> 5) & 1);
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (id < 64 * DV && kt0 + j < gi.k_count)
+          x = *(const u32x4*)(p.KV + (key_row(gi, kt0 + j) * p.ldkv + p.v_off + h * D + v * 8) * 2);
+        rv[i] = x;
+      }
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const int id = tid + 256 * i;
+      if (id < 64 * DV) {
+        {
+          const int j = id / DV, v = id % DV;
+          *(u32x4*)(sK + j * SK + v * 16) = rk[i];
+        }
+        {
+          const int j = (id & 31) + 32 * ((id >> 6) & 1);
+          const int v = 2 * (id >> 7) + ((id >> 5) & 1);
+          uint16_t* dst = (uint16_t*)(sVt + (8 * v) * SVT_STRIDE + 2 * j);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            dst[e * (SVT_STRIDE / 2)] = (uint16_t)((rv[i][e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        }
+      }
+    }
+  };
+
+  load_kv(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();          // previous tile fully consumed
+    store_kv();
+    __syncthreads();
+    if (t + 1 < ntiles) load_kv((t + 1) * 64);   // in flight during the MFMAs below
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const char* kb = sK + (kt * 32 + l31) * SK + half * 16;
+#pragma unroll
+      for (int st = 0; st < KST; ++st) {
+        const u32x4 kf = *(const u32x4*)(kb + st * 32);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[st]), s[kt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (lane-local row; partner lane^32 holds the other 32 keys)
+    const int kbase = t * 64 + 4 * half;
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = kbase + 32 * kt + (r & 3) + 8 * (r >> 2);
+        float v = s[kt][r] * sc;
+        v = kk < gi.k_count ? v : -1e30f;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+        s[kt][r] = e;
+        ps += e;
+      }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    // ---- O^T += V^T P^T : P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * st + j];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const char* vb = sVt + (dt * 32 + l31) * SVT_STRIDE + (32 * kt + 16 * st + 4 * half) * 2;
+          const u32x2 v0 = *(const u32x2*)(vb);
+          const u32x2 v1 = *(const u32x2*)(vb + 16);
+          u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+        }
+      }
+  }
+  // ---- normalise and store: lane owns query qi, d = 32*dt + (r&3) + 8*(r>>2) + 4*half
+  if (qok) {
+    const float inv = 1.f / l_run;
+    char* op = p.O + ((gi.q_row0 + qi) * p.ldo + h * D) * 2;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * half;
+        if (d < D) {
+          bf16x4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = (__bf16)(o[dt][4 * q4 + j] * inv);
+          *(bf16x4*)(op + d * 2) = w;
+        }
+      }
+  }
+}
+
+// ============================================================================= generic VALU flash attention
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ch = p.ch;
+  const int LQ = ch + 1;
+  float* sQ = (float*)smem;            // [64][ch+1]  (pre-scaled)
+  float* sK = sQ + 64 * LQ;            // [64][ch+1]
+  float* sV = sK + 64 * LQ;            // [64][ch]
+  float* sS = sV + 64 * ch;            // [64][65]
+  float* sM = sS + 64 * 65;            // [64] running max
+  float* sL = sM + 64;                 // [64] running sum
+  float* sAl = sL + 64;                // [64] rescale of this tile
+
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y;
+  const GroupInfo gi = group_info(p, blockIdx.z);
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= gi.q_count) return;
+  const int ty = tid >> 4, tx = tid & 15;
+
+  for (int i = tid; i < 64 * ch; i += 256) {
+    const int r = i / ch, d = i % ch;
+    float v = 0.f;
+    if (q0 + r < gi.q_count) v = Elt<T>::ld(p.Q, (gi.q_row0 + q0 + r) * p.ldq + p.q_off + h * ch + d) * p.scale;
+    sQ[r * LQ + d] = v;
+  }
+  if (tid < 64) { sM[tid] = -1e30f; sL[tid] = 0.f; }
+  float oacc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) oacc[a][b] = 0.f;
+
+  const int ntiles = (gi.k_count + 63) >> 6;
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+    for (int i = tid; i < 64 * ch; i += 256) {
+      const int r = i / ch, d = i % ch;
+      float kv = 0.f, vv = 0.f;
+      if (t * 64 + r < gi.k_count) {
+        const int64_t row = key_row(gi, t * 64 + r);
+        kv = Elt<T>::ld(p.KV, row * p.ldkv + p.k_off + h * ch + d);
+        vv = Elt<T>::ld(p.KV, row * p.ldkv + p.v_off + h * ch + d);
+      }
+      sK[r * LQ + d] = kv;
+      sV[r * ch + d] = vv;
+    }
+    __syncthreads();
+    // S block: rows ty*4.., keys tx*4..
+    float sacc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sacc[a][b] = 0.f;
+    for (int d = 0; d < ch; ++d) {
+      float qa[4], kb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) qa[a] = sQ[(ty * 4 + a) * LQ + d];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) kb[b] = sK[(tx * 4 + b) * LQ + d];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sacc[a][b] += qa[a] * kb[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int kk = t * 64 + tx * 4 + b;
+        sS[(ty * 4 + a) * 65 + tx * 4 + b] = kk < gi.k_count ? sacc[a][b] : -1e30f;
+      }
+    __syncthreads();
+    // row softmax update: 4 threads per row
+    {
+      const int r = tid >> 2, part = tid & 3;
+      float mx = -1e30f;
+      for (int k = part * 16; k < part * 16 + 16; ++k) mx = fmaxf(mx, sS[r * 65 + k]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      const float m_old = sM[r];
+      const float m_new = fmaxf(m_old, mx);
+      float sum = 0.f;
+      for (int k = part * 16; k < part * 16 + 16; ++k) {
+        const float e = __expf(sS[r * 65 + k] - m_new);
+        sS[r * 65 + k] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      __syncthreads();   // everyone has read sM[r] before it is overwritten
+      if (part == 0) {
+        const float al = __expf(m_old - m_new);
+        sAl[r] = al;
+        sL[r] = sL[r] * al + sum;
+        sM[r] = m_new;
+      }
+    }
+    __syncthreads();
+    // O update: rows ty*4.., columns tx + 16*b
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float al = sAl[ty * 4 + a];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) oacc[a][b] *= al;
+    }
+    for (int k = 0; k < 64; ++k) {
+      float pv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) pv[a] = sS[(ty * 4 + a) * 65 + k];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int d = tx + 16 * b;
+        if (d < ch) {
+          const float vv = sV[k * ch + d];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) oacc[a][b] += pv[a] * vv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = ty * 4 + a;
+    if (q0 + r < gi.q_count) {
+      const float inv = 1.f / sL[r];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int d = tx + 16 * b;
+        if (d < ch) Elt<T>::st(p.O, (gi.q_row0 + q0 + r) * p.ldo + h * ch + d, oacc[a][b] * inv);
+      }
+    }
+  }
+}
+
+// ============================================================================= short-sequence attention
+struct SmallAttnParams {
+  const char* QKV; int64_t ld;
+  char* O; int64_t ldo;
+  int C, heads, ch;
+  int S, Tn, inner;
+  int64_t outer_stride, inner_stride, tstride;
+  float scale;
+};
+
+// One wave per (slice, head); lane = (query qi = lane/4 [+16], d-quarter dq = lane%4).
+template <typename T, int CHQ>
+__global__ __launch_bounds__(256) void attn_small_kernel(const SmallAttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ch = CHQ * 4;
+  const int Tn = p.Tn;
+  float* sK = (float*)smem + wave * 2 * 32 * ch;   // [Tn][ch]
+  float* sV = sK + 32 * ch;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  const bool active = item < (int64_t)p.S * p.heads;
+  const int s = active ? (int)(item / p.heads) : 0, h = active ? (int)(item % p.heads) : 0;
+  const int64_t base = (int64_t)(s / p.inner) * p.outer_stride + (int64_t)(s % p.inner) * p.inner_stride;
+  if (active) {
+    for (int i = lane; i < Tn * ch; i += 64) {
+      const int j = i / ch, d = i % ch;
+      const int64_t row = base + (int64_t)j * p.tstride;
+      sK[j * ch + d] = Elt<T>::ld(p.QKV, row * p.ld + p.C + h * ch + d);
+      sV[j * ch + d] = Elt<T>::ld(p.QKV, row * p.ld + 2 * p.C + h * ch + d);
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const int dq = lane & 3;
+  for (int qb = 0; qb < Tn; qb += 16) {
+    const int qi = qb + (lane >> 2);
+    const bool ok = qi < Tn;
+    float q[CHQ];
+    {
+      const int64_t row = base + (int64_t)(ok ? qi : 0) * p.tstride;
+#pragma unroll
+      for (int d = 0; d < CHQ; ++d) q[d] = Elt<T>::ld(p.QKV, row * p.ld + h * ch + dq * CHQ + d) * p.scale;
+    }
+    float sc[32];
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      float a = 0.f;
+      if (j < Tn) {
+#pragma unroll
+        for (int d = 0; d < CHQ; ++d) a += q[d] * sK[j * ch + dq * CHQ + d];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        mx = fmaxf(mx, a);
+      }
+      sc[j] = a;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float e = j < Tn ? __expf(sc[j] - mx) : 0.f;
+      sc[j] = e;
+      sum += e;
+    }
+    float o[CHQ];
+#pragma unroll
+    for (int d = 0; d < CHQ; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < Tn) {
+#pragma unroll
+        for (int d = 0; d < CHQ; ++d) o[d] += sc[j] * sV[j * ch + dq * CHQ + d];
+      }
+    }
+    if (ok) {
+      const float inv = 1.f / sum;
+      const int64_t row = base + (int64_t)qi * p.tstride;
+#pragma unroll
+      for (int d = 0; d < CHQ; ++d) Elt<T>::st(p.O, row * p.ldo + h * ch + dq * CHQ + d, o[d] * inv);
+    }
+  }
+}
+
+// ============================================================================= C-ABI
+template <int D>
+static int launch_mfma(const AttnParams& p, int qmax, hipStream_t st) {
+  constexpr int SK = D * 2 + 16;
+  constexpr int DT = (D + 31) / 32;
+  const size_t lds = 64 * SK + DT * 32 * SVT_STRIDE;
+  dim3 grid(cdiv(qmax, 128), p.heads, p.nb * p.G);
+  hipLaunchKernelGGL(attn_mfma_kernel<D>, grid, dim3(256), lds, st, p);
+  return mmd_check_launch("attn_mfma");
+}
+
+template <typename T>
+static int launch_generic(const AttnParams& p, int qmax, hipStream_t st) {
+  const size_t lds = (size_t)(64 * (p.ch + 1) * 2 + 64 * p.ch + 64 * 65 + 192) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_generic_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_generic: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(qmax, 64), p.heads, p.nb * p.G);
+  hipLaunchKernelGGL(attn_generic_kernel<T>, grid, dim3(256), lds, st, p);
+  return mmd_check_launch("attn_generic");
+}
+
+// impl: 0 = auto (MFMA when dtype is bf16 and ch is supported), 1 = force generic VALU kernel
+extern "C" int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off,
+                            int v_off, void* O, int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch,
+                            int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev,
+                            int impl, void* stream) {
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "attn_fwd: bad dtype %d", dtype);
+  MMD_REQUIRE(Q && KV && O, "attn_fwd: null pointer");
+  MMD_REQUIRE(heads > 0 && ch > 0 && ch <= 128 && nb > 0 && G > 0, "attn_fwd: bad heads/ch/nb/G (%d,%d,%d,%d)", heads, ch, nb, G);
+  MMD_REQUIRE(q_per_group > 0 && (int64_t)(G - 1) * q_per_group < q_rows_per_batch, "attn_fwd: bad query grouping");
+  MMD_REQUIRE(k_per_group > 0 && win > 0 && (int64_t)win * k_per_group <= k_rows_per_batch, "attn_fwd: key window exceeds the key rows");
+  AttnParams p;
+  p.Q = (const char*)Q; p.ldq = ldq; p.KV = (const char*)KV; p.ldkv = ldkv; p.O = (char*)O; p.ldo = ldo;
+  p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.heads = heads; p.ch = ch; p.nb = nb; p.G = G;
+  p.q_rows_per_batch = q_rows_per_batch; p.q_per_group = q_per_group; p.k_rows_per_batch = k_rows_per_batch;
+  p.k_per_group = k_per_group; p.win = win; p.shift_ptr = shift_dev;
+  p.scale = 1.0f / sqrtf((float)ch);
+  const int qmax = (int)(q_rows_per_batch - (int64_t)(G - 1) * q_per_group);   // last group is the largest
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned = ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 &&
+                       ((uintptr_t)Q | (uintptr_t)KV) % 16 == 0 && (uintptr_t)O % 8 == 0;
+  if (dtype == MMD_BF16 && impl == 0 && aligned) {
+    switch (ch) {
+      case 16: return launch_mfma<16>(p, qmax, st);
+      case 32: return launch_mfma<32>(p, qmax, st);
+      case 48: return launch_mfma<48>(p, qmax, st);
+      case 64: return launch_mfma<64>(p, qmax, st);
+      case 96: return launch_mfma<96>(p, qmax, st);
+      case 128: return launch_mfma<128>(p, qmax, st);
+      default: break;
+    }
+  }
+  if (dtype == MMD_BF16) return launch_generic<__bf16>(p, qmax, st);
+  return launch_generic<float>(p, qmax, st);
+}
+
+template <typename T, int CHQ>
+static int launch_small(const SmallAttnParams& p, hipStream_t st) {
+  const size_t lds = (size_t)4 * 2 * 32 * (CHQ * 4) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_small_kernel<T, CHQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_small: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int64_t items = (int64_t)p.S * p.heads;
+  hipLaunchKernelGGL((attn_small_kernel<T, CHQ>), dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, p);
+  return mmd_check_launch("attn_small");
+}
+
+template <typename T>
+static int dispatch_small(const SmallAttnParams& p, hipStream_t st) {
+  switch (p.ch) {
+    case 16: return launch_small<T, 4>(p, st);
+    case 32: return launch_small<T, 8>(p, st);
+    case 48: return launch_small<T, 12>(p, st);
+    case 64: return launch_small<T, 16>(p, st);
+    case 96: return launch_small<T, 24>(p, st);
+    case 128: return launch_small<T, 32>(p, st);
+    default: return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_small: head width %d not in {16,32,48,64,96,128}", p.ch);
+  }
+}
+
+// Self-attention over short slices (temporal attention: slices = pixels, Tn = frames <= 32).
+// qkv rows hold [q(C) | k(C) | v(C)], head h = channels h*ch .. (h+1)*ch of each third.
+extern "C" int mmd_attn_small_fwd(int dtype, const void* QKV, int64_t ld, void* O, int64_t ldo, int C, int heads, int S,
+                                  int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride,
+                                  void* stream) {
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "attn_small: bad dtype %d", dtype);
+  MMD_REQUIRE(QKV && O && C > 0 && heads > 0 && C % heads == 0, "attn_small: bad argument");
+  MMD_REQUIRE(Tn >= 1 && Tn <= 32, "attn_small: sequence length %d not in [1,32]", Tn);
+  SmallAttnParams p;
+  p.QKV = (const char*)QKV; p.ld = ld; p.O = (char*)O; p.ldo = ldo; p.C = C; p.heads = heads; p.ch = C / heads;
+  p.S = S; p.Tn = Tn; p.inner = inner; p.outer_stride = outer_stride; p.inner_stride = inner_stride; p.tstride = tstride;
+  p.scale = 1.0f / sqrtf((float)p.ch);
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == MMD_BF16 ? dispatch_small<__bf16>(p, st) : dispatch_small<float>(p, st);
+}

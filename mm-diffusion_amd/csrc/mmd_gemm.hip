@@ -1,0 +1,266 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// Replaces, for channels-last activations X[rows, Cin] (row stride lda):
+//   * VideoConv '2d+1d' spatial 3x3 / temporal k=3   (reference multimodal_unet.py:83-99)
+//   * VideoConv '3d' k=1 (ResBlock out conv, skip, cross-attn proj, unet:378,401,609)
+//   * AudioConv k=3 dilated / k=1                     (unet:108-131)
+//   * every qkv / proj_out 1x1 Conv1d of the attention blocks (unet:272,275,605-606)
+// as  Y[m, co] = bias[co] + sum_tap sum_ci X[src(m,tap), ci] * W[co, tap*Cin + ci]  (+ R[m, co])
+// where src(m,tap) offsets the row position (p0,p1,p2) of m by the tap and zero-pads out of range.
+//
+// Mapping: 256 threads = 4 waves in a 2(co) x 2(m) grid, block tile BM x BN, K step = 128 bytes per
+// row (64 bf16 / 32 fp32).  Operands are staged global -> VGPR -> LDS (144-byte padded rows: every
+// 16-lane ds_read_b128 group is conflict free) with register prefetch of the next K step while the
+// current one feeds v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact fp32).
+// The weights are the MFMA A operand (D rows = co) so each lane owns 4 consecutive output channels;
+// the accumulators are staged through LDS in fp32 and written with 16-byte coalesced row stores with
+// bias and residual folded in.
+#include "mmd_common.h"
+
+struct ConvGemmParams {
+  const char* A; int64_t lda;
+  const char* W;
+  const float* bias;
+  const char* R; int64_t ldr;
+  char* Y; int64_t ldy;
+  int M, Cout, Cin, ntaps;
+  int D0, D1, D2;
+  int taps[27 * 3];
+};
+
+#define ROWB 144   // LDS bytes per staged operand row
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // 16 bytes = 4 consecutive k per half-wave; MFMA j pairs k=j (lanes 0-31) with k=4+j (lanes 32-63).
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;            // element size in bytes
+  constexpr int AR = BM / 32, WR = BN / 32;   // rows staged per thread
+  constexpr int TCO = BN / 64, TMM = BM / 64; // 32x32 tiles per wave
+  constexpr int LDC = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                          // [2][BM][ROWB]
+  char* sW = smem + 2 * BM * ROWB;          // [2][BN][ROWB]
+  float* sC = (float*)smem;                 // [BM][LDC] (epilogue, aliases the operand buffers)
+  // tap table lives behind the operand/epilogue region (all LDS in ONE dynamic array: keeps the base 16-B aligned)
+  constexpr int MAIN_B = (2 * (BM + BN) * ROWB > BM * LDC * 4) ? 2 * (BM + BN) * ROWB : BM * LDC * 4;
+  int* s_taps = (int*)(smem + MAIN_B);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wc = wave & 1, wr = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  if (tid < p.ntaps * 3) s_taps[tid] = p.taps[tid];
+
+  // XCD-aware tile order: consecutive tiles (sharing activation halos / weight panels) stay on one L2
+  const int Nt = (p.Cout + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wgid % Nt, mt = wgid / Nt;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int CinV = p.Cin / EPV;
+  const int KV = CinV * p.ntaps;
+  const int64_t K = (int64_t)p.Cin * p.ntaps;
+  const int nit = (KV + 7) >> 3;
+  const int cv = tid & 7, r0 = tid >> 3;
+  const int D12 = p.D1 * p.D2;
+
+  int pp0[AR], pp1[AR], pp2[AR];
+  int64_t arow[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    arow[i] = (int64_t)m;
+    if (m < p.M) {
+      pp2[i] = m % p.D2;
+      pp1[i] = (m / p.D2) % p.D1;
+      pp0[i] = (m / D12) % p.D0;
+    } else {
+      pp0[i] = pp1[i] = pp2[i] = -(1 << 28);
+    }
+  }
+  int tap = cv / CinV, civ = cv % CinV;
+  int kv = cv;
+
+  u32x4 ra[AR], rw[WR];
+  __syncthreads();   // s_taps visible
+
+  auto load_tile = [&]() {
+    const bool tapok = tap < p.ntaps;
+    int o0 = 0, o1 = 0, o2 = 0;
+    if (tapok) { o0 = s_taps[tap * 3]; o1 = s_taps[tap * 3 + 1]; o2 = s_taps[tap * 3 + 2]; }
+    const int64_t roff = (int64_t)o0 * D12 + o1 * p.D2 + o2;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const bool ok = tapok && (unsigned)(pp0[i] + o0) < (unsigned)p.D0 &&
+                      (unsigned)(pp1[i] + o1) < (unsigned)p.D1 && (unsigned)(pp2[i] + o2) < (unsigned)p.D2;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *(const u32x4*)(p.A + ((arow[i] + roff) * p.lda + (int64_t)civ * EPV) * ES);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const int co = n0 + r0 + 32 * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (co < p.Cout && kv < KV) v = *(const u32x4*)(p.W + ((int64_t)co * K + (int64_t)kv * EPV) * ES);
+      rw[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      *(u32x4*)(sA + buf * BM * ROWB + (r0 + 32 * i) * ROWB + cv * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+      *(u32x4*)(sW + buf * BN * ROWB + (r0 + 32 * i) * ROWB + cv * 16) = rw[i];
+  };
+  auto advance = [&]() {
+    kv += 8;
+    civ += 8;
+    while (civ >= CinV) { civ -= CinV; ++tap; }
+  };
+
+  f32x16 acc[TCO][TMM];
+#pragma unroll
+  for (int a = 0; a < TCO; ++a)
+#pragma unroll
+    for (int b = 0; b < TMM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < nit; ++it) {
+    const bool more = it + 1 < nit;
+    if (more) { advance(); load_tile(); }
+    const char* bW = sW + cur * BN * ROWB + (wc * (BN / 2) + l31) * ROWB + half * 16;
+    const char* bA = sA + cur * BM * ROWB + (wr * (BM / 2) + l31) * ROWB + half * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      u32x4 fw[TCO], fa[TMM];
+#pragma unroll
+      for (int a = 0; a < TCO; ++a) fw[a] = *(const u32x4*)(bW + a * 32 * ROWB + c * 32);
+#pragma unroll
+      for (int b = 0; b < TMM; ++b) fa[b] = *(const u32x4*)(bA + b * 32 * ROWB + c * 32);
+#pragma unroll
+      for (int a = 0; a < TCO; ++a)
+#pragma unroll
+        for (int b = 0; b < TMM; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: acc -> LDS (fp32, [m][co]) -> coalesced 16-byte row stores
+#pragma unroll
+  for (int a = 0; a < TCO; ++a)
+#pragma unroll
+    for (int b = 0; b < TMM; ++b) {
+      const int ml = wr * (BM / 2) + b * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = wc * (BN / 2) + a * 32 + 8 * q + 4 * half;
+        f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        *(f32x4*)(sC + ml * LDC + col) = v;
+      }
+    }
+  __syncthreads();
+  constexpr int CVN = BN / 8;          // 8-channel groups per row
+  constexpr int RP = 256 / CVN;        // rows per pass
+  const int cg = tid % CVN, rr = tid / CVN;
+  const int co = n0 + cg * 8;
+  if (co < p.Cout) {
+    float bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
+#pragma unroll 2
+    for (int ml = rr; ml < BM; ml += RP) {
+      const int m = m0 + ml;
+      if (m >= p.M) break;
+      float v[8];
+      const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + cg * 8);
+      const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + cg * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
+      if (p.R) {
+#pragma unroll
+        for (int h = 0; h < 8 / EPV; ++h) {
+          float rf[EPV];
+          Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 8 / EPV; ++h)
+        *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
+    }
+  }
+}
+
+template <typename T, int BM, int BN>
+static int launch_conv_gemm(const ConvGemmParams& p, hipStream_t st) {
+  const size_t lds_ops = 2 * (size_t)(BM + BN) * ROWB;
+  const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+  const size_t lds = (lds_ops > lds_c ? lds_ops : lds_c) + 336;   // + tap table
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<T, BM, BN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = cdiv(p.M, BM) * cdiv(p.Cout, BN);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, st, p);
+  return mmd_check_launch("conv_gemm");
+}
+
+extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias,
+                             const void* R, int64_t ldr, void* Y, int64_t ldy, int M, int Cout, int Cin,
+                             int ntaps, const int* taps, int D0, int D1, int D2, int tile, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_gemm: bad dtype %d", dtype);
+  MMD_REQUIRE(A && W && Y && M > 0 && Cout > 0 && Cin > 0, "conv_gemm: null/empty argument");
+  MMD_REQUIRE(ntaps >= 1 && ntaps <= 27 && taps, "conv_gemm: ntaps %d out of [1,27]", ntaps);
+  MMD_REQUIRE(Cin % epv == 0, "conv_gemm: Cin %d must be a multiple of %d", Cin, epv);
+  MMD_REQUIRE(Cout % 8 == 0, "conv_gemm: Cout %d must be a multiple of 8", Cout);
+  MMD_REQUIRE(lda % epv == 0 && ldy % epv == 0 && (!R || ldr % epv == 0), "conv_gemm: row strides must be 16-byte multiples");
+  MMD_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)R) % 16 == 0, "conv_gemm: pointers must be 16-byte aligned");
+  MMD_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "conv_gemm: bad position dims");
+  ConvGemmParams p;
+  p.A = (const char*)A; p.lda = lda; p.W = (const char*)W; p.bias = bias;
+  p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
+  p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
+  for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
+  hipStream_t st = (hipStream_t)stream;
+  if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
+  if (dtype == MMD_BF16) {
+    if (tile == 128) return launch_conv_gemm<__bf16, 128, 128>(p, st);
+    return launch_conv_gemm<__bf16, 64, 64>(p, st);
+  }
+  if (tile == 128) return launch_conv_gemm<float, 128, 128>(p, st);
+  return launch_conv_gemm<float, 64, 64>(p, st);
+}

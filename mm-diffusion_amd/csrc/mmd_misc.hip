@@ -1,0 +1,370 @@
+// Small / bandwidth-bound kernels of the denoising step:
+//   timestep embedding + MLP (nn.py:192-210, multimodal_unet.py:791-795,1075), batched emb_layers Linear
+//   (unet:366-372), avg-pool / nearest resampling (unet:133-208), the stem (InitialBlock, unet:680-694) and
+//   head (unet:1003-1012) convolutions at the API layout edge, skip-concat copies (unet:1093-1094) and the
+//   fused DDPM ancestral update (multimodal_gaussian_diffusion.py:231-343 get_variance + 453-470 p_sample).
+#include "mmd_common.h"
+
+// ----------------------------------------------------------------------------- timestep embedding + MLP
+// one block per sample; out_silu = SiLU(W2 SiLU(W0 e + b0) + b2), out_raw (optional) = without the last SiLU
+__global__ __launch_bounds__(256) void temb_kernel(const void* __restrict__ t, int t_kind, int dim, const float* __restrict__ W0,
+                                                   const float* __restrict__ b0, const float* __restrict__ W2,
+                                                   const float* __restrict__ b2, float* __restrict__ out_silu,
+                                                   float* __restrict__ out_raw) {
+  extern __shared__ float sm[];
+  float* e = sm;          // [dim]
+  float* h = sm + dim;    // [dim]
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float tv;
+  if (t_kind == 0) tv = (float)((const int64_t*)t)[n];
+  else if (t_kind == 1) tv = (float)((const int32_t*)t)[n];
+  else tv = ((const float*)t)[n];
+  const int half = dim / 2;
+  for (int i = tid; i < dim; i += 256) {
+    float v = 0.f;
+    if (i < 2 * half) {
+      const int k = i < half ? i : i - half;
+      const float f = expf(-logf(10000.f) * (float)k / (float)half);
+      const float a = tv * f;
+      v = i < half ? cosf(a) : sinf(a);
+    }
+    e[i] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < dim; j += 256) {
+    float a = b0[j];
+    for (int k = 0; k < dim; ++k) a += W0[j * dim + k] * e[k];
+    h[j] = silu_f(a);
+  }
+  __syncthreads();
+  for (int j = tid; j < dim; j += 256) {
+    float a = b2[j];
+    for (int k = 0; k < dim; ++k) a += W2[j * dim + k] * h[k];
+    if (out_raw) out_raw[n * dim + j] = a;
+    out_silu[n * dim + j] = silu_f(a);
+  }
+}
+
+// y[n, j] = b[j] + sum_k x[n,k] W[j,k] ; one wave per output column j, all n (N <= 16)
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ b, float* __restrict__ y, int N, int K, int J) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= J) return;
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float w = W[(int64_t)j * K + k];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n0 + i < N) acc[i] += w * x[(int64_t)(n0 + i) * K + k];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float s = wave_sum(acc[i]);
+      if (lane == 0 && n0 + i < N) y[(int64_t)(n0 + i) * J + j] = s + (b ? b[j] : 0.f);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- resampling (channels-last rows)
+// mode 0: average pool, mode 1: nearest upsample.  Rows are (n, f, h, w) with factors (1, fh, fw) - audio uses
+// F=1, H=1, W=L, fw=4.  Geometry given for the INPUT; output dims = in / factor (pool) or in * factor (up).
+template <typename T>
+__global__ __launch_bounds__(256) void resample_kernel(const char* __restrict__ x, int64_t ldx, char* __restrict__ y, int64_t ldy,
+                                                       int C, int NF, int H, int W, int fh, int fw, int mode) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  const int CV = C / EPV;
+  const int Ho = mode == 0 ? H / fh : H * fh, Wo = mode == 0 ? W / fw : W * fw;
+  const int64_t total = (int64_t)NF * Ho * Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const int64_t orow = i / CV;
+    const int wo = (int)(orow % Wo), ho = (int)((orow / Wo) % Ho);
+    const int64_t nf = orow / ((int64_t)Wo * Ho);
+    float acc[EPV];
+    if (mode == 0) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+      for (int a = 0; a < fh; ++a)
+        for (int b = 0; b < fw; ++b) {
+          const int64_t irow = (nf * H + ho * fh + a) * W + wo * fw + b;
+          float f[EPV];
+          Elt<T>::unpack(*(const u32x4*)(x + (irow * ldx + (int64_t)cv * EPV) * ES), f);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) acc[e] += f[e];
+        }
+      const float inv = 1.f / (float)(fh * fw);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) acc[e] *= inv;
+      *(u32x4*)(y + (orow * ldy + (int64_t)cv * EPV) * ES) = Elt<T>::pack(acc);
+    } else {
+      const int64_t irow = (nf * H + ho / fh) * W + wo / fw;
+      *(u32x4*)(y + (orow * ldy + (int64_t)cv * EPV) * ES) = *(const u32x4*)(x + (irow * ldx + (int64_t)cv * EPV) * ES);
+    }
+  }
+}
+
+// strided 2-D copy of 16-byte vecs (skip-connection concat: write a tensor into a column slice)
+__global__ __launch_bounds__(256) void copy2d_kernel(const char* __restrict__ x, int64_t ldx_b, char* __restrict__ y, int64_t ldy_b,
+                                                     int64_t rows, int vecs) {
+  const int64_t total = rows * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / vecs;
+    const int v = (int)(i % vecs);
+    *(u32x4*)(y + r * ldy_b + (int64_t)v * 16) = *(const u32x4*)(x + r * ldx_b + (int64_t)v * 16);
+  }
+}
+
+// ----------------------------------------------------------------------------- stem conv (API layout -> channels-last)
+// in : fp32 [N, F, Cin, H, W] (audio: F=1, H=1, W=L)   W packed fp32 [ntaps][Cin][Cout]   out: T [N*F*H*W, Cout]
+struct EdgeConvParams {
+  const float* x; const float* w; const float* bias;
+  char* y; int64_t ldy;
+  int N, F, Cin, H, W, Cout, ntaps;
+  int taps[27 * 3];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const EdgeConvParams p) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  extern __shared__ float sw[];    // [ntaps*Cin][Cout]
+  const int KW = p.ntaps * p.Cin;
+  for (int i = threadIdx.x; i < KW * p.Cout; i += 256) sw[i] = p.w[i];
+  __syncthreads();
+  const int CV = p.Cout / EPV;
+  const int HW = p.H * p.W;
+  const int64_t rows = (int64_t)p.N * p.F * HW;
+  const int64_t total = rows * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const int64_t m = i / CV;
+    const int w0 = (int)(m % p.W), h0 = (int)((m / p.W) % p.H), f0 = (int)((m / HW) % p.F);
+    const int64_t n = m / ((int64_t)HW * p.F);
+    float acc[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) acc[e] = p.bias ? p.bias[cv * EPV + e] : 0.f;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int f = f0 + p.taps[t * 3], h = h0 + p.taps[t * 3 + 1], w = w0 + p.taps[t * 3 + 2];
+      if ((unsigned)f >= (unsigned)p.F || (unsigned)h >= (unsigned)p.H || (unsigned)w >= (unsigned)p.W) continue;
+      for (int ci = 0; ci < p.Cin; ++ci) {
+        const float xv = p.x[(((n * p.F + f) * p.Cin + ci) * p.H + h) * p.W + w];
+        const float* wr = sw + (t * p.Cin + ci) * p.Cout + cv * EPV;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc[e] += xv * wr[e];
+      }
+    }
+    *(u32x4*)(p.y + (m * p.ldy + (int64_t)cv * EPV) * ES) = Elt<T>::pack(acc);
+  }
+}
+
+// ----------------------------------------------------------------------------- head conv (channels-last -> API layout)
+// in: T rows [N*F*H*W, Cin] (already GN+SiLU'd)   W packed fp32 [ntaps][Cin][Co] (Co <= 8)   out fp32 [N,F,Co,H,W]
+struct HeadConvParams {
+  const char* x; int64_t ldx; const float* w; const float* bias;
+  float* y;
+  int N, F, Cin, H, W, Co, ntaps;
+  int taps[27 * 3];
+};
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void head_conv_kernel(const HeadConvParams p) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  extern __shared__ float sw[];    // [ntaps*Cin][CO]
+  const int KW = p.ntaps * p.Cin;
+  for (int i = threadIdx.x; i < KW * CO; i += 256) {
+    const int co = i % CO;
+    sw[i] = co < p.Co ? p.w[(i / CO) * p.Co + co] : 0.f;
+  }
+  __syncthreads();
+  const int HW = p.H * p.W;
+  const int64_t rows = (int64_t)p.N * p.F * HW;
+  const int CinV = p.Cin / EPV;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < rows; m += (int64_t)gridDim.x * 256) {
+    const int w0 = (int)(m % p.W), h0 = (int)((m / p.W) % p.H), f0 = (int)((m / HW) % p.F);
+    const int64_t n = m / ((int64_t)HW * p.F);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = (p.bias && c < p.Co) ? p.bias[c] : 0.f;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int df = p.taps[t * 3], dh = p.taps[t * 3 + 1], dw = p.taps[t * 3 + 2];
+      if ((unsigned)(f0 + df) >= (unsigned)p.F || (unsigned)(h0 + dh) >= (unsigned)p.H || (unsigned)(w0 + dw) >= (unsigned)p.W) continue;
+      const int64_t src = m + (int64_t)df * HW + dh * p.W + dw;
+      const char* xr = p.x + src * p.ldx * ES;
+      const float* wt = sw + (int64_t)t * p.Cin * CO;
+      for (int v = 0; v < CinV; ++v) {
+        float f[EPV];
+        Elt<T>::unpack(*(const u32x4*)(xr + v * 16), f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e)
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[c] += f[e] * wt[(v * EPV + e) * CO + c];
+      }
+    }
+    const int hw = h0 * p.W + w0;
+    for (int c = 0; c < p.Co; ++c) p.y[((n * p.F + f0) * p.Co + c) * HW + hw] = acc[c];
+  }
+}
+
+// ----------------------------------------------------------------------------- fused DDPM ancestral update
+// tables: fp32 [7][T] rows = sqrt_recip_ac, sqrt_recipm1_ac, post_c1, post_c2, logvar_fixed, min_log, max_log
+// x, noise, out: fp32 [N, F, C, HW] ; model_out fp32 [N, F, Cm, HW] with Cm = C (fixed var) or 2C (learned range)
+// flags bit0: clip x0 to [-1,1], bit1: model predicts x0, bit2: learned-range variance
+struct DdpmParams {
+  const float* x; const float* mo; const float* noise; float* out; float* x0_out;
+  const float* tables; const int64_t* t;
+  int T, N, F, C, HW, flags;
+};
+__global__ __launch_bounds__(256) void ddpm_update_kernel(const DdpmParams p) {
+  const int64_t per = (int64_t)p.F * p.C * p.HW;
+  const int64_t total = per * p.N;
+  const int Cm = (p.flags & 4) ? 2 * p.C : p.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / per, r = i % per;
+    const int hw = (int)(r % p.HW), c = (int)((r / p.HW) % p.C);
+    const int64_t f = r / ((int64_t)p.HW * p.C);
+    const int ti = (int)p.t[n];
+    const float cr = p.tables[ti], crm1 = p.tables[p.T + ti], c1 = p.tables[2 * p.T + ti], c2 = p.tables[3 * p.T + ti];
+    const int64_t mbase = ((n * p.F + f) * Cm) * (int64_t)p.HW + hw;
+    const float o = p.mo[mbase + (int64_t)c * p.HW];
+    float logvar;
+    if (p.flags & 4) {
+      const float vv = p.mo[mbase + (int64_t)(c + p.C) * p.HW];
+      const float frac = (vv + 1.f) / 2.f;
+      logvar = frac * p.tables[6 * p.T + ti] + (1.f - frac) * p.tables[5 * p.T + ti];
+    } else {
+      logvar = p.tables[4 * p.T + ti];
+    }
+    const float xv = p.x[i];
+    float x0 = (p.flags & 2) ? o : cr * xv - crm1 * o;
+    if (p.flags & 1) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    const float mean = c1 * x0 + c2 * xv;
+    const float nz = ti != 0 ? 1.f : 0.f;
+    p.out[i] = mean + nz * expf(0.5f * logvar) * p.noise[i];
+    if (p.x0_out) p.x0_out[i] = x0;
+  }
+}
+
+// x_t = sqrt_ac[t] x0 + sqrt_1mac[t] eps   (q_sample, multimodal_gaussian_diffusion.py:187-205); tab2 = [2][T]
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ eps, float* __restrict__ out,
+                                                       const float* __restrict__ tab2, const int64_t* __restrict__ t, int T, int64_t per,
+                                                       int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ti = (int)t[i / per];
+    out[i] = tab2[ti] * x0[i] + tab2[T + ti] * eps[i];
+  }
+}
+
+// ============================================================================= C-ABI
+static inline int ew_grid(int64_t total) { return (int)min((int64_t)4096, (total + 255) / 256); }
+
+extern "C" int mmd_temb_fwd(const void* t, int t_kind, int N, int dim, const float* W0, const float* b0, const float* W2,
+                            const float* b2, float* out_silu, float* out_raw, void* stream) {
+  MMD_REQUIRE(t && W0 && b0 && W2 && b2 && out_silu && N > 0 && dim > 0 && dim <= 4096, "temb_fwd: bad argument");
+  MMD_REQUIRE(t_kind >= 0 && t_kind <= 2, "temb_fwd: t_kind must be 0 (int64), 1 (int32) or 2 (float32)");
+  hipLaunchKernelGGL(temb_kernel, dim3(N), dim3(256), 2 * dim * sizeof(float), (hipStream_t)stream, t, t_kind, dim, W0, b0, W2,
+                     b2, out_silu, out_raw);
+  return mmd_check_launch("temb");
+}
+
+extern "C" int mmd_linear_fwd(const float* x, const float* W, const float* b, float* y, int N, int K, int J, void* stream) {
+  MMD_REQUIRE(x && W && y && N > 0 && K > 0 && J > 0, "linear_fwd: bad argument");
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(J, 4)), dim3(256), 0, (hipStream_t)stream, x, W, b, y, N, K, J);
+  return mmd_check_launch("linear");
+}
+
+extern "C" int mmd_resample(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int NF, int H, int W, int fh,
+                            int fw, int mode, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "resample: bad dtype");
+  MMD_REQUIRE(x && y && C % epv == 0 && NF > 0 && H > 0 && W > 0 && fh > 0 && fw > 0, "resample: bad argument");
+  MMD_REQUIRE(mode == 1 || (H % fh == 0 && W % fw == 0), "resample: pooled dims must divide (%d/%d, %d/%d)", H, fh, W, fw);
+  const int64_t orows = mode == 0 ? (int64_t)NF * (H / fh) * (W / fw) : (int64_t)NF * H * fh * W * fw;
+  const int grid = ew_grid(orows * (C / epv));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL(resample_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, NF, H, W, fh, fw, mode);
+  else
+    hipLaunchKernelGGL(resample_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, NF, H, W, fh, fw, mode);
+  return mmd_check_launch("resample");
+}
+
+extern "C" int mmd_copy2d(const void* x, int64_t ldx_bytes, void* y, int64_t ldy_bytes, int64_t rows, int64_t row_bytes, void* stream) {
+  MMD_REQUIRE(x && y && rows > 0 && row_bytes > 0 && row_bytes % 16 == 0 && ldx_bytes % 16 == 0 && ldy_bytes % 16 == 0,
+              "copy2d: rows must be 16-byte multiples");
+  MMD_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "copy2d: unaligned pointer");
+  const int vecs = (int)(row_bytes / 16);
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * vecs)), dim3(256), 0, (hipStream_t)stream, (const char*)x, ldx_bytes,
+                     (char*)y, ldy_bytes, rows, vecs);
+  return mmd_check_launch("copy2d");
+}
+
+extern "C" int mmd_stem_conv(int dtype, const float* x, const float* w, const float* bias, void* y, int64_t ldy, int N, int F,
+                             int Cin, int H, int W, int Cout, int ntaps, const int* taps, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "stem_conv: bad dtype");
+  MMD_REQUIRE(x && w && y && taps && ntaps >= 1 && ntaps <= 27 && Cout % epv == 0, "stem_conv: bad argument");
+  const size_t lds = (size_t)ntaps * Cin * Cout * sizeof(float);
+  MMD_REQUIRE(lds <= 64 * 1024, "stem_conv: weights (%zu B) exceed the 64 KiB LDS stage", lds);
+  EdgeConvParams p;
+  p.x = x; p.w = w; p.bias = bias; p.y = (char*)y; p.ldy = ldy;
+  p.N = N; p.F = F; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.ntaps = ntaps;
+  for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
+  const int64_t total = (int64_t)N * F * H * W * (Cout / epv);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16) hipLaunchKernelGGL(stem_conv_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(ew_grid(total)), dim3(256), lds, st, p);
+  return mmd_check_launch("stem_conv");
+}
+
+template <typename T>
+static int launch_head(const HeadConvParams& p, hipStream_t st) {
+  const int64_t rows = (int64_t)p.N * p.F * p.H * p.W;
+  const int grid = (int)min((int64_t)8192, (rows + 255) / 256);
+  const int CO = p.Co <= 2 ? 2 : (p.Co <= 4 ? 4 : 8);
+  const size_t lds = (size_t)p.ntaps * p.Cin * CO * sizeof(float);
+  if (lds > 150 * 1024) return mmd_set_error(MMD_ERR_UNSUPPORTED, "head_conv: weights (%zu B) exceed LDS", lds);
+  const void* fn = CO == 2 ? (const void*)head_conv_kernel<T, 2> : CO == 4 ? (const void*)head_conv_kernel<T, 4> : (const void*)head_conv_kernel<T, 8>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "head_conv: set LDS attr: %s", hipGetErrorString(e));
+  }
+  if (CO == 2) hipLaunchKernelGGL((head_conv_kernel<T, 2>), dim3(grid), dim3(256), lds, st, p);
+  else if (CO == 4) hipLaunchKernelGGL((head_conv_kernel<T, 4>), dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((head_conv_kernel<T, 8>), dim3(grid), dim3(256), lds, st, p);
+  return mmd_check_launch("head_conv");
+}
+
+extern "C" int mmd_head_conv(int dtype, const void* x, int64_t ldx, const float* w, const float* bias, float* y, int N, int F,
+                             int Cin, int H, int W, int Co, int ntaps, const int* taps, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "head_conv: bad dtype");
+  MMD_REQUIRE(x && w && y && taps && ntaps >= 1 && ntaps <= 27 && Cin % epv == 0 && Co >= 1 && Co <= 8, "head_conv: bad argument");
+  HeadConvParams p;
+  p.x = (const char*)x; p.ldx = ldx; p.w = w; p.bias = bias; p.y = y;
+  p.N = N; p.F = F; p.Cin = Cin; p.H = H; p.W = W; p.Co = Co; p.ntaps = ntaps;
+  for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == MMD_BF16 ? launch_head<__bf16>(p, st) : launch_head<float>(p, st);
+}
+
+extern "C" int mmd_ddpm_update(const float* x, const float* model_out, const float* noise, float* out, float* x0_out,
+                               const float* tables, const int64_t* t, int T, int N, int F, int C, int HW, int flags, void* stream) {
+  MMD_REQUIRE(x && model_out && noise && out && tables && t && T > 0 && N > 0 && F > 0 && C > 0 && HW > 0, "ddpm_update: bad argument");
+  DdpmParams p;
+  p.x = x; p.mo = model_out; p.noise = noise; p.out = out; p.x0_out = x0_out; p.tables = tables; p.t = t;
+  p.T = T; p.N = N; p.F = F; p.C = C; p.HW = HW; p.flags = flags;
+  hipLaunchKernelGGL(ddpm_update_kernel, dim3(ew_grid((int64_t)N * F * C * HW)), dim3(256), 0, (hipStream_t)stream, p);
+  return mmd_check_launch("ddpm_update");
+}
+
+extern "C" int mmd_q_sample(const float* x0, const float* eps, float* out, const float* tab2, const int64_t* t, int T, int N,
+                            int64_t per_sample, void* stream) {
+  MMD_REQUIRE(x0 && eps && out && tab2 && t && T > 0 && N > 0 && per_sample > 0, "q_sample: bad argument");
+  const int64_t total = per_sample * N;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x0, eps, out, tab2, t, T, per_sample, total);
+  return mmd_check_launch("q_sample");
+}

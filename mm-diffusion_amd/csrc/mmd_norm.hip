@@ -1,0 +1,248 @@
+// GroupNorm32 (+FiLM) (+SiLU) on channels-last activations, native layout - no permute copies.
+//
+// Replaces reference nn.py:16-33 (GroupNorm32: 32 groups, eps 1e-5, fp32 statistics, the
+// 'b t c h w -> b c t h w' round trip), nn.SiLU and the FiLM modulation norm(h)*(1+scale)+shift of
+// ResBlock._forward (multimodal_unet.py:457-470).
+//
+// A "slice" is the set of rows one GroupNorm instance normalises over:
+//   rows(s) = base(s) + j*tstride, j < Tn,  base(s) = (s / inner)*outer_stride + (s % inner)*inner_stride
+//   per-sample video/audio GN : S=N,     inner=1,  outer_stride=rows/sample, tstride=1, Tn=rows/sample
+//   spatial self-attn GN      : S=N*F,   inner=1,  outer_stride=HW,          tstride=1, Tn=HW
+//   temporal self-attn GN     : S=N*HW,  inner=HW, outer_stride=F*HW, inner_stride=1, tstride=HW, Tn=F
+// Stage 1 (gn_partial): per (chunk of 256 rows, slice) per-channel fp32 partial sums, combined in
+//   fp64 in a fixed order (deterministic - no atomics) -> per-group (sum, sumsq) doubles.
+// Stage 2 (gn_finalize): mean / rstd per (slice, group) and the fused affine
+//   a[s,c] = rstd*gamma[c]*(1+scale[s,c]),  b[s,c] = (beta[c]-mean*rstd*gamma[c])*(1+scale[s,c]) + shift[s,c]
+// Stage 3 (gn_apply): y = act(x*a + b), 16-byte vector loads/stores (HBM-bound, 2 bytes moved per byte read).
+#include "mmd_common.h"
+
+#define GN_TPB 256      // rows per stage-1 block
+#define GN_GROUPS 32
+
+struct SliceGeom {
+  int S, Tn, inner;
+  int64_t outer_stride, inner_stride, tstride;
+};
+
+__device__ __forceinline__ int64_t slice_base(const SliceGeom& g, int s) {
+  return (int64_t)(s / g.inner) * g.outer_stride + (int64_t)(s % g.inner) * g.inner_stride;
+}
+__device__ __forceinline__ int slice_of_row(const SliceGeom& g, int64_t m) {
+  const int64_t o = m / g.outer_stride, rem = m % g.outer_stride;
+  return (int)(o * g.inner + (rem / g.inner_stride) % g.inner);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict__ x, int64_t ld, int C, SliceGeom g,
+                                                         double* __restrict__ part, int nchunks) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  __shared__ float s_sum[256 * EPV];
+  __shared__ float s_sq[256 * EPV];
+  __shared__ double s_csum[1024];
+  __shared__ double s_csq[1024];
+  const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int CV = C / EPV;                 // vecs per row (<= 256)
+  const int RPP = 256 / CV;               // rows per pass
+  const int col = tid % CV, rl = tid / CV;
+  float sum[EPV], sq[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) sum[j] = sq[j] = 0.f;
+  const int j0 = chunk * GN_TPB;
+  const int j1 = min(j0 + GN_TPB, g.Tn);
+  const int64_t base = slice_base(g, s);
+  // shifted-data sums: pivot = first element of the group in the slice's first row (kills the
+  // E[x^2]-E[x]^2 cancellation when a group carries a large common offset)
+  const int cpg = C / GN_GROUPS;
+  float piv[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) piv[e] = Elt<T>::ld(x, base * ld + (int64_t)((col * EPV + e) / cpg) * cpg);
+  if (rl < RPP) {
+    for (int j = j0 + rl; j < j1; j += RPP) {
+      const int64_t row = base + (int64_t)j * g.tstride;
+      float f[EPV];
+      Elt<T>::unpack(*(const u32x4*)(x + (row * ld + (int64_t)col * EPV) * ES), f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { const float d = f[e] - piv[e]; sum[e] += d; sq[e] += d * d; }
+    }
+  }
+  // per-channel combine over the RPP row lanes, in double, fixed order
+  if (rl < RPP) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      s_sum[rl * C + col * EPV + e] = sum[e];
+      s_sq[rl * C + col * EPV + e] = sq[e];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < RPP; ++r) { a += (double)s_sum[r * C + c]; b += (double)s_sq[r * C + c]; }
+    s_csum[c] = a;
+    s_csq[c] = b;
+  }
+  __syncthreads();
+  if (tid < GN_GROUPS) {
+    double a = 0.0, b = 0.0;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += s_csum[c]; b += s_csq[c]; }
+    double* o = part + (((int64_t)s * nchunks + chunk) * GN_GROUPS + tid) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const char* __restrict__ x, int dtype, int64_t ld, SliceGeom g,
+                                                          const double* __restrict__ part, int nchunks, int C, int Tn,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ film, int64_t film_ld, float eps,
+                                                          float* __restrict__ a_out, float* __restrict__ b_out) {
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (tid < GN_GROUPS) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+      const double* p = part + (((int64_t)s * nchunks + k) * GN_GROUPS + tid) * 2;
+      a += p[0];
+      b += p[1];
+    }
+    const double cnt = (double)Tn * (double)(C / GN_GROUPS);
+    const int64_t pidx = slice_base(g, s) * ld + (int64_t)tid * (C / GN_GROUPS);
+    const double piv = dtype == MMD_BF16 ? (double)Elt<__bf16>::ld(x, pidx) : (double)Elt<float>::ld(x, pidx);
+    const double dm = a / cnt;
+    double var = b / cnt - dm * dm;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)(piv + dm);
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cpg = C / GN_GROUPS;
+  for (int c = tid; c < C; c += 256) {
+    const int gi = c / cpg;
+    float a = s_rstd[gi] * gamma[c];
+    float b = beta[c] - s_mean[gi] * a;
+    if (film) {
+      const float sc = 1.f + film[(int64_t)s * film_ld + c];
+      const float sh = film[(int64_t)s * film_ld + C + c];
+      a *= sc;
+      b = b * sc + sh;
+    }
+    a_out[(int64_t)s * C + c] = a;
+    b_out[(int64_t)s * C + c] = b;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const char* __restrict__ x, int64_t ldx, char* __restrict__ y, int64_t ldy,
+                                                       int64_t rows, int C, SliceGeom g, const float* __restrict__ a,
+                                                       const float* __restrict__ b, int act) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  const int CV = C / EPV;
+  const int64_t total = rows * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / CV;
+    const int cvi = (int)(i % CV);
+    const int s = slice_of_row(g, m);
+    float f[EPV];
+    Elt<T>::unpack(*(const u32x4*)(x + (m * ldx + (int64_t)cvi * EPV) * ES), f);
+    const float* ap = a + (int64_t)s * C + cvi * EPV;
+    const float* bp = b + (int64_t)s * C + cvi * EPV;
+#pragma unroll
+    for (int e = 0; e < EPV; e += 4) {
+      const f32x4 av = *(const f32x4*)(ap + e), bv = *(const f32x4*)(bp + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = f[e + k] * av[k] + bv[k];
+        f[e + k] = act ? silu_f(v) : v;
+      }
+    }
+    *(u32x4*)(y + (m * ldy + (int64_t)cvi * EPV) * ES) = Elt<T>::pack(f);
+  }
+}
+
+// x[m, c] += e[n(m), c]   (non-FiLM ResBlock: h + emb_out, multimodal_unet.py:473-477)
+template <typename T>
+__global__ __launch_bounds__(256) void add_rowbias_kernel(char* __restrict__ x, int64_t ld, int64_t rows, int C,
+                                                          int64_t rows_per_sample, const float* __restrict__ e, int64_t e_ld) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  const int CV = C / EPV;
+  const int64_t total = rows * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / CV;
+    const int cvi = (int)(i % CV);
+    const int64_t n = m / rows_per_sample;
+    char* p = x + (m * ld + (int64_t)cvi * EPV) * ES;
+    float f[EPV];
+    Elt<T>::unpack(*(const u32x4*)p, f);
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) f[k] += e[n * e_ld + cvi * EPV + k];
+    *(u32x4*)p = Elt<T>::pack(f);
+  }
+}
+
+static int check_geom(const char* who, int dtype, int C, int S, int Tn, int inner) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "%s: bad dtype %d", who, dtype);
+  MMD_REQUIRE(C % GN_GROUPS == 0 && C % epv == 0 && C / epv <= 256 && C <= 1024, "%s: unsupported channel count %d", who, C);
+  MMD_REQUIRE(S > 0 && Tn > 0 && inner > 0, "%s: empty slice geometry", who);
+  return MMD_OK;
+}
+
+extern "C" int64_t mmd_gn_workspace_bytes(int S, int Tn) {
+  return (int64_t)S * cdiv(Tn, GN_TPB) * GN_GROUPS * 2 * sizeof(double);
+}
+
+extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int inner, int64_t outer_stride,
+                            int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta,
+                            const float* film, int64_t film_ld, float eps, float* a_out, float* b_out, void* workspace,
+                            void* stream) {
+  int rc = check_geom("gn_stats", dtype, C, S, Tn, inner);
+  if (rc) return rc;
+  MMD_REQUIRE(x && gamma && beta && a_out && b_out && workspace, "gn_stats: null pointer");
+  MMD_REQUIRE(((uintptr_t)x) % 16 == 0 && ld % (dtype == MMD_BF16 ? 8 : 4) == 0, "gn_stats: x must be 16-byte aligned rows");
+  SliceGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};
+  const int nchunks = cdiv(Tn, GN_TPB);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nchunks, S);
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL(gn_partial_kernel<__bf16>, grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks);
+  rc = mmd_check_launch("gn_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(S), dim3(256), 0, st, (const char*)x, dtype, ld, g, (const double*)workspace, nchunks, C, Tn, gamma, beta,
+                     film, film_ld, eps, a_out, b_out);
+  return mmd_check_launch("gn_finalize");
+}
+
+extern "C" int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn,
+                            int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
+                            const float* b, int act, void* stream) {
+  int rc = check_geom("gn_apply", dtype, C, S, Tn, inner);
+  if (rc) return rc;
+  MMD_REQUIRE(x && y && a && b && rows > 0, "gn_apply: null pointer / empty");
+  SliceGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};
+  const int64_t total = rows * (C / (dtype == MMD_BF16 ? 8 : 4));
+  const int grid = (int)min((int64_t)4096, (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, rows, C, g, a, b, act);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, rows, C, g, a, b, act);
+  return mmd_check_launch("gn_apply");
+}
+
+extern "C" int mmd_add_rowbias(int dtype, void* x, int64_t ld, int64_t rows, int C, int64_t rows_per_sample, const float* e,
+                               int64_t e_ld, void* stream) {
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "add_rowbias: bad dtype");
+  MMD_REQUIRE(x && e && rows > 0 && C % 8 == 0, "add_rowbias: bad argument");
+  const int64_t total = rows * (C / (dtype == MMD_BF16 ? 8 : 4));
+  const int grid = (int)min((int64_t)4096, (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL(add_rowbias_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (char*)x, ld, rows, C, rows_per_sample, e, e_ld);
+  else
+    hipLaunchKernelGGL(add_rowbias_kernel<float>, dim3(grid), dim3(256), 0, st, (char*)x, ld, rows, C, rows_per_sample, e, e_ld);
+  return mmd_check_launch("add_rowbias");
+}

@@ -1,0 +1,94 @@
+"""ctypes binding of libmmd.so (include/mmd.h).  There is NO fallback: if the library is missing or a
+call fails this raises - the product path never silently computes on the CPU or with stock torch ops."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmd.so")
+
+F32, BF16 = 0, 1
+_lib = None
+
+i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+_PROTOS = {
+    "mmd_version": (C.c_int, []),
+    "mmd_last_error": (C.c_char_p, []),
+    "mmd_graph_begin": (i32, [vp]),
+    "mmd_graph_end": (i32, [vp, C.POINTER(vp)]),
+    "mmd_graph_launch": (i32, [vp, vp]),
+    "mmd_graph_destroy": (i32, [vp]),
+    "mmd_event_create": (i32, [C.POINTER(vp)]),
+    "mmd_event_record": (i32, [vp, vp]),
+    "mmd_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
+    "mmd_event_destroy": (i32, [vp]),
+    "mmd_temb_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "mmd_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mmd_gn_workspace_bytes": (i64, [i32, i32]),
+    "mmd_gn_stats": (i32, [i32, vp, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, i64, f32, vp, vp, vp, vp]),
+    "mmd_gn_apply": (i32, [i32, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, i32, vp]),
+    "mmd_add_rowbias": (i32, [i32, vp, i64, i64, i32, i64, vp, i64, vp]),
+    "mmd_conv_gemm": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
+    "mmd_attn_fwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, i64, i32, i64, i32, i32, vp, i32, vp]),
+    "mmd_attn_small_fwd": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
+    "mmd_resample": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mmd_copy2d": (i32, [vp, i64, vp, i64, i64, i64, vp]),
+    "mmd_stem_conv": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
+    "mmd_head_conv": (i32, [i32, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
+    "mmd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mmd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
+}
+EXPORTS = tuple(_PROTOS)
+
+
+class MMDError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmmd.so (once).  Raises MMDError when it has not been built - never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMDError(f"{LIB_PATH} not found - build it with `python mm-diffusion_amd/build.py` "
+                           "(the MI355X HIP path has no CPU/torch fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise MMDError(f"{name} failed ({rc}): {lib().mmd_last_error().decode()}")
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise MMDError(f"unsupported activation dtype {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def taps_array(taps):
+    flat = [int(v) for t in taps for v in t]
+    return (i32 * len(flat))(*flat), len(taps)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MMDError("the MI355X HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")

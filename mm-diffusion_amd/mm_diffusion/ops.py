@@ -1,0 +1,199 @@
+"""Thin per-op Python wrappers over the C-ABI (one function per libmmd entry point).
+
+Activations are 2-D torch tensors [rows, C] with stride(1) == 1 and any row stride (a column slice of a
+wider buffer is fine); torch is used for device memory and the current stream only - every arithmetic
+op runs in libmmd."""
+import math
+
+import torch
+
+from . import _hip as H
+
+GN_EPS = 1e-5
+
+
+class Geom:
+    """Slice geometry of a GroupNorm / short-attention instance (see include/mmd.h: mmd_gn_stats)."""
+    __slots__ = ("S", "Tn", "inner", "outer_stride", "inner_stride", "tstride")
+
+    def __init__(self, S, Tn, inner=1, outer_stride=None, inner_stride=1, tstride=1):
+        self.S, self.Tn, self.inner = int(S), int(Tn), int(inner)
+        self.outer_stride = int(Tn if outer_stride is None else outer_stride)
+        self.inner_stride, self.tstride = int(inner_stride), int(tstride)
+
+    @staticmethod
+    def per_sample(N, rows_per_sample):
+        return Geom(N, rows_per_sample, 1, rows_per_sample, 1, 1)
+
+    @staticmethod
+    def spatial(N, F, HW):
+        return Geom(N * F, HW, 1, HW, 1, 1)
+
+    @staticmethod
+    def temporal(N, F, HW):
+        return Geom(N * HW, F, HW, F * HW, 1, HW)
+
+    def args(self):
+        return (self.S, self.Tn, self.inner, self.outer_stride, self.inner_stride, self.tstride)
+
+
+def _chk2d(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise H.MMDError(f"expected a [rows, C] tensor with unit channel stride, got {tuple(t.shape)} strides {t.stride()}")
+    H.require_cuda(t)
+
+
+def gn_workspace(geom: Geom, device):
+    nbytes = H.lib().mmd_gn_workspace_bytes(geom.S, geom.Tn)
+    return torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+
+
+def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None):
+    _chk2d(x)
+    C = x.shape[1]
+    a = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if a is None else a
+    b = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if b is None else b
+    ws = gn_workspace(geom, x.device) if ws is None else ws
+    H.call("mmd_gn_stats", H.dt_of(x), x.data_ptr(), x.stride(0), C, *geom.args(), gamma.data_ptr(), beta.data_ptr(),
+           H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), ws.data_ptr(),
+           H.stream_handle())
+    return a, b
+
+
+def gn_apply(x, a, b, geom: Geom, act=True, out=None):
+    _chk2d(x)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    H.call("mmd_gn_apply", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+           *geom.args(), a.data_ptr(), b.data_ptr(), 1 if act else 0, H.stream_handle())
+    return out
+
+
+def add_rowbias(x, e, rows_per_sample):
+    _chk2d(x)
+    H.call("mmd_add_rowbias", H.dt_of(x), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], rows_per_sample,
+           e.data_ptr(), e.stride(0), H.stream_handle())
+    return x
+
+
+# ---- tap tables (offsets of (p0, p1, p2))
+TAPS_1 = [(0, 0, 0)]
+TAPS_SPATIAL = [(0, dh, dw) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]      # D = (1|F, H, W)
+TAPS_TEMPORAL = [(df, 0, 0) for df in (-1, 0, 1)]                           # D = (F, HW, 1)
+TAPS_3D = [(df, dh, dw) for df in (-1, 0, 1) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]
+
+
+def taps_audio(dilation):
+    return [(-dilation, 0, 0), (0, 0, 0), (dilation, 0, 0)]                 # D = (L, 1, 1)
+
+
+def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0):
+    """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None."""
+    _chk2d(x)
+    M, Cin = x.shape
+    Cout = w.shape[0]
+    if w.dtype != x.dtype or w.shape[1] != len(taps) * Cin or not w.is_contiguous():
+        raise H.MMDError(f"conv_gemm: weight {tuple(w.shape)} {w.dtype} does not match input {tuple(x.shape)} {x.dtype} x {len(taps)} taps")
+    out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    arr, nt = H.taps_array(taps)
+    H.call("mmd_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias),
+           H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
+           M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile, H.stream_handle())
+    return out
+
+
+def attn(q, kv, out, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group, win,
+         q_off=0, k_off=None, v_off=None, shift_dev=None, impl=0):
+    """See include/mmd.h: mmd_attn_fwd.  q/kv are qkv GEMM outputs [rows, 3C]; out [q rows, C]."""
+    _chk2d(q), _chk2d(kv), _chk2d(out)
+    C = heads * ch
+    k_off = C if k_off is None else k_off
+    v_off = 2 * C if v_off is None else v_off
+    H.call("mmd_attn_fwd", H.dt_of(q), q.data_ptr(), q.stride(0), q_off, kv.data_ptr(), kv.stride(0), k_off, v_off,
+           out.data_ptr(), out.stride(0), heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group,
+           win, H.ptr(shift_dev), impl, H.stream_handle())
+    return out
+
+
+def attn_small(qkv, out, C, heads, geom: Geom):
+    _chk2d(qkv), _chk2d(out)
+    H.call("mmd_attn_small_fwd", H.dt_of(qkv), qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), C, heads,
+           *geom.args(), H.stream_handle())
+    return out
+
+
+def resample(x, out, NF, Hh, Ww, fh, fw, mode):
+    """mode 0 avg-pool / 1 nearest-upsample by (1, fh, fw); Hh, Ww describe the input rows (nf, h, w)."""
+    _chk2d(x), _chk2d(out)
+    H.call("mmd_resample", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], NF, Hh, Ww,
+           fh, fw, mode, H.stream_handle())
+    return out
+
+
+def copy2d(x, out):
+    _chk2d(x), _chk2d(out)
+    es = x.element_size()
+    H.call("mmd_copy2d", x.data_ptr(), x.stride(0) * es, out.data_ptr(), out.stride(0) * es, x.shape[0], x.shape[1] * es,
+           H.stream_handle())
+    return out
+
+
+def temb(t, dim, W0, b0, W2, b2, out_silu, out_raw=None):
+    kind = {torch.int64: 0, torch.int32: 1, torch.float32: 2}.get(t.dtype)
+    if kind is None:
+        raise H.MMDError(f"timesteps must be int64/int32/float32, got {t.dtype}")
+    H.require_cuda(t, W0)
+    H.call("mmd_temb_fwd", t.data_ptr(), kind, t.shape[0], dim, W0.data_ptr(), b0.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+           out_silu.data_ptr(), H.ptr(out_raw), H.stream_handle())
+    return out_silu
+
+
+def linear(x, W, b, out):
+    H.call("mmd_linear_fwd", x.data_ptr(), W.data_ptr(), H.ptr(b), out.data_ptr(), x.shape[0], x.shape[1], W.shape[0],
+           H.stream_handle())
+    return out
+
+
+def stem_conv(x, w, bias, out, N, F, Cin, Hh, Ww, taps):
+    """x fp32 contiguous [N,F,Cin,H,W]; w fp32 [ntaps, Cin, Cout]; out rows [N*F*H*W, Cout]."""
+    _chk2d(out)
+    arr, nt = H.taps_array(taps)
+    H.call("mmd_stem_conv", H.dt_of(out), x.data_ptr(), w.data_ptr(), H.ptr(bias), out.data_ptr(), out.stride(0), N, F, Cin,
+           Hh, Ww, out.shape[1], nt, arr, H.stream_handle())
+    return out
+
+
+def head_conv(x, w, bias, out, N, F, Hh, Ww, taps):
+    """x rows [N*F*H*W, Cin]; w fp32 [ntaps, Cin, Co]; out fp32 contiguous [N,F,Co,H,W]."""
+    _chk2d(x)
+    arr, nt = H.taps_array(taps)
+    H.call("mmd_head_conv", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), out.data_ptr(), N, F,
+           x.shape[1], Hh, Ww, w.shape[2], nt, arr, H.stream_handle())
+    return out
+
+
+def ddpm_update(x, model_out, noise, out, tables, t, F, C, HW, flags, x0_out=None):
+    H.require_cuda(x, model_out, noise, out, tables, t)
+    H.call("mmd_ddpm_update", x.data_ptr(), model_out.data_ptr(), noise.data_ptr(), out.data_ptr(), H.ptr(x0_out),
+           tables.data_ptr(), t.data_ptr(), tables.shape[1], x.shape[0], F, C, HW, flags, H.stream_handle())
+    return out
+
+
+def q_sample(x0, eps, out, tab2, t):
+    H.require_cuda(x0, eps, out, tab2, t)
+    H.call("mmd_q_sample", x0.data_ptr(), eps.data_ptr(), out.data_ptr(), tab2.data_ptr(), t.data_ptr(), tab2.shape[1],
+           x0.shape[0], x0[0].numel(), H.stream_handle())
+    return out
+
+
+def pack_conv_weight(w: torch.Tensor, dtype) -> torch.Tensor:
+    """[Cout, Cin, *k] (torch conv layout) -> [Cout, ntaps*Cin] with K index = tap*Cin + ci (tap = row-major k)."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    return w.reshape(Cout, Cin, -1).permute(0, 2, 1).reshape(Cout, -1).to(dtype).contiguous()
+
+
+def pack_edge_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, *k] -> fp32 [ntaps, Cin, Cout] for the stem / head kernels."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    return w.reshape(Cout, Cin, -1).permute(2, 1, 0).float().contiguous()

@@ -1,0 +1,334 @@
+"""Per-kernel parity: every libmmd entry point (through the C-ABI) against the oracle's primitives.
+
+Tolerances (rel-L2 against the fp32 CPU oracle on the same inputs):
+  fp32 kernels : 2e-5   (exact-fp32 MFMA / fp32 VALU; differences are summation order only)
+  bf16 kernels : 1e-2   (inputs are rounded to bf16 first and the oracle sees the ROUNDED values, so the
+                         budget covers bf16 output rounding + bf16 P in the attention MFMA only)
+Index/window/padding errors produce O(1) errors, far above either bound.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F_
+
+from helpers import rel_l2
+from oracle import unet_ref as uref
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 1e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from mm_diffusion import ops as o
+    return o
+
+
+def rnd(*shape, dt=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    return x.to(dt).float()          # value representable in dt, held as fp32 for the oracle
+
+
+def dev(x, dt):
+    return x.to(dt).cuda()
+
+
+def rows_video(x):   # [N,C,F,H,W] -> [(n f h w), C]
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def rows_audio(x):   # [N,C,L] -> [(n l), C]
+    return x.permute(0, 2, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def unrows_video(r, N, F, H, W):
+    return r.reshape(N, F, H, W, -1).permute(0, 4, 1, 2, 3)
+
+
+# --------------------------------------------------------------------------- implicit-GEMM convs
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("M,Cin,Cout", [(300, 64, 96), (1024, 128, 384), (77, 32, 8)])
+def test_pointwise(ops, dt, tile, M, Cin, Cout):
+    x, w, b, r = rnd(M, Cin, dt=dt, seed=1), rnd(Cout, Cin, dt=dt, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3), rnd(M, Cout, dt=dt, seed=4)
+    y = ops.conv_gemm(dev(x, dt), dev(w, dt), b.cuda(), residual=dev(r, dt), tile=tile)
+    ref = x @ w.t() + b + r
+    assert rel_l2(y.float().cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_strided_views(ops, dt):
+    """Input, residual and output as column slices of wider buffers (free skip-concat views)."""
+    M, Cin, Cout = 200, 64, 64
+    xb, ob, rb = rnd(M, 160, dt=dt, seed=5), torch.zeros(M, 192), rnd(M, 128, dt=dt, seed=6)
+    w, b = rnd(Cout, Cin, dt=dt, seed=7, scale=0.1), rnd(Cout, seed=8)
+    xd, od, rd = dev(xb, dt), dev(ob, dt), dev(rb, dt)
+    ops.conv_gemm(xd[:, 96:160], dev(w, dt), b.cuda(), residual=rd[:, 64:128], out=od[:, 64:128])
+    ref = xb[:, 96:160] @ w.t() + b + rb[:, 64:128]
+    assert rel_l2(od[:, 64:128].float().cpu(), ref) < tol(dt)
+    assert float(od[:, :64].abs().max()) == 0 and float(od[:, 128:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,F,H,W,Cin,Cout", [(2, 3, 8, 8, 64, 64), (1, 2, 5, 7, 32, 96), (1, 16, 16, 16, 128, 128)])
+def test_video_conv_2d1d(ops, dt, N, F, H, W, Cin, Cout):
+    x = rnd(N, Cin, F, H, W, dt=dt, seed=9)
+    ws, bs = rnd(Cout, Cin, 3, 3, dt=dt, seed=10, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=11)
+    wt, bt = rnd(Cout, Cout, 3, dt=dt, seed=12, scale=(3 * Cout) ** -0.5), rnd(Cout, seed=13)
+    sd = {"p.video_conv_spatial.weight": ws, "p.video_conv_spatial.bias": bs,
+          "p.video_conv_temporal.weight": wt, "p.video_conv_temporal.bias": bt}
+    y1 = ops.conv_gemm(dev(rows_video(x), dt), dev(ops.pack_conv_weight(ws, torch.float32), dt), bs.cuda(),
+                       taps=ops.TAPS_SPATIAL, dims=(N * F, H, W))
+    ref1 = F_.conv3d(x, ws[:, :, None], bs, padding=(0, 1, 1))
+    assert rel_l2(unrows_video(y1.float().cpu(), N, F, H, W), ref1) < tol(dt)
+    y2 = ops.conv_gemm(y1, dev(ops.pack_conv_weight(wt, torch.float32), dt), bt.cuda(), taps=ops.TAPS_TEMPORAL, dims=(F, H * W, 1))
+    ref = uref.video_conv_2d1d(x, sd, "p")
+    assert rel_l2(unrows_video(y2.float().cpu(), N, F, H, W), ref) < 2 * tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("L,d", [(100, 1), (100, 4), (64, 128), (400, 512), (257, 16)])
+def test_audio_conv_dilated(ops, dt, L, d):
+    N, Cin, Cout = 2, 64, 96
+    x = rnd(N, Cin, L, dt=dt, seed=14)
+    w, b = rnd(Cout, Cin, 3, dt=dt, seed=15, scale=(3 * Cin) ** -0.5), rnd(Cout, seed=16)
+    y = ops.conv_gemm(dev(rows_audio(x), dt), dev(ops.pack_conv_weight(w, torch.float32), dt), b.cuda(), taps=ops.taps_audio(d), dims=(L, 1, 1))
+    ref = uref.audio_conv(x, {"p.audio_conv.weight": w, "p.audio_conv.bias": b}, "p", d)
+    assert rel_l2(y.float().cpu().reshape(N, L, Cout).permute(0, 2, 1), ref) < tol(dt)
+
+
+# --------------------------------------------------------------------------- GroupNorm (+FiLM, +SiLU)
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C", [64, 128, 384, 896])
+def test_groupnorm_per_sample(ops, dt, C):
+    N, F, H, W = 2, 3, 6, 5
+    x = rnd(N, C, F, H, W, dt=dt, seed=17) * 2 + 0.7
+    x = x.to(dt).float()
+    g, b, film = 1 + 0.1 * rnd(C, seed=18), rnd(C, seed=19), rnd(N, 2 * C, seed=20, scale=0.3)
+    geom = ops.Geom.per_sample(N, F * H * W)
+    xa = dev(rows_video(x), dt)
+    a_, b_ = ops.gn_stats(xa, g.cuda(), b.cuda(), geom, film=film.cuda())
+    y = ops.gn_apply(xa, a_, b_, geom, act=True)
+    sc, sh = film[:, :C, None, None, None], film[:, C:, None, None, None]
+    ref = F_.silu(uref.group_norm(x, g, b) * (1 + sc) + sh)
+    assert rel_l2(unrows_video(y.float().cpu(), N, F, H, W), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_groupnorm_attention_slices(ops, dt):
+    N, C, F, H, W = 2, 64, 4, 3, 5
+    x = rnd(N, C, F, H, W, dt=dt, seed=21)
+    g, b = 1 + 0.1 * rnd(C, seed=22), rnd(C, seed=23)
+    xa = dev(rows_video(x), dt)
+    # spatial: (b f) c (h w)
+    geom = ops.Geom.spatial(N, F, H * W)
+    y = ops.gn_apply(xa, *ops.gn_stats(xa, g.cuda(), b.cuda(), geom), geom, act=False)
+    xs = x.permute(0, 2, 1, 3, 4).reshape(N * F, C, H * W)
+    ref = uref.group_norm(xs, g, b).reshape(N, F, C, H, W).permute(0, 2, 1, 3, 4)
+    assert rel_l2(unrows_video(y.float().cpu(), N, F, H, W), ref) < tol(dt)
+    # temporal: (b h w) c f
+    geom = ops.Geom.temporal(N, F, H * W)
+    y = ops.gn_apply(xa, *ops.gn_stats(xa, g.cuda(), b.cuda(), geom), geom, act=False)
+    xt = x.permute(0, 3, 4, 1, 2).reshape(N * H * W, C, F)
+    ref = uref.group_norm(xt, g, b).reshape(N, H, W, C, F).permute(0, 3, 4, 1, 2)
+    assert rel_l2(unrows_video(y.float().cpu(), N, F, H, W), ref) < tol(dt)
+
+
+def test_groupnorm_large_mean_fp32(ops):
+    """Statistics are accumulated in fp64 partials: a large common offset must not cancel catastrophically."""
+    N, C, R = 1, 32, 5000
+    x = rnd(N * R, C, seed=24) * 0.01 + 100.0
+    g, b = torch.ones(C), torch.zeros(C)
+    geom = ops.Geom.per_sample(N, R)
+    xa = x.cuda()
+    y = ops.gn_apply(xa, *ops.gn_stats(xa, g.cuda(), b.cuda(), geom), geom, act=False)
+    xd = x.double().reshape(R, 32, C // 32)
+    mu = xd.mean(dim=(0, 2), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(0, 2), keepdim=True)
+    ref = ((xd - mu) / torch.sqrt(var + 1e-5)).reshape(R, C)
+    assert rel_l2(y.cpu(), ref) < 2e-3
+
+
+# --------------------------------------------------------------------------- attention
+def _qkv_rows(N, T, C, dt, seed):
+    return rnd(N * T, 3 * C, dt=dt, seed=seed)
+
+
+def _ref_attn(q_rows, kv_rows, heads, ch, q_idx, k_idx):
+    """rows -> oracle _attend for one (batch, group)."""
+    C = heads * ch
+    q = q_rows[q_idx, :C].t()[None]
+    k = kv_rows[k_idx, C:2 * C].t()[None]
+    v = kv_rows[k_idx, 2 * C:].t()[None]
+    return uref._attend(q, k, v, heads)[0].t()
+
+
+@pytest.mark.parametrize("dt,impl", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("T,heads,ch", [(64, 4, 32), (100, 2, 64), (4, 4, 16), (1024, 1, 64), (400, 2, 128), (130, 2, 48), (70, 1, 96)])
+def test_self_attention(ops, dt, impl, T, heads, ch):
+    N, G, C = 2, 3, heads * ch
+    qkv = _qkv_rows(N * G, T, C, dt, 25)
+    out = torch.zeros(N * G * T, C, dtype=dt, device="cuda")
+    ops.attn(dev(qkv, dt), dev(qkv, dt), out, heads, ch, N, G, G * T, T, G * T, T, 1, impl=impl)
+    ref = torch.cat([_ref_attn(qkv, qkv, heads, ch, torch.arange(s * T, (s + 1) * T), torch.arange(s * T, (s + 1) * T))
+                     for s in range(N * G)])
+    assert rel_l2(out.float().cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt,impl", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("F,HW,L,win,shift,heads,ch", [
+    (8, 16, 64, 1, 0, 2, 32), (8, 16, 64, 1, 5, 2, 32), (8, 16, 64, 4, 3, 4, 32), (8, 4, 8, 8, 0, 4, 16),
+    (16, 4, 100, 4, 2, 2, 32), (16, 4, 100, 4, 12, 2, 32), (8, 4, 32, 8, 0, 2, 32), (16, 256, 1600, 4, 7, 2, 64),
+])
+def test_cross_attention_windows(ops, dt, impl, F, HW, L, win, shift, heads, ch):
+    """RS-MMA both directions; includes wrap-around, 1 audio token/frame, L % F != 0 (remainder queries)."""
+    N, C = 2, heads * ch
+    apf = L // F
+    vq, aq = _qkv_rows(N, F * HW, C, dt, 26), _qkv_rows(N, L, C, dt, 27)
+    sh = torch.tensor([shift], dtype=torch.int32, device="cuda")
+    vo = torch.zeros(N * F * HW, C, dtype=dt, device="cuda")
+    ao = torch.zeros(N * L, C, dtype=dt, device="cuda")
+    ops.attn(dev(vq, dt), dev(aq, dt), vo, heads, ch, N, F, F * HW, HW, L, apf, win, shift_dev=sh, impl=impl)
+    ops.attn(dev(aq, dt), dev(vq, dt), ao, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh, impl=impl)
+    vref, aref = torch.zeros(N * F * HW, C), torch.zeros(N * L, C)
+    for n in range(N):
+        for i in range(F):
+            a_idx = n * L + (torch.arange(win * apf) + (i + shift) * apf) % L
+            qi = n * F * HW + torch.arange(i * HW, (i + 1) * HW)
+            vref[qi] = _ref_attn(vq, aq, heads, ch, qi, a_idx)
+            v_idx = n * F * HW + (torch.arange(win * HW) + (i + shift) * HW) % (F * HW)
+            hi = L if i == F - 1 else (i + 1) * apf
+            qa = n * L + torch.arange(i * apf, hi)
+            aref[qa] = _ref_attn(aq, vq, heads, ch, qa, v_idx)
+    assert rel_l2(vo.float().cpu(), vref) < tol(dt)
+    assert rel_l2(ao.float().cpu(), aref) < tol(dt)
+
+
+def test_attention_softmax_spike(ops):
+    """Online-softmax rescale path: one key dominates late in the sequence (forces a big running-max jump)."""
+    T, heads, ch = 300, 1, 64
+    qkv = rnd(T, 3 * 64, dt=torch.bfloat16, seed=28) * 0.3
+    qkv[250, 64:128] = qkv[7, :64] * 40           # key 250 (4th tile) aligned with query 7
+    qkv = qkv.to(torch.bfloat16).float()
+    out = torch.zeros(T, 64, dtype=torch.bfloat16, device="cuda")
+    ops.attn(dev(qkv, torch.bfloat16), dev(qkv, torch.bfloat16), out, heads, ch, 1, 1, T, T, T, T, 1)
+    ref = _ref_attn(qkv, qkv, heads, ch, torch.arange(T), torch.arange(T))
+    assert rel_l2(out.float().cpu(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("F,HW,heads,ch", [(16, 9, 4, 64), (8, 5, 4, 16), (16, 3, 4, 96), (20, 2, 2, 32), (3, 7, 4, 128)])
+def test_temporal_attention(ops, dt, F, HW, heads, ch):
+    N, C = 2, heads * ch
+    qkv = _qkv_rows(N, F * HW, C, dt, 29)
+    out = torch.zeros(N * F * HW, C, dtype=dt, device="cuda")
+    ops.attn_small(dev(qkv, dt), out, C, heads, ops.Geom.temporal(N, F, HW))
+    ref = torch.zeros(N * F * HW, C)
+    for n in range(N):
+        for p in range(HW):
+            idx = n * F * HW + torch.arange(F) * HW + p
+            ref[idx] = _ref_attn(qkv, qkv, heads, ch, idx, idx)
+    assert rel_l2(out.float().cpu(), ref) < tol(dt)
+
+
+# --------------------------------------------------------------------------- bandwidth kernels
+@pytest.mark.parametrize("dt", DTYPES)
+def test_resample_and_copy(ops, dt):
+    N, C, F, H, W = 2, 64, 3, 8, 6
+    x = rnd(N, C, F, H, W, dt=dt, seed=30)
+    xa = dev(rows_video(x), dt)
+    out = torch.empty(N * F * (H // 2) * (W // 2), C, dtype=dt, device="cuda")
+    ops.resample(xa, out, N * F, H, W, 2, 2, 0)
+    assert rel_l2(unrows_video(out.float().cpu(), N, F, H // 2, W // 2), F_.avg_pool3d(x, (1, 2, 2))) < tol(dt)
+    up = torch.empty(N * F * H * 2 * W * 2, C, dtype=dt, device="cuda")
+    ops.resample(xa, up, N * F, H, W, 2, 2, 1)
+    ref = x.repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
+    assert torch.equal(unrows_video(up.float().cpu(), N, F, 2 * H, 2 * W), ref)
+    a = rnd(N, C, 40, dt=dt, seed=31)
+    aa = dev(rows_audio(a), dt)
+    o = torch.empty(N * 10, C, dtype=dt, device="cuda")
+    ops.resample(aa, o, N, 1, 40, 1, 4, 0)
+    assert rel_l2(o.float().cpu().reshape(N, 10, C).permute(0, 2, 1), F_.avg_pool1d(a, 4)) < tol(dt)
+    o = torch.empty(N * 160, C, dtype=dt, device="cuda")
+    ops.resample(aa, o, N, 1, 40, 1, 4, 1)
+    assert torch.equal(o.float().cpu().reshape(N, 160, C).permute(0, 2, 1), a.repeat_interleave(4, dim=2))
+    wide = torch.zeros(N * 40, 3 * C, dtype=dt, device="cuda")
+    ops.copy2d(aa, wide[:, C:2 * C])
+    assert torch.equal(wide[:, C:2 * C], aa) and float(wide[:, :C].abs().max()) == 0
+
+
+def test_temb_and_linear(ops):
+    dim, N = 128, 5
+    W0, b0, W2, b2 = rnd(dim, dim, seed=32, scale=dim ** -0.5), rnd(dim, seed=33), rnd(dim, dim, seed=34, scale=dim ** -0.5), rnd(dim, seed=35)
+    for t in (torch.tensor([0, 1, 17, 999, 500]), torch.tensor([0.0, 0.25, 131.5, 999.0, 3.0]), torch.tensor([5, 4, 3, 2, 1], dtype=torch.int32)):
+        e = uref.timestep_embedding(t, dim)
+        raw = F_.linear(F_.silu(F_.linear(e, W0, b0)), W2, b2)
+        o_s, o_r = torch.empty(N, dim, device="cuda"), torch.empty(N, dim, device="cuda")
+        ops.temb(t.cuda(), dim, W0.cuda(), b0.cuda(), W2.cuda(), b2.cuda(), o_s, o_r)
+        assert rel_l2(o_r.cpu(), raw) < 2e-5 and rel_l2(o_s.cpu(), F_.silu(raw)) < 2e-5
+    J = 1234
+    W, b = rnd(J, dim, seed=36), rnd(J, seed=37)
+    x = rnd(N, dim, seed=38)
+    y = torch.empty(N, J, device="cuda")
+    ops.linear(x.cuda(), W.cuda(), b.cuda(), y)
+    assert rel_l2(y.cpu(), F_.linear(x, W, b)) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_stem_and_head(ops, dt):
+    N, F, H, W, C = 2, 3, 8, 6, 64
+    xv = rnd(N, F, 3, H, W, seed=39)
+    ws, bs = rnd(C, 3, 3, 3, seed=40, scale=27 ** -0.5), rnd(C, seed=41)
+    out = torch.empty(N * F * H * W, C, dtype=dt, device="cuda")
+    ops.stem_conv(xv.cuda(), ops.pack_edge_weight(ws).cuda(), bs.cuda(), out, N, F, 3, H, W, ops.TAPS_SPATIAL)
+    ref = F_.conv3d(xv.permute(0, 2, 1, 3, 4), ws[:, :, None], bs, padding=(0, 1, 1))
+    assert rel_l2(unrows_video(out.float().cpu(), N, F, H, W), ref) < tol(dt)
+    xa = rnd(N, 1, 50, seed=42)
+    wa, ba = rnd(C, 1, 3, seed=43), rnd(C, seed=44)
+    out = torch.empty(N * 50, C, dtype=dt, device="cuda")
+    ops.stem_conv(xa.cuda(), ops.pack_edge_weight(wa).cuda(), ba.cuda(), out, N, 1, 1, 1, 50, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+    assert rel_l2(out.float().cpu().reshape(N, 50, C).permute(0, 2, 1), F_.conv1d(xa, wa, ba, padding=1)) < tol(dt)
+    for Co in (3, 6):
+        h = rnd(N, C, F, H, W, dt=dt, seed=45)
+        wh, bh = rnd(Co, C, 3, 3, 3, seed=46, scale=(27 * C) ** -0.5), rnd(Co, seed=47)
+        y = torch.empty(N, F, Co, H, W, device="cuda")
+        ops.head_conv(dev(rows_video(h), dt), ops.pack_edge_weight(wh).cuda(), bh.cuda(), y, N, F, H, W, ops.TAPS_3D)
+        ref = F_.conv3d(h, wh, bh, padding=1).permute(0, 2, 1, 3, 4)
+        assert rel_l2(y.cpu(), ref) < 2e-5
+    for Co in (1, 2):
+        h = rnd(N, C, 50, dt=dt, seed=48)
+        wh, bh = rnd(Co, C, 3, seed=49), rnd(Co, seed=50)
+        y = torch.empty(N, Co, 50, device="cuda")
+        ops.head_conv(dev(rows_audio(h), dt), ops.pack_edge_weight(wh).cuda(), bh.cuda(), y, N, 1, 1, 50, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+        assert rel_l2(y.cpu(), F_.conv1d(h, wh, bh, padding=1)) < 2e-5
+
+
+@pytest.mark.parametrize("learn_sigma", [False, True])
+def test_ddpm_update(ops, learn_sigma):
+    from oracle import diffusion_ref as dref
+    S = dref.Schedule(respacing="10", learn_sigma=learn_sigma)
+    N, F, C, HW = 3, 4, 3, 20
+    x, noise = rnd(N, F, C, HW, seed=51), rnd(N, F, C, HW, seed=52)
+    mo = rnd(N, F, 2 * C if learn_sigma else C, HW, seed=53)
+    t = torch.tensor([9, 0, 4])
+    mean, logvar, x0 = dref.p_mean_variance(S, mo, x, t, 2, clip=True)
+    nz = (t != 0).float().reshape(-1, 1, 1, 1)
+    ref = mean + nz * torch.exp(0.5 * logvar) * noise
+    tab = np.stack([S.sqrt_recip_ac, S.sqrt_recipm1_ac, S.post_c1, S.post_c2,
+                    np.log(np.append(S.post_var[1], S.betas[1:])), S.post_logvar_clipped, np.log(S.betas)])
+    tab = torch.from_numpy(tab).float().cuda()
+    out, x0o = torch.empty(N, F, C, HW, device="cuda"), torch.empty(N, F, C, HW, device="cuda")
+    ops.ddpm_update(x.cuda(), mo.cuda(), noise.cuda(), out, tab, t.cuda(), F, C, HW, 1 | (4 if learn_sigma else 0), x0_out=x0o)
+    assert rel_l2(out.cpu(), ref) < 1e-6 and rel_l2(x0o.cpu(), x0) < 1e-6
+    xq = torch.empty_like(out)
+    ops.q_sample(x.cuda(), noise.cuda(), xq, torch.from_numpy(np.stack([S.sqrt_ac, S.sqrt_1mac])).float().cuda(), t.cuda())
+    assert rel_l2(xq.cpu(), dref.q_sample(S, x, t, noise)) < 1e-6
