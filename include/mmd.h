@@ -112,9 +112,11 @@ int mmd_head_conv(int dtype, const void* x, int64_t ldx, const float* w, const f
 /* One DDPM ancestral step for one stream (p_mean_variance + p_sample, multimodal_gaussian_diffusion.py:231-343,
  * 415-474) on API-layout fp32 tensors x/noise/out [N,F,C,HW], model_out [N,F,Cm,HW] (Cm = 2C with flag 4).
  * tables fp32 [7][T]: sqrt_recip_ac, sqrt_recipm1_ac, post_c1, post_c2, fixed logvar, min_log, max_log;
- * t int64[N] device.  flags: 1 clip x0, 2 model predicts x0, 4 learned-range variance.  x0_out nullable. */
-int mmd_ddpm_update(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, const float* tables,
-                    const int64_t* t, int T, int N, int F, int C, int HW, int flags, void* stream);
+ * t int64[N] device.  flags: 1 clip x0, 2 model predicts x0, 4 learned-range variance.  out (sample = mean +
+ * [t!=0] exp(logvar/2) noise), x0_out, mean_out, logvar_out are each nullable (p_mean_variance alone: out = NULL). */
+int mmd_ddpm_update(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, float* mean_out,
+                    float* logvar_out, const float* tables, const int64_t* t, int T, int N, int F, int C, int HW, int flags,
+                    void* stream);
 /* q_sample (gd:187-205): out = tab2[0][t] x0 + tab2[1][t] eps. */
 int mmd_q_sample(const float* x0, const float* eps, float* out, const float* tab2, const int64_t* t, int T, int N,
                  int64_t per_sample, void* stream);

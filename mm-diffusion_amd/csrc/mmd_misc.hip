@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadConvParams p) 
 // x, noise, out: fp32 [N, F, C, HW] ; model_out fp32 [N, F, Cm, HW] with Cm = C (fixed var) or 2C (learned range)
 // flags bit0: clip x0 to [-1,1], bit1: model predicts x0, bit2: learned-range variance
 struct DdpmParams {
-  const float* x; const float* mo; const float* noise; float* out; float* x0_out;
+  const float* x; const float* mo; const float* noise; float* out; float* x0_out; float* mean_out; float* logvar_out;
   const float* tables; const int64_t* t;
   int T, N, F, C, HW, flags;
 };
@@ -243,8 +243,10 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(const DdpmParams p) {
     if (p.flags & 1) x0 = fminf(fmaxf(x0, -1.f), 1.f);
     const float mean = c1 * x0 + c2 * xv;
     const float nz = ti != 0 ? 1.f : 0.f;
-    p.out[i] = mean + nz * expf(0.5f * logvar) * p.noise[i];
+    if (p.out) p.out[i] = mean + nz * expf(0.5f * logvar) * p.noise[i];
     if (p.x0_out) p.x0_out[i] = x0;
+    if (p.mean_out) p.mean_out[i] = mean;
+    if (p.logvar_out) p.logvar_out[i] = logvar;
   }
 }
 
@@ -352,10 +354,13 @@ extern "C" int mmd_head_conv(int dtype, const void* x, int64_t ldx, const float*
 }
 
 extern "C" int mmd_ddpm_update(const float* x, const float* model_out, const float* noise, float* out, float* x0_out,
-                               const float* tables, const int64_t* t, int T, int N, int F, int C, int HW, int flags, void* stream) {
-  MMD_REQUIRE(x && model_out && noise && out && tables && t && T > 0 && N > 0 && F > 0 && C > 0 && HW > 0, "ddpm_update: bad argument");
+                               float* mean_out, float* logvar_out, const float* tables, const int64_t* t, int T, int N, int F,
+                               int C, int HW, int flags, void* stream) {
+  MMD_REQUIRE(x && model_out && tables && t && T > 0 && N > 0 && F > 0 && C > 0 && HW > 0, "ddpm_update: bad argument");
+  MMD_REQUIRE(!out || noise, "ddpm_update: sampling (out != NULL) needs noise");
   DdpmParams p;
-  p.x = x; p.mo = model_out; p.noise = noise; p.out = out; p.x0_out = x0_out; p.tables = tables; p.t = t;
+  p.x = x; p.mo = model_out; p.noise = noise; p.out = out; p.x0_out = x0_out; p.mean_out = mean_out; p.logvar_out = logvar_out;
+  p.tables = tables; p.t = t;
   p.T = T; p.N = N; p.F = F; p.C = C; p.HW = HW; p.flags = flags;
   hipLaunchKernelGGL(ddpm_update_kernel, dim3(ew_grid((int64_t)N * F * C * HW)), dim3(256), 0, (hipStream_t)stream, p);
   return mmd_check_launch("ddpm_update");

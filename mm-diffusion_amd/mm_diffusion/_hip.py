@@ -36,7 +36,7 @@ _PROTOS = {
     "mmd_copy2d": (i32, [vp, i64, vp, i64, i64, i64, vp]),
     "mmd_stem_conv": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
     "mmd_head_conv": (i32, [i32, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
-    "mmd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mmd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
 }
 EXPORTS = tuple(_PROTOS)

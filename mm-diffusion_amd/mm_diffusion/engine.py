@@ -1,0 +1,435 @@
+"""Launch-plan engine: turns a MultimodalUNet parameter tree into a flat list of libmmd kernel launches.
+
+Built once per (batch, dtype, device):
+  * weights are packed for the kernels (GEMM operands [Cout][tap*Cin] in the activation dtype, biases /
+    GroupNorm affine / emb Linear in fp32, all ResBlock emb_layers concatenated into ONE Linear)
+  * every activation buffer is pre-allocated from a plan-time pool (liveness-based reuse, so the working set
+    stays small and L2/MALL resident); skip-connection concats are free: each input block writes its output
+    straight into the right-hand column slice of the buffer its output block will read, and the previous
+    output block writes the left-hand slice
+  * the window shifts / timesteps live in device buffers, so the identical plan can be captured into a
+    hipGraph (mmd_graph_*) and replayed with new shifts and timesteps every denoising step
+Layout: video rows (n, f, h, w) x C, audio rows (n, l) x C; API-layout conversion happens only inside the
+stem (InitialBlock) and head kernels.
+"""
+import torch
+
+from . import _hip as H
+from . import ops
+from .ops import Geom
+
+
+class _Pool:
+    """Plan-time buffer pool with reuse by liveness (run-time order == plan order on one stream)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = []
+        self.all = []
+
+    def get(self, nbytes):
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        best = None
+        for i, raw in enumerate(self.free):
+            sz = raw.numel()
+            if sz >= nbytes and sz <= 2 * nbytes + 65536 and (best is None or sz < self.free[best].numel()):
+                best = i
+        if best is not None:
+            return self.free.pop(best)
+        raw = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.all.append(raw)
+        return raw
+
+    def put(self, raw):
+        self.free.append(raw)
+
+    def total_bytes(self):
+        return sum(r.numel() for r in self.all)
+
+
+class UNetEngine:
+    def __init__(self, model, N, dtype, device):
+        if not torch.cuda.is_available():
+            raise H.MMDError("no HIP device visible: the MI355X path cannot run (no CPU fallback)")
+        H.lib()
+        self.model, self.N, self.dtype, self.device = model, N, dtype, torch.device(device)
+        self.F, self.Cv_in, self.H0, self.W0 = model.video_size
+        self.Ca_in, self.L0 = model.audio_size
+        self.mc = model.model_channels
+        self.params = {k: v for k, v in model.named_parameters()}
+        for k, v in self.params.items():
+            if v.device.type != "cuda":
+                raise H.MMDError(f"parameter {k} is on {v.device}: move the model to the GPU first (model.to('cuda'))")
+        self._sig = self._signature()
+        self.pool = _Pool(self.device)
+        self.keep = []          # packed weights etc. (kept alive)
+        self.plan = []
+        self.graph = None
+        self._build()
+
+    # ------------------------------------------------------------------ staleness
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.params.values())
+
+    def stale(self):
+        return self._sig != self._signature()
+
+    # ------------------------------------------------------------------ helpers
+    def _alloc(self, rows, C, dtype=None):
+        dtype = dtype or self.dtype
+        es = torch.empty(0, dtype=dtype).element_size()
+        raw = self.pool.get(rows * C * es)
+        t = raw[: rows * C * es].view(dtype).view(rows, C)
+        t._raw = raw
+        return t
+
+    def _release(self, *ts):
+        for t in ts:
+            if t is not None and hasattr(t, "_raw"):
+                self.pool.put(t._raw)
+                del t._raw
+
+    def _static(self, shape, dtype):
+        t = torch.zeros(shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def _f32(self, key):
+        t = self.params[key].detach().float().contiguous()
+        self.keep.append(t)
+        return t
+
+    def _gemm_w(self, key):
+        t = ops.pack_conv_weight(self.params[key].detach().float(), self.dtype)
+        self.keep.append(t)
+        return t
+
+    def _edge_w(self, key):
+        t = ops.pack_edge_weight(self.params[key].detach())
+        self.keep.append(t)
+        return t
+
+    def _gn(self, x, prefix, geom, act, film=None, out=None):
+        """GroupNorm32(+FiLM)(+SiLU): stats -> fused affine -> apply.  Returns the normalised tensor."""
+        C = x.shape[1]
+        a = self._alloc(geom.S, C, torch.float32)
+        b = self._alloc(geom.S, C, torch.float32)
+        nws = H.lib().mmd_gn_workspace_bytes(geom.S, geom.Tn)
+        ws = self._alloc(nws // 8, 1, torch.float64)
+        ops.gn_stats(x, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), geom,
+                     film=film, a=a, b=b, ws=ws)
+        y = self._alloc(x.shape[0], C) if out is None else out
+        ops.gn_apply(x, a, b, geom, act=act, out=y)
+        self._release(a, b, ws)
+        return y
+
+    def _pw(self, x, wkey, bkey, residual=None, out=None):
+        y = self._alloc(x.shape[0], self.params[wkey].shape[0]) if out is None else out
+        return ops.conv_gemm(x, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y)
+
+    # ------------------------------------------------------------------ blocks
+    def _self_attn(self, x, prefix, kind, Hh, out):
+        """SingleModalAtten on rows x [rows, C]: kind in {'spatial','temporal','audio'} (unet:246-287,485-493)."""
+        N, F, C = self.N, self.F, x.shape[1]
+        heads = self.model.num_heads
+        ch = C // heads
+        rows = x.shape[0]
+        if kind == "spatial":
+            geom = Geom.spatial(N, F, Hh * Hh)
+        elif kind == "temporal":
+            geom = Geom.temporal(N, F, Hh * Hh)
+        else:
+            geom = Geom.per_sample(N, rows // N)
+        n1 = self._gn(x, prefix + ".norm", geom, act=False)
+        qkv = self._pw(n1, prefix + ".qkv.weight", prefix + ".qkv.bias")
+        self._release(n1)
+        att = self._alloc(rows, C)
+        if kind == "temporal":
+            if F > 32:
+                raise H.MMDError(f"temporal attention over {F} frames: the short-sequence kernel handles <= 32")
+            ops.attn_small(qkv, att, C, heads, geom)
+        else:
+            T = geom.Tn
+            G = F if kind == "spatial" else 1
+            ops.attn(qkv, qkv, att, heads, ch, N, G, G * T, T, G * T, T, 1)
+        self._release(qkv)
+        self._pw(att, prefix + ".proj_out.weight", prefix + ".proj_out.bias", residual=x, out=out)
+        self._release(att)
+        return out
+
+    def _res(self, v, a, layer, Hh, L, out_v=None, out_a=None):
+        """ResBlock (unet:434-495).  v [N*F*H*H, cin], a [N*L, cin].  Returns (v', a', H', L')."""
+        N, F = self.N, self.F
+        p, cin, cout = layer["prefix"], layer["cin"], layer["cout"]
+        ss = self.model.use_scale_shift_norm
+        film = self.emb_all[:, layer["emb_off"]: layer["emb_off"] + (2 * cout if ss else cout)]
+        fh = 2 if (layer["up"] or layer["down"]) else 1
+        Ho = Hh // 2 if layer["down"] else (Hh * 2 if layer["up"] else Hh)
+        Lo = L // 4 if layer["down"] else (L * 4 if layer["up"] else L)
+        mode = 0 if layer["down"] else 1
+
+        def stream(x, mod, rows_in, rows_out, out):
+            vid = mod == "video"
+            t0 = self._gn(x, f"{p}.{mod}_in_layers.0", Geom.per_sample(N, rows_in // N), act=True)
+            if vid:
+                t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
+                                   self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,
+                                   dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
+                self._release(t0)
+                h = ops.conv_gemm(t1, self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight"),
+                                  self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), taps=ops.TAPS_TEMPORAL,
+                                  dims=(F, Hh * Hh, 1), out=self._alloc(rows_in, cout))
+                self._release(t1)
+            else:
+                h = ops.conv_gemm(t0, self._gemm_w(f"{p}.audio_in_layers.2.audio_conv.weight"),
+                                  self._f32(f"{p}.audio_in_layers.2.audio_conv.bias"), taps=ops.taps_audio(layer["dilation"]),
+                                  dims=(L, 1, 1), out=self._alloc(rows_in, cout))
+                self._release(t0)
+            xs = x
+            if fh != 1:        # conv at the input resolution, THEN resample both h and x (unet:441-448)
+                hp, xp = self._alloc(rows_out, cout), self._alloc(rows_out, cin)
+                if vid:
+                    ops.resample(h, hp, N * F, Hh, Hh, 2, 2, mode)
+                    ops.resample(x, xp, N * F, Hh, Hh, 2, 2, mode)
+                else:
+                    ops.resample(h, hp, N, 1, L, 1, 4, mode)
+                    ops.resample(x, xp, N, 1, L, 1, 4, mode)
+                self._release(h)
+                h, xs = hp, xp
+            geom = Geom.per_sample(N, rows_out // N)
+            if ss:
+                t2 = self._gn(h, f"{p}.{mod}_out_layers.0", geom, act=True, film=film)
+            else:
+                ops.add_rowbias(h, film, rows_out // N)
+                t2 = self._gn(h, f"{p}.{mod}_out_layers.0", geom, act=True)
+            self._release(h)
+            conv = "video_conv" if vid else "audio_conv"
+            if cin != cout:
+                sk = self._pw(xs, f"{p}.{mod}_skip_connection.{conv}.weight", f"{p}.{mod}_skip_connection.{conv}.bias")
+            else:
+                sk = xs
+            attn_here = layer["vattn"] if vid else layer["aattn"]
+            dest = self._alloc(rows_out, cout) if (attn_here or out is None) else out
+            self._pw(t2, f"{p}.{mod}_out_layers.3.{conv}.weight", f"{p}.{mod}_out_layers.3.{conv}.bias", residual=sk, out=dest)
+            self._release(t2)
+            if sk is not xs:
+                self._release(sk)
+            if xs is not x:
+                self._release(xs)
+            if attn_here:
+                if vid:
+                    mid = self._self_attn(dest, p + ".spatial_attention_block", "spatial", Ho, self._alloc(rows_out, cout))
+                    self._release(dest)
+                    fin = out if out is not None else self._alloc(rows_out, cout)
+                    self._self_attn(mid, p + ".temporal_attention_block", "temporal", Ho, fin)
+                    self._release(mid)
+                else:
+                    fin = out if out is not None else self._alloc(rows_out, cout)
+                    self._self_attn(dest, p + ".audio_attention_block", "audio", Ho, fin)
+                    self._release(dest)
+                dest = fin
+            return dest
+
+        vo = stream(v, "video", N * F * Hh * Hh, N * F * Ho * Ho, out_v)
+        ao = stream(a, "audio", N * L, N * Lo, out_a)
+        return vo, ao, Ho, Lo
+
+    def _cross(self, v, a, layer, Hh, L, out_v=None, out_a=None):
+        """CrossAttentionBlock (unet:655-678) with arithmetic random-shift windows."""
+        N, F = self.N, self.F
+        p, C, heads, win = layer["prefix"], layer["ch"], layer["heads"], layer["window"]
+        ch = C // heads
+        HW, apf = Hh * Hh, int(L / F)
+        if apf < 1:
+            raise H.MMDError(f"cross attention needs at least one audio token per frame (L={L}, F={F})")
+        vn = self._gn(v, p + ".v_norm", Geom.per_sample(N, F * HW), act=False)
+        vqkv = self._pw(vn, p + ".v_qkv.weight", p + ".v_qkv.bias")
+        self._release(vn)
+        an = self._gn(a, p + ".a_norm", Geom.per_sample(N, L), act=False)
+        aqkv = self._pw(an, p + ".a_qkv.weight", p + ".a_qkv.bias")
+        self._release(an)
+        sh = self.shift_dev[layer["shift_idx"]: layer["shift_idx"] + 1] if layer["shift"] else None
+        vatt, aatt = self._alloc(N * F * HW, C), self._alloc(N * L, C)
+        ops.attn(vqkv, aqkv, vatt, heads, ch, N, F, F * HW, HW, L, apf, win, shift_dev=sh)
+        ops.attn(aqkv, vqkv, aatt, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
+        self._release(vqkv, aqkv)
+        vo = out_v if out_v is not None else self._alloc(N * F * HW, C)
+        ao = out_a if out_a is not None else self._alloc(N * L, C)
+        self._pw(vatt, p + ".video_proj_out.video_conv.weight", p + ".video_proj_out.video_conv.bias", residual=v, out=vo)
+        self._pw(aatt, p + ".audio_proj_out.audio_conv.weight", p + ".audio_proj_out.audio_conv.bias", residual=a, out=ao)
+        self._release(vatt, aatt)
+        return vo, ao
+
+    # ------------------------------------------------------------------ plan
+    def _build(self):
+        m, N, F, dt = self.model, self.N, self.F, self.dtype
+        arch_in, arch_mid, arch_out = m._arch
+        if self.H0 != self.W0:
+            raise H.MMDError("square frames only (the reference's avg-pool/upsample path is exercised on H == W)")
+        # ---- static I/O buffers
+        self.x_video = self._static((N, F, self.Cv_in, self.H0, self.W0), torch.float32)
+        self.x_audio = self._static((N, self.Ca_in, self.L0), torch.float32)
+        self.t_i64 = self._static((N,), torch.int64)
+        self.t_f32 = self._static((N,), torch.float32)
+        self.out_video = self._static((N, F, m.video_out_channels, self.H0, self.W0), torch.float32)
+        self.out_audio = self._static((N, m.audio_out_channels, self.L0), torch.float32)
+        # ---- shifts + emb Linear concatenation
+        nshift, off = 0, 0
+        Ws, bs = [], []
+        for blk in arch_in + [arch_mid] + arch_out:
+            for layer in blk:
+                if layer["kind"] == "cross" and layer["shift"]:
+                    layer["shift_idx"] = nshift
+                    nshift += 1
+                if layer["kind"] == "res":
+                    layer["emb_off"] = off
+                    W = self.params[layer["prefix"] + ".emb_layers.1.weight"]
+                    Ws.append(W.detach().float())
+                    bs.append(self.params[layer["prefix"] + ".emb_layers.1.bias"].detach().float())
+                    off += W.shape[0]
+        self.nshift = nshift
+        self.shift_dev = self._static((max(nshift, 1),), torch.int32)
+        self.shift_host = torch.zeros(max(nshift, 1), dtype=torch.int32).pin_memory()
+        self.emb_W = torch.cat(Ws).contiguous()
+        self.emb_b = torch.cat(bs).contiguous()
+        self.emb_silu = self._static((N, self.mc), torch.float32)
+        self.emb_all = self._static((N, off), torch.float32)
+
+        def record(t_tensor):
+            plan = []
+            with ops.recording(plan):
+                self._record(t_tensor, arch_in, arch_mid, arch_out)
+            return plan
+
+        # two plans that differ only in the timestep dtype read by the first kernel
+        self.plan = record(self.t_i64)
+        self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name) if name == "mmd_temb_fwd" else (fn, args, name)
+                         for fn, args, name in self.plan]
+
+    def _record(self, t_tensor, arch_in, arch_mid, arch_out):
+        m, N, F, dt = self.model, self.N, self.F, self.dtype
+        mc = self.mc
+        ops.temb(t_tensor, mc, self._f32("time_embed.0.weight"), self._f32("time_embed.0.bias"),
+                 self._f32("time_embed.2.weight"), self._f32("time_embed.2.bias"), self.emb_silu)
+        ops.linear(self.emb_silu, self.emb_W, self.emb_b, self.emb_all)
+
+        # consumer channel split of every skip: output block k reads [h (ch_prev) | skip (ich)]
+        skip_cols = []
+        ch = arch_mid[-1]["cout"]
+        for layers in arch_out:
+            ich = layers[0]["skip_ch"]
+            skip_cols.append((ch, ich))
+            ch = layers[-1]["cout"] if layers[-1]["kind"] == "res" else layers[-1]["ch"]
+
+        Hh, L = self.H0, self.L0
+        cat_bufs = []   # per input block: (video cat buffer, audio cat buffer) for its consumer
+        v = a = None
+        nin = len(arch_in)
+        for i, layers in enumerate(arch_in):
+            chp, ich = skip_cols[nin - 1 - i]
+            # geometry of this block's OUTPUT
+            Ho, Lo = Hh, L
+            for layer in layers:
+                if layer["kind"] == "res" and layer["down"]:
+                    Ho, Lo = Hh // 2, L // 4
+            vcat = self._alloc(N * F * Ho * Ho, chp + ich)
+            acat = self._alloc(N * Lo, chp + ich)
+            cat_bufs.append((vcat, acat))
+            ov, oa = vcat[:, chp:], acat[:, chp:]
+            for j, layer in enumerate(layers):
+                last = j == len(layers) - 1
+                tv, ta = (ov, oa) if last else (None, None)
+                if layer["kind"] == "init":
+                    C0 = layer["cout"]
+                    p = layer["prefix"]
+                    s1 = self._alloc(N * F * Hh * Hh, C0)
+                    ops.stem_conv(self.x_video, self._edge_w(p + ".video_conv.video_conv_spatial.weight"),
+                                  self._f32(p + ".video_conv.video_conv_spatial.bias"), s1, N, F, self.Cv_in, Hh, Hh,
+                                  ops.TAPS_SPATIAL)
+                    nv = ops.conv_gemm(s1, self._gemm_w(p + ".video_conv.video_conv_temporal.weight"),
+                                       self._f32(p + ".video_conv.video_conv_temporal.bias"), taps=ops.TAPS_TEMPORAL,
+                                       dims=(F, Hh * Hh, 1), out=tv if tv is not None else self._alloc(N * F * Hh * Hh, C0))
+                    self._release(s1)
+                    na = tv is not None and ta or self._alloc(N * L, C0)
+                    ops.stem_conv(self.x_audio, self._edge_w(p + ".audio_conv.audio_conv.weight"),
+                                  self._f32(p + ".audio_conv.audio_conv.bias"), na, N, 1, self.Ca_in, 1, L,
+                                  [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+                elif layer["kind"] == "res":
+                    nv, na, Hh, L = self._res(v, a, layer, Hh, L, tv, ta)
+                else:
+                    nv, na = self._cross(v, a, layer, Hh, L, tv, ta)
+                if j > 0:            # intermediates inside a block are ours; block inputs belong to the skip stack
+                    self._release(v, a)
+                v, a = nv, na
+
+        # ---- middle: last layer writes the left slice of the first output block's concat buffer
+        def run_block(layers, v, a, Hh, L, ov, oa, own_input):
+            for j, layer in enumerate(layers):
+                last = j == len(layers) - 1
+                tv, ta = (ov, oa) if last else (None, None)
+                if layer["kind"] == "res":
+                    nv, na, Hh, L = self._res(v, a, layer, Hh, L, tv, ta)
+                else:
+                    nv, na = self._cross(v, a, layer, Hh, L, tv, ta)
+                if j > 0 or own_input:
+                    self._release(v, a)
+                v, a = nv, na
+            return v, a, Hh, L
+
+        vcat, acat = cat_bufs[-1]
+        chp, _ = skip_cols[0]
+        v, a, Hh, L = run_block(arch_mid, v, a, Hh, L, vcat[:, :chp], acat[:, :chp], own_input=False)
+
+        # ---- output blocks
+        for k, layers in enumerate(arch_out):
+            vcat, acat = cat_bufs[nin - 1 - k]
+            if k + 1 < len(arch_out):
+                nvcat, nacat = cat_bufs[nin - 2 - k]
+                chn, _ = skip_cols[k + 1]
+                ov, oa = nvcat[:, :chn], nacat[:, :chn]
+            else:
+                ov = oa = None
+            v, a, Hh, L = run_block(layers, vcat, acat, Hh, L, ov, oa, own_input=False)
+            self._release(vcat, acat)
+
+        # ---- heads: GN -> SiLU -> conv (unet:1003-1012), fp32 API-layout outputs
+        hv = self._gn(v, "video_out.0", Geom.per_sample(N, F * Hh * Hh), act=True)
+        ops.head_conv(hv, self._edge_w("video_out.2.video_conv.weight"), self._f32("video_out.2.video_conv.bias"),
+                      self.out_video, N, F, Hh, Hh, ops.TAPS_3D)
+        ha = self._gn(a, "audio_out.0", Geom.per_sample(N, L), act=True)
+        ops.head_conv(ha, self._edge_w("audio_out.2.audio_conv.weight"), self._f32("audio_out.2.audio_conv.bias"),
+                      self.out_audio, N, 1, 1, L, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+        self._release(hv, ha, v, a)
+
+    # ------------------------------------------------------------------ execution
+    def set_inputs(self, video, audio, timesteps, shifts):
+        N = self.N
+        if tuple(video.shape) != tuple(self.x_video.shape) or tuple(audio.shape) != tuple(self.x_audio.shape):
+            raise H.MMDError(f"input shapes {tuple(video.shape)}/{tuple(audio.shape)} do not match the model's "
+                             f"{tuple(self.x_video.shape)}/{tuple(self.x_audio.shape)}")
+        if video.data_ptr() != self.x_video.data_ptr():
+            self.x_video.copy_(video)
+        if audio.data_ptr() != self.x_audio.data_ptr():
+            self.x_audio.copy_(audio)
+        use_f32 = timesteps.dtype.is_floating_point
+        tgt = self.t_f32 if use_f32 else self.t_i64
+        if timesteps.data_ptr() != tgt.data_ptr():
+            tgt.copy_(timesteps)
+        self.set_shifts(shifts)
+        return use_f32
+
+    def set_shifts(self, shifts):
+        if self.nshift:
+            if len(shifts) != self.nshift:
+                raise H.MMDError(f"expected {self.nshift} window shifts, got {len(shifts)}")
+            for i, s in enumerate(shifts):
+                self.shift_host[i] = int(s)
+            self.shift_dev.copy_(self.shift_host, non_blocking=True)
+
+    def run(self, use_f32=False):
+        ops.run_plan(self.plan_f32 if use_f32 else self.plan, H.stream_handle())
+
+    def forward(self, video, audio, timesteps, shifts):
+        use_f32 = self.set_inputs(video, audio, timesteps, shifts)
+        self.run(use_f32)
+        return self.out_video.clone(), self.out_audio.clone()

@@ -11,6 +11,38 @@ from . import _hip as H
 
 GN_EPS = 1e-5
 
+# When a recorder list is installed, ops append (cfunc, args, name) instead of launching: the engine replays
+# such a plan with `cfunc(*args, stream)` (every libmmd entry point takes the stream as its LAST argument).
+_recorder = None
+
+
+class recording:
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        global _recorder
+        self._prev, _recorder = _recorder, self.plan
+        return self.plan
+
+    def __exit__(self, *a):
+        global _recorder
+        _recorder = self._prev
+
+
+def _dispatch(name, *args):
+    if _recorder is not None:
+        _recorder.append((getattr(H.lib(), name), args, name))
+    else:
+        H.call(name, *args, H.stream_handle())
+
+
+def run_plan(plan, stream):
+    for fn, args, name in plan:
+        rc = fn(*args, stream)
+        if rc != 0:
+            raise H.MMDError(f"{name} failed ({rc}): {H.lib().mmd_last_error().decode()}")
+
 
 class Geom:
     """Slice geometry of a GroupNorm / short-attention instance (see include/mmd.h: mmd_gn_stats)."""
@@ -54,9 +86,8 @@ def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None):
     a = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if a is None else a
     b = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if b is None else b
     ws = gn_workspace(geom, x.device) if ws is None else ws
-    H.call("mmd_gn_stats", H.dt_of(x), x.data_ptr(), x.stride(0), C, *geom.args(), gamma.data_ptr(), beta.data_ptr(),
-           H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), ws.data_ptr(),
-           H.stream_handle())
+    _dispatch("mmd_gn_stats", H.dt_of(x), x.data_ptr(), x.stride(0), C, *geom.args(), gamma.data_ptr(), beta.data_ptr(),
+           H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), ws.data_ptr())
     return a, b
 
 
@@ -64,15 +95,15 @@ def gn_apply(x, a, b, geom: Geom, act=True, out=None):
     _chk2d(x)
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
-    H.call("mmd_gn_apply", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
-           *geom.args(), a.data_ptr(), b.data_ptr(), 1 if act else 0, H.stream_handle())
+    _dispatch("mmd_gn_apply", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+           *geom.args(), a.data_ptr(), b.data_ptr(), 1 if act else 0)
     return out
 
 
 def add_rowbias(x, e, rows_per_sample):
     _chk2d(x)
-    H.call("mmd_add_rowbias", H.dt_of(x), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], rows_per_sample,
-           e.data_ptr(), e.stride(0), H.stream_handle())
+    _dispatch("mmd_add_rowbias", H.dt_of(x), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], rows_per_sample,
+           e.data_ptr(), e.stride(0))
     return x
 
 
@@ -97,9 +128,9 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     arr, nt = H.taps_array(taps)
-    H.call("mmd_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias),
+    _dispatch("mmd_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias),
            H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
-           M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile, H.stream_handle())
+           M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile)
     return out
 
 
@@ -110,32 +141,31 @@ def attn(q, kv, out, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per
     C = heads * ch
     k_off = C if k_off is None else k_off
     v_off = 2 * C if v_off is None else v_off
-    H.call("mmd_attn_fwd", H.dt_of(q), q.data_ptr(), q.stride(0), q_off, kv.data_ptr(), kv.stride(0), k_off, v_off,
+    _dispatch("mmd_attn_fwd", H.dt_of(q), q.data_ptr(), q.stride(0), q_off, kv.data_ptr(), kv.stride(0), k_off, v_off,
            out.data_ptr(), out.stride(0), heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group,
-           win, H.ptr(shift_dev), impl, H.stream_handle())
+           win, H.ptr(shift_dev), impl)
     return out
 
 
 def attn_small(qkv, out, C, heads, geom: Geom):
     _chk2d(qkv), _chk2d(out)
-    H.call("mmd_attn_small_fwd", H.dt_of(qkv), qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), C, heads,
-           *geom.args(), H.stream_handle())
+    _dispatch("mmd_attn_small_fwd", H.dt_of(qkv), qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), C, heads,
+           *geom.args())
     return out
 
 
 def resample(x, out, NF, Hh, Ww, fh, fw, mode):
     """mode 0 avg-pool / 1 nearest-upsample by (1, fh, fw); Hh, Ww describe the input rows (nf, h, w)."""
     _chk2d(x), _chk2d(out)
-    H.call("mmd_resample", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], NF, Hh, Ww,
-           fh, fw, mode, H.stream_handle())
+    _dispatch("mmd_resample", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], NF, Hh, Ww,
+           fh, fw, mode)
     return out
 
 
 def copy2d(x, out):
     _chk2d(x), _chk2d(out)
     es = x.element_size()
-    H.call("mmd_copy2d", x.data_ptr(), x.stride(0) * es, out.data_ptr(), out.stride(0) * es, x.shape[0], x.shape[1] * es,
-           H.stream_handle())
+    _dispatch("mmd_copy2d", x.data_ptr(), x.stride(0) * es, out.data_ptr(), out.stride(0) * es, x.shape[0], x.shape[1] * es)
     return out
 
 
@@ -144,14 +174,13 @@ def temb(t, dim, W0, b0, W2, b2, out_silu, out_raw=None):
     if kind is None:
         raise H.MMDError(f"timesteps must be int64/int32/float32, got {t.dtype}")
     H.require_cuda(t, W0)
-    H.call("mmd_temb_fwd", t.data_ptr(), kind, t.shape[0], dim, W0.data_ptr(), b0.data_ptr(), W2.data_ptr(), b2.data_ptr(),
-           out_silu.data_ptr(), H.ptr(out_raw), H.stream_handle())
+    _dispatch("mmd_temb_fwd", t.data_ptr(), kind, t.shape[0], dim, W0.data_ptr(), b0.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+           out_silu.data_ptr(), H.ptr(out_raw))
     return out_silu
 
 
 def linear(x, W, b, out):
-    H.call("mmd_linear_fwd", x.data_ptr(), W.data_ptr(), H.ptr(b), out.data_ptr(), x.shape[0], x.shape[1], W.shape[0],
-           H.stream_handle())
+    _dispatch("mmd_linear_fwd", x.data_ptr(), W.data_ptr(), H.ptr(b), out.data_ptr(), x.shape[0], x.shape[1], W.shape[0])
     return out
 
 
@@ -159,8 +188,8 @@ def stem_conv(x, w, bias, out, N, F, Cin, Hh, Ww, taps):
     """x fp32 contiguous [N,F,Cin,H,W]; w fp32 [ntaps, Cin, Cout]; out rows [N*F*H*W, Cout]."""
     _chk2d(out)
     arr, nt = H.taps_array(taps)
-    H.call("mmd_stem_conv", H.dt_of(out), x.data_ptr(), w.data_ptr(), H.ptr(bias), out.data_ptr(), out.stride(0), N, F, Cin,
-           Hh, Ww, out.shape[1], nt, arr, H.stream_handle())
+    _dispatch("mmd_stem_conv", H.dt_of(out), x.data_ptr(), w.data_ptr(), H.ptr(bias), out.data_ptr(), out.stride(0), N, F, Cin,
+           Hh, Ww, out.shape[1], nt, arr)
     return out
 
 
@@ -168,22 +197,22 @@ def head_conv(x, w, bias, out, N, F, Hh, Ww, taps):
     """x rows [N*F*H*W, Cin]; w fp32 [ntaps, Cin, Co]; out fp32 contiguous [N,F,Co,H,W]."""
     _chk2d(x)
     arr, nt = H.taps_array(taps)
-    H.call("mmd_head_conv", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), out.data_ptr(), N, F,
-           x.shape[1], Hh, Ww, w.shape[2], nt, arr, H.stream_handle())
+    _dispatch("mmd_head_conv", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), out.data_ptr(), N, F,
+           x.shape[1], Hh, Ww, w.shape[2], nt, arr)
     return out
 
 
-def ddpm_update(x, model_out, noise, out, tables, t, F, C, HW, flags, x0_out=None):
+def ddpm_update(x, model_out, noise, out, tables, t, F, C, HW, flags, x0_out=None, mean_out=None, logvar_out=None):
     H.require_cuda(x, model_out, noise, out, tables, t)
-    H.call("mmd_ddpm_update", x.data_ptr(), model_out.data_ptr(), noise.data_ptr(), out.data_ptr(), H.ptr(x0_out),
-           tables.data_ptr(), t.data_ptr(), tables.shape[1], x.shape[0], F, C, HW, flags, H.stream_handle())
+    _dispatch("mmd_ddpm_update", x.data_ptr(), model_out.data_ptr(), H.ptr(noise), H.ptr(out), H.ptr(x0_out),
+              H.ptr(mean_out), H.ptr(logvar_out), tables.data_ptr(), t.data_ptr(), tables.shape[1], x.shape[0], F, C, HW, flags)
     return out
 
 
 def q_sample(x0, eps, out, tab2, t):
     H.require_cuda(x0, eps, out, tab2, t)
-    H.call("mmd_q_sample", x0.data_ptr(), eps.data_ptr(), out.data_ptr(), tab2.data_ptr(), t.data_ptr(), tab2.shape[1],
-           x0.shape[0], x0[0].numel(), H.stream_handle())
+    _dispatch("mmd_q_sample", x0.data_ptr(), eps.data_ptr(), out.data_ptr(), tab2.data_ptr(), t.data_ptr(), tab2.shape[1],
+           x0.shape[0], x0[0].numel())
     return out
 
 

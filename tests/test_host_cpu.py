@@ -1,0 +1,119 @@
+"""Host-side logic of the product (no GPU): flag surface, state-dict parity, diffusion tables, respacing,
+loud failure without a device."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import DEFAULT_FLAGS, GOLD, flags, gold, gold_keys
+
+
+def test_flag_surface_matches_reference_defaults():
+    from mm_diffusion import multimodal_script_util as msu
+    assert msu.model_and_diffusion_defaults() == DEFAULT_FLAGS
+    import argparse
+    p = argparse.ArgumentParser()
+    msu.add_dict_to_argparser(p, msu.model_and_diffusion_defaults())
+    a = p.parse_args(["--use_fp16", "True", "--num_channels", "64", "--resblock_updown", "yes"])
+    assert a.use_fp16 is True and a.num_channels == 64 and a.resblock_updown is True
+    assert msu.args_to_dict(a, ["num_channels"]) == {"num_channels": 64}
+    with pytest.raises(argparse.ArgumentTypeError):
+        msu.str2bool("maybe")
+
+
+@pytest.mark.parametrize("name,cfg,over", [("tiny", "tiny", {}), ("full", "full", {}), ("tiny_learn_sigma", "tiny", dict(learn_sigma=True))])
+def test_state_dict_keys_shapes_and_order(name, cfg, over):
+    from mm_diffusion import multimodal_script_util as msu
+    model, _ = msu.create_model_and_diffusion(**flags(cfg, **over))
+    want = gold_keys()[name]
+    assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == want
+    assert [k for k, _ in model.named_parameters()] == [k for k, _ in want]
+    assert model.video_size == flags(cfg)["video_size"] and model.audio_size == flags(cfg)["audio_size"]
+    assert model.video_out_channels == (6 if over else 3) and model.audio_out_channels == (2 if over else 1)
+    assert model.dtype == torch.float32
+    # fresh model: zero-initialised output convs like the reference (zero_module)
+    sd = model.state_dict()
+    assert float(sd["video_out.2.video_conv.weight"].abs().max()) == 0
+    assert float(sd["input_blocks.1.0.video_out_layers.3.video_conv.weight"].abs().max()) == 0
+
+
+def test_load_state_dict_tolerant():
+    from mm_diffusion import logger, multimodal_script_util as msu
+    logger.set_quiet(True)
+    model, _ = msu.create_model_and_diffusion(**flags("tiny"))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["time_embed.0.weight"] = torch.zeros(3, 3)       # shape mismatch -> dropped
+    sd.pop("time_embed.0.bias")                          # missing -> tolerated
+    sd["bogus"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):                   # strict=True would still reject the unexpected key
+        model.load_state_dict_(dict(sd), is_strict=True)
+    sd.pop("bogus")
+    model.load_state_dict_(sd, is_strict=False)
+
+
+def test_diffusion_tables_match_reference():
+    from mm_diffusion import multimodal_script_util as msu
+    from mm_diffusion import multimodal_gaussian_diffusion as gd
+    from mm_diffusion.multimodal_respace import space_timesteps
+    g = gold("tables")
+    for sched in ("linear", "cosine"):
+        for steps in (1000, 50):
+            np.testing.assert_array_equal(gd.get_named_beta_schedule(sched, steps), g[f"betas_{sched}_{steps}"])
+    with open(os.path.join(GOLD, "space_timesteps.json")) as f:
+        for k, v in json.load(f).items():
+            steps, sc = k.split("|")
+            assert sorted(space_timesteps(int(steps), sc)) == v
+    for resp in ("", "2", "250", "ddim25"):
+        d = msu.create_gaussian_diffusion(steps=1000, timestep_respacing=resp)
+        tag = resp or "full"
+        assert d.timestep_map == list(g[f"{tag}.timestep_map"])
+        for attr in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                     "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                     "posterior_mean_coef1", "posterior_mean_coef2", "sqrt_alphas_cumprod",
+                     "sqrt_one_minus_alphas_cumprod"):
+            np.testing.assert_array_equal(getattr(d, attr), g[f"{tag}.{attr}"])
+    d = msu.create_gaussian_diffusion(learn_sigma=True, predict_xstart=True, rescale_learned_sigmas=True)
+    assert d.model_var_type == gd.ModelVarType.LEARNED_RANGE and d.model_mean_type == gd.ModelMeanType.START_X
+    assert d.loss_type == gd.LossType.RESCALED_MSE
+    with pytest.raises(ValueError):
+        space_timesteps(10, "20")
+
+
+def test_shift_draws_follow_reference_order():
+    import random
+    from mm_diffusion import multimodal_script_util as msu
+    model, _ = msu.create_model_and_diffusion(**flags("tiny"))
+    g = gold("tiny_forward")
+    random.seed(int(g["seed"]))
+    assert model.draw_shifts() == list(g["shifts"])        # same global `random` stream, same call order
+    model.shift_source = lambda lo, hi: hi
+    F = 8
+    assert model.draw_shifts() == [F - 1, F - 4, F - 8, F - 8, F - 8, F - 4, F - 4, F - 1, F - 1]
+
+
+def test_no_cpu_fallback():
+    """The product never computes on the CPU: CPU tensors / missing device raise."""
+    from mm_diffusion import multimodal_script_util as msu
+    from mm_diffusion._hip import MMDError
+    fl = flags("tiny")
+    model, diff = msu.create_model_and_diffusion(**fl)
+    v, a = torch.zeros(1, *fl["video_size"]), torch.zeros(1, *fl["audio_size"])
+    with torch.no_grad(), pytest.raises(MMDError):
+        model(v, a, torch.zeros(1, dtype=torch.int64))
+    with pytest.raises(MMDError):
+        diff.p_sample_loop(model, {"video": (1, *fl["video_size"]), "audio": (1, *fl["audio_size"])},
+                           device=torch.device("cpu"), progress=False)
+    if not torch.cuda.is_available():
+        with pytest.raises(MMDError):
+            diff.q_sample(v, torch.zeros(1, dtype=torch.int64))
+
+
+def test_shard_batch_partition():
+    from mm_diffusion.dist_util import shard_batch
+    for gb, w in ((32, 8), (10, 4), (3, 8), (7, 1)):
+        parts = [shard_batch(gb, w, r) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == gb
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
