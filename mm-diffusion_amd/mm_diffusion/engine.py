@@ -350,7 +350,7 @@ class UNetEngine:
                                        self._f32(p + ".video_conv.video_conv_temporal.bias"), taps=ops.TAPS_TEMPORAL,
                                        dims=(F, Hh * Hh, 1), out=tv if tv is not None else self._alloc(N * F * Hh * Hh, C0))
                     self._release(s1)
-                    na = tv is not None and ta or self._alloc(N * L, C0)
+                    na = ta if ta is not None else self._alloc(N * L, C0)
                     ops.stem_conv(self.x_audio, self._edge_w(p + ".audio_conv.audio_conv.weight"),
                                   self._f32(p + ".audio_conv.audio_conv.bias"), na, N, 1, self.Ca_in, 1, L,
                                   [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
