@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native MM-Diffusion denoising hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one DDPM p_sample (coupled U-Net forward + fused ancestral update of both streams) of the per-GPU
+batch, replayed from one captured hipGraph.  Workload = BASELINE.json configs[1]: Landscape base model
+(133.68 M params), 250-step respacing, batch 4 per GPU, 16x3x64x64 video + 1x25600 audio, bf16 activations /
+GEMM operands with fp32 statistics and accumulation, synthetic inputs and key-seeded synthetic weights.
+Batch shards over ranks with NO data-path collective (independent trajectories) -> weak scaling.
+
+Prints ONE JSON line (rank 0).  `value` = video+audio pair denoising steps per second, whole job
+(= steps/s x global batch).  `roofline` = the dominant kernel (bf16 implicit-GEMM conv) timed live with HIP events
+on the launch stream; `cpu_baseline` = the oracle (CPU restatement, kind "port") timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mm-diffusion_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FULL = dict(video_size=[16, 3, 64, 64], audio_size=[1, 25600], num_channels=128, num_head_channels=64,
+            num_res_blocks=2, resblock_updown=True)
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+MODEL_FLOPS_PER_PAIR = 1328.8e9    # conv 1133.0 G + attention matmuls 195.8 G
+
+
+def build(dtype_flag, respacing, batch, device):
+    from mm_diffusion import logger, multimodal_script_util as msu
+    from mm_diffusion.synth import synth_init_
+    logger.set_quiet(True)
+    fl = msu.model_and_diffusion_defaults()
+    fl.update(FULL)
+    fl.update(use_fp16=(dtype_flag == "bf16"), timestep_respacing=respacing)
+    model, diff = msu.create_model_and_diffusion(**fl)
+    synth_init_(model)
+    model.to(device).eval()
+    return fl, model, diff
+
+
+def kernel_breakdown(stepper, reps=3):
+    """Per-kernel time of one step measured with HIP events on the launch stream (eager replay of the plan)."""
+    from mm_diffusion import _hip as H
+    import ctypes
+    lib = H.lib()
+    stream = H.stream_handle()
+    plan = (stepper.eng.plan_f32 if stepper.use_f32 else stepper.eng.plan) + stepper.update_plan
+    evs = []
+    for _ in range(len(plan) + 1):
+        e = ctypes.c_void_p()
+        H.call("mmd_event_create", ctypes.byref(e))
+        evs.append(e)
+    agg = {}
+    for rep in range(reps):
+        torch.cuda.synchronize()
+        lib.mmd_event_record(evs[0], stream)
+        for i, (fn, args, name, meta) in enumerate(plan):
+            rc = fn(*args, stream)
+            assert rc == 0, name
+            lib.mmd_event_record(evs[i + 1], stream)
+        torch.cuda.synchronize()
+        ms = ctypes.c_float()
+        for i, (fn, args, name, meta) in enumerate(plan):
+            H.call("mmd_event_elapsed_ms", evs[i], evs[i + 1], ctypes.byref(ms))
+            label, flops, nbytes = meta
+            a = agg.setdefault(label, dict(ms=0.0, calls=0, flops=0, bytes=0))
+            a["ms"] += ms.value
+            a["calls"] += 1
+            a["flops"] += flops
+            a["bytes"] += nbytes
+    for e in evs:
+        lib.mmd_event_destroy(e)
+    for a in agg.values():
+        for k in a:
+            a[k] /= reps
+    return agg
+
+
+def cpu_baseline(fl, seconds_budget=30.0):
+    """The oracle (oracle/*.py, CPU restatement of the reference path) on the host cores: batch 1, 2-step DDPM."""
+    from oracle import diffusion_ref as dref, unet_ref as uref
+    from mm_diffusion.synth import synth_tensor
+    from mm_diffusion import multimodal_script_util as msu
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model, _ = msu.create_model_and_diffusion(**{**fl, "use_fp16": False})
+    sd = {k: synth_tensor(k, v.shape) for k, v in model.state_dict().items()}
+    del model
+    om = uref.OracleModel(sd, fl)
+    S = dref.Schedule(respacing="2")
+    torch.manual_seed(0)
+    import random
+    random.seed(0)
+    x = {"video": torch.randn(1, *fl["video_size"]), "audio": torch.randn(1, *fl["audio_size"])}
+    t0 = time.perf_counter()
+    n = 0
+    for i in (1, 0):
+        x = dref.p_sample(S, om, x, torch.tensor([i]))
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "pair-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} p_sample step(s) of the Landscape base model at batch 1, fp32, oracle/unet_ref.py on {cores} host threads ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]: 4)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--respacing", default="250")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--breakdown-out", default="")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from mm_diffusion import dist_util
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist_util.setup_dist()
+    rank = dist_util.rank()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
+    device = dist_util.dev()
+
+    fl, model, diff = build(args.dtype, args.respacing, args.batch, device)
+    from mm_diffusion.sampler import GraphStepper
+    import random
+    random.seed(1234 + rank)
+    torch.manual_seed(1234 + rank)
+    stepper = GraphStepper(diff, model, args.batch, device, clip_denoised=True)
+    stepper.load(torch.randn(args.batch, *fl["video_size"]).to(device), torch.randn(args.batch, *fl["audio_size"]).to(device))
+    T = diff.num_timesteps
+    idx = T - 1
+
+    def one_step():
+        nonlocal idx
+        stepper.step(idx)
+        idx = idx - 1 if idx > 0 else T - 1
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(stepper.eng.x_video).all() and torch.isfinite(stepper.eng.x_audio).all())
+
+    global_batch = args.batch * world
+    steps_per_s = args.steps / elapsed
+    res = {
+        "metric": "denoising steps/sec (video+audio pair), 16x64x64 / 25600",
+        "value": steps_per_s * global_batch, "unit": "pair-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Landscape base model (133.68M params), DDPM p_sample, "
+                               f"timestep_respacing={args.respacing}, per-GPU batch {args.batch}, 16x3x64x64 video + 1x25600 audio",
+                   "global_batch": global_batch, "batch_steps_per_s": steps_per_s, "parallelism": f"batch-sharded x{world}, no in-loop collective",
+                   "weights": "key-seeded synthetic (mm_diffusion.synth)", "graph_replay": True, "finite": finite},
+        "model_tflops": steps_per_s * args.batch * MODEL_FLOPS_PER_PAIR / 1e12,
+    }
+    if rank == 0 and not args.no_breakdown:
+        agg = kernel_breakdown(stepper)
+        total_ms = sum(a["ms"] for a in agg.values())
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        a = agg[dom]
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                           "traffic": None, "launches_per_step": a["calls"], "avg_launch_ms": a["ms"] / max(a["calls"], 1),
+                           "algorithmic_gflop_per_launch": a["flops"] / max(a["calls"], 1) / 1e9,
+                           "share_of_step": a["ms"] / total_ms}
+        res["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        hb = {k: v for k, v in agg.items() if v["flops"] == 0 and v["bytes"] > 0}
+        if hb:
+            res["hbm_kernels_gbs"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in hb.items()}
+        if args.breakdown_out:
+            with open(args.breakdown_out, "w") as f:
+                json.dump({k: v for k, v in agg.items()}, f, indent=1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(fl)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

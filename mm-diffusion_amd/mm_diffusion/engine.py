@@ -303,8 +303,8 @@ class UNetEngine:
 
         # two plans that differ only in the timestep dtype read by the first kernel
         self.plan = record(self.t_i64)
-        self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name) if name == "mmd_temb_fwd" else (fn, args, name)
-                         for fn, args, name in self.plan]
+        self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name, meta) if name == "mmd_temb_fwd" else (fn, args, name, meta)
+                         for fn, args, name, meta in self.plan]
 
     def _record(self, t_tensor, arch_in, arch_mid, arch_out):
         m, N, F, dt = self.model, self.N, self.F, self.dtype

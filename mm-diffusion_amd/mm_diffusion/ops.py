@@ -30,15 +30,16 @@ class recording:
         _recorder = self._prev
 
 
-def _dispatch(name, *args):
+def _dispatch(name, *args, meta=None):
+    """meta = (kernel label, algorithmic flops, algorithmic HBM bytes) of this launch (bench roofline accounting)."""
     if _recorder is not None:
-        _recorder.append((getattr(H.lib(), name), args, name))
+        _recorder.append((getattr(H.lib(), name), args, name, meta or (name, 0, 0)))
     else:
         H.call(name, *args, H.stream_handle())
 
 
 def run_plan(plan, stream):
-    for fn, args, name in plan:
+    for fn, args, name, _ in plan:
         rc = fn(*args, stream)
         if rc != 0:
             raise H.MMDError(f"{name} failed ({rc}): {H.lib().mmd_last_error().decode()}")
@@ -87,7 +88,8 @@ def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None):
     b = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if b is None else b
     ws = gn_workspace(geom, x.device) if ws is None else ws
     _dispatch("mmd_gn_stats", H.dt_of(x), x.data_ptr(), x.stride(0), C, *geom.args(), gamma.data_ptr(), beta.data_ptr(),
-           H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), ws.data_ptr())
+           H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), ws.data_ptr(),
+           meta=("gn_stats", 0, geom.S * geom.Tn * C * x.element_size()))
     return a, b
 
 
@@ -96,7 +98,8 @@ def gn_apply(x, a, b, geom: Geom, act=True, out=None):
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     _dispatch("mmd_gn_apply", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
-           *geom.args(), a.data_ptr(), b.data_ptr(), 1 if act else 0)
+           *geom.args(), a.data_ptr(), b.data_ptr(), 1 if act else 0,
+           meta=("gn_apply", 0, 2 * x.shape[0] * x.shape[1] * x.element_size()))
     return out
 
 
@@ -128,9 +131,15 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     arr, nt = H.taps_array(taps)
+    if tile == 0:       # same rule as the library's auto choice, made explicit so launches can be labelled
+        tile = 128 if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
+    es = x.element_size()
+    flops = 2 * M * Cout * Cin * nt
+    nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
     _dispatch("mmd_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias),
            H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
-           M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile)
+           M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile,
+           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{tile}>", flops, nbytes))
     return out
 
 
@@ -143,14 +152,16 @@ def attn(q, kv, out, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per
     v_off = 2 * C if v_off is None else v_off
     _dispatch("mmd_attn_fwd", H.dt_of(q), q.data_ptr(), q.stride(0), q_off, kv.data_ptr(), kv.stride(0), k_off, v_off,
            out.data_ptr(), out.stride(0), heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group,
-           win, H.ptr(shift_dev), impl)
+           win, H.ptr(shift_dev), impl,
+           meta=("attn_fwd", 4 * nb * q_rows_per_batch * win * k_per_group * C,
+                 q.element_size() * nb * (2 * q_rows_per_batch * C + 2 * G * win * k_per_group * C)))
     return out
 
 
 def attn_small(qkv, out, C, heads, geom: Geom):
     _chk2d(qkv), _chk2d(out)
     _dispatch("mmd_attn_small_fwd", H.dt_of(qkv), qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), C, heads,
-           *geom.args())
+           *geom.args(), meta=("attn_small", 4 * geom.S * geom.Tn * geom.Tn * C, 4 * geom.S * geom.Tn * C * qkv.element_size()))
     return out
 
 
@@ -158,7 +169,7 @@ def resample(x, out, NF, Hh, Ww, fh, fw, mode):
     """mode 0 avg-pool / 1 nearest-upsample by (1, fh, fw); Hh, Ww describe the input rows (nf, h, w)."""
     _chk2d(x), _chk2d(out)
     _dispatch("mmd_resample", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], NF, Hh, Ww,
-           fh, fw, mode)
+           fh, fw, mode, meta=("resample", 0, (x.shape[0] + out.shape[0]) * x.shape[1] * x.element_size()))
     return out
 
 
@@ -189,7 +200,8 @@ def stem_conv(x, w, bias, out, N, F, Cin, Hh, Ww, taps):
     _chk2d(out)
     arr, nt = H.taps_array(taps)
     _dispatch("mmd_stem_conv", H.dt_of(out), x.data_ptr(), w.data_ptr(), H.ptr(bias), out.data_ptr(), out.stride(0), N, F, Cin,
-           Hh, Ww, out.shape[1], nt, arr)
+           Hh, Ww, out.shape[1], nt, arr, meta=("stem_conv", 2 * out.shape[0] * out.shape[1] * Cin * nt,
+                                                 x.numel() * 4 + out.shape[0] * out.shape[1] * out.element_size()))
     return out
 
 
@@ -198,14 +210,16 @@ def head_conv(x, w, bias, out, N, F, Hh, Ww, taps):
     _chk2d(x)
     arr, nt = H.taps_array(taps)
     _dispatch("mmd_head_conv", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), out.data_ptr(), N, F,
-           x.shape[1], Hh, Ww, w.shape[2], nt, arr)
+           x.shape[1], Hh, Ww, w.shape[2], nt, arr,
+           meta=("head_conv", 2 * x.shape[0] * x.shape[1] * w.shape[2] * nt, x.shape[0] * x.shape[1] * x.element_size() + out.numel() * 4))
     return out
 
 
 def ddpm_update(x, model_out, noise, out, tables, t, F, C, HW, flags, x0_out=None, mean_out=None, logvar_out=None):
     H.require_cuda(x, model_out, noise, out, tables, t)
     _dispatch("mmd_ddpm_update", x.data_ptr(), model_out.data_ptr(), H.ptr(noise), H.ptr(out), H.ptr(x0_out),
-              H.ptr(mean_out), H.ptr(logvar_out), tables.data_ptr(), t.data_ptr(), tables.shape[1], x.shape[0], F, C, HW, flags)
+              H.ptr(mean_out), H.ptr(logvar_out), tables.data_ptr(), t.data_ptr(), tables.shape[1], x.shape[0], F, C, HW, flags,
+              meta=("ddpm_update", 0, 16 * x.numel()))
     return out
 
 
