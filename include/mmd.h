@@ -79,6 +79,14 @@ int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const fl
                   void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
                   void* stream);
 
+/* 1x1 conv whose input GroupNorm32(+FiLM)(+SiLU) is applied on the fly in the A-operand loader:
+ *   Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R),  s(m) = (m / outer_stride) * inner + ((m % outer_stride) / inner_stride) % inner
+ * gn_a / gn_b [S, Cin] come from mmd_gn_stats.  Replaces norm -> SiLU -> {out conv | qkv conv} pairs
+ * (unet:284, 373-388, 664-665) without materialising the normalised tensor. */
+int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int inner,
+                   int64_t outer_stride, int64_t inner_stride, const void* W, const float* bias, const void* R, int64_t ldr,
+                   void* Y, int64_t ldy, int M, int Cout, int Cin, int tile, void* stream);
+
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).
  * For batch n, group g (< G): queries = Q rows n*q_rows_per_batch + g*q_per_group + [0, q_per_group) (the last

@@ -25,6 +25,10 @@ struct ConvGemmParams {
   char* Y; int64_t ldy;
   int M, Cout, Cin, ntaps;
   int D0, D1, D2;
+  // optional GroupNorm(+SiLU) fused into the A loader (1x1 convs only): x' = act(x * a[s(m)] + b[s(m)])
+  const float* gn_a; const float* gn_b;
+  int gn_act, gn_inner;
+  int64_t gn_outer_stride, gn_inner_stride;
   int taps[27 * 3];
 };
 
@@ -45,7 +49,7 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool GN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;            // element size in bytes
@@ -101,6 +105,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
   int tap = cv / CinV, civ = cv % CinV;
   int kv = cv;
+  int64_t gnoff[AR];
+  if (GN) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int64_t m = arow[i] < p.M ? arow[i] : 0;
+      const int64_t o = m / p.gn_outer_stride, rem = m % p.gn_outer_stride;
+      gnoff[i] = (o * p.gn_inner + (rem / p.gn_inner_stride) % p.gn_inner) * p.Cin;
+    }
+  }
 
   u32x4 ra[AR], rw[WR];
   __syncthreads();   // s_taps visible
@@ -115,7 +128,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       const bool ok = tapok && (unsigned)(pp0[i] + o0) < (unsigned)p.D0 &&
                       (unsigned)(pp1[i] + o1) < (unsigned)p.D1 && (unsigned)(pp2[i] + o2) < (unsigned)p.D2;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *(const u32x4*)(p.A + ((arow[i] + roff) * p.lda + (int64_t)civ * EPV) * ES);
+      if (ok) {
+        v = *(const u32x4*)(p.A + ((arow[i] + roff) * p.lda + (int64_t)civ * EPV) * ES);
+        if (GN) {
+          float f[EPV];
+          Elt<T>::unpack(v, f);
+          const float* ap = p.gn_a + gnoff[i] + civ * EPV;
+          const float* bp = p.gn_b + gnoff[i] + civ * EPV;
+#pragma unroll
+          for (int e = 0; e < EPV; e += 4) {
+            const f32x4 av = *(const f32x4*)(ap + e), bv = *(const f32x4*)(bp + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float y = f[e + k] * av[k] + bv[k];
+              f[e + k] = p.gn_act ? silu_f(y) : y;
+            }
+          }
+          v = Elt<T>::pack(f);
+        }
+      }
       ra[i] = v;
     }
 #pragma unroll
@@ -221,26 +252,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool GN>
 static int launch_conv_gemm(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds_ops = 2 * (size_t)(BM + BN) * ROWB;
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   const size_t lds = (lds_ops > lds_c ? lds_ops : lds_c) + 336;   // + tap table
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<T, BM, BN>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<T, BM, BN, GN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, GN>), dim3(grid), dim3(256), lds, st, p);
   return mmd_check_launch("conv_gemm");
 }
 
-extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias,
-                             const void* R, int64_t ldr, void* Y, int64_t ldy, int M, int Cout, int Cin,
-                             int ntaps, const int* taps, int D0, int D1, int D2, int tile, void* stream) {
+template <typename T>
+static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st) {
+  if (p.gn_a) {
+    if (tile == 128) return launch_conv_gemm<T, 128, 128, true>(p, st);
+    return launch_conv_gemm<T, 64, 64, true>(p, st);
+  }
+  if (tile == 128) return launch_conv_gemm<T, 128, 128, false>(p, st);
+  return launch_conv_gemm<T, 64, 64, false>(p, st);
+}
+
+static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
+                          void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
+                          int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_inner, int64_t gn_outer_stride,
+                          int64_t gn_inner_stride, void* stream) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_gemm: bad dtype %d", dtype);
   MMD_REQUIRE(A && W && Y && M > 0 && Cout > 0 && Cin > 0, "conv_gemm: null/empty argument");
@@ -250,17 +292,35 @@ extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* 
   MMD_REQUIRE(lda % epv == 0 && ldy % epv == 0 && (!R || ldr % epv == 0), "conv_gemm: row strides must be 16-byte multiples");
   MMD_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)R) % 16 == 0, "conv_gemm: pointers must be 16-byte aligned");
   MMD_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "conv_gemm: bad position dims");
+  MMD_REQUIRE(!gn_a || (gn_b && ntaps == 1 && gn_inner > 0 && gn_outer_stride > 0 && gn_inner_stride > 0 && Cin % 4 == 0),
+              "conv_gemm: fused GroupNorm needs a 1x1 conv and a valid slice geometry");
   ConvGemmParams p;
   p.A = (const char*)A; p.lda = lda; p.W = (const char*)W; p.bias = bias;
   p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
+  p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = gn_act; p.gn_inner = gn_inner;
+  p.gn_outer_stride = gn_outer_stride; p.gn_inner_stride = gn_inner_stride;
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
-  if (dtype == MMD_BF16) {
-    if (tile == 128) return launch_conv_gemm<__bf16, 128, 128>(p, st);
-    return launch_conv_gemm<__bf16, 64, 64>(p, st);
-  }
-  if (tile == 128) return launch_conv_gemm<float, 128, 128>(p, st);
-  return launch_conv_gemm<float, 64, 64>(p, st);
+  MMD_REQUIRE(tile == 64 || tile == 128, "conv_gemm: tile must be 0, 64 or 128");
+  return dtype == MMD_BF16 ? dispatch_conv_gemm<__bf16>(p, tile, st) : dispatch_conv_gemm<float>(p, tile, st);
+}
+
+extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
+                             void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
+                             int tile, void* stream) {
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 1,
+                        1, 1, stream);
+}
+
+// 1x1 conv of GroupNorm32(+SiLU)'d rows: Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R); gn_a/gn_b [S, Cin] from
+// mmd_gn_stats, slice(m) = (m / outer_stride) * inner + ((m % outer_stride) / inner_stride) % inner.
+extern "C" int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int inner,
+                              int64_t outer_stride, int64_t inner_stride, const void* W, const float* bias, const void* R,
+                              int64_t ldr, void* Y, int64_t ldy, int M, int Cout, int Cin, int tile, void* stream) {
+  static const int tap0[3] = {0, 0, 0};
+  MMD_REQUIRE(gn_a && gn_b, "gn_conv1x1: null GroupNorm affine");
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, inner,
+                        outer_stride, inner_stride, stream);
 }

@@ -18,6 +18,7 @@
 
 #define GN_TPB 256      // rows per stage-1 block
 #define GN_GROUPS 32
+#define GN_ONE_MAX 256   // slices up to this many rows are reduced by a single block
 
 struct SliceGeom {
   int S, Tn, inner;
@@ -32,9 +33,14 @@ __device__ __forceinline__ int slice_of_row(const SliceGeom& g, int64_t m) {
   return (int)(o * g.inner + (rem / g.inner_stride) % g.inner);
 }
 
-template <typename T>
+// ONE = true: the block owns the whole slice (Tn <= GN_ONE_MAX rows) and writes the fused affine directly
+// (no partials, no second launch) - every attention GroupNorm and the deep-level per-sample ones.
+template <typename T, bool ONE>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict__ x, int64_t ld, int C, SliceGeom g,
-                                                         double* __restrict__ part, int nchunks) {
+                                                         double* __restrict__ part, int nchunks,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ film, int64_t film_ld, float eps,
+                                                         float* __restrict__ a_out, float* __restrict__ b_out) {
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
   __shared__ float s_sum[256 * EPV];
@@ -48,8 +54,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
   float sum[EPV], sq[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) sum[j] = sq[j] = 0.f;
-  const int j0 = chunk * GN_TPB;
-  const int j1 = min(j0 + GN_TPB, g.Tn);
+  const int j0 = ONE ? 0 : chunk * GN_TPB;
+  const int j1 = ONE ? g.Tn : min(j0 + GN_TPB, g.Tn);
   const int64_t base = slice_base(g, s);
   // shifted-data sums: pivot = first element of the group in the slice's first row (kills the
   // E[x^2]-E[x]^2 cancellation when a group carries a large common offset)
@@ -85,9 +91,35 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
   if (tid < GN_GROUPS) {
     double a = 0.0, b = 0.0;
     for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += s_csum[c]; b += s_csq[c]; }
-    double* o = part + (((int64_t)s * nchunks + chunk) * GN_GROUPS + tid) * 2;
-    o[0] = a;
-    o[1] = b;
+    if (!ONE) {
+      double* o = part + (((int64_t)s * nchunks + chunk) * GN_GROUPS + tid) * 2;
+      o[0] = a;
+      o[1] = b;
+    } else {
+      const double cnt = (double)g.Tn * (double)cpg;
+      const double piv0 = (double)Elt<T>::ld(x, base * ld + (int64_t)tid * cpg);
+      const double dm = a / cnt;
+      double var = b / cnt - dm * dm;
+      if (var < 0.0) var = 0.0;
+      s_csum[tid] = piv0 + dm;                         // mean
+      s_csq[tid] = 1.0 / sqrt(var + (double)eps);      // rstd
+    }
+  }
+  if (ONE) {
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const int gi = c / cpg;
+      float a = (float)s_csq[gi] * gamma[c];
+      float b = beta[c] - (float)s_csum[gi] * a;
+      if (film) {
+        const float sc = 1.f + film[(int64_t)s * film_ld + c];
+        const float sh = film[(int64_t)s * film_ld + C + c];
+        a *= sc;
+        b = b * sc + sh;
+      }
+      a_out[(int64_t)s * C + c] = a;
+      b_out[(int64_t)s * C + c] = b;
+    }
   }
 }
 
@@ -202,13 +234,24 @@ extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, 
   MMD_REQUIRE(x && gamma && beta && a_out && b_out && workspace, "gn_stats: null pointer");
   MMD_REQUIRE(((uintptr_t)x) % 16 == 0 && ld % (dtype == MMD_BF16 ? 8 : 4) == 0, "gn_stats: x must be 16-byte aligned rows");
   SliceGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};
-  const int nchunks = cdiv(Tn, GN_TPB);
   hipStream_t st = (hipStream_t)stream;
+  if (Tn <= GN_ONE_MAX) {
+    if (dtype == MMD_BF16)
+      hipLaunchKernelGGL((gn_partial_kernel<__bf16, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, (double*)nullptr, 1,
+                         gamma, beta, film, film_ld, eps, a_out, b_out);
+    else
+      hipLaunchKernelGGL((gn_partial_kernel<float, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, (double*)nullptr, 1,
+                         gamma, beta, film, film_ld, eps, a_out, b_out);
+    return mmd_check_launch("gn_stats_one");
+  }
+  const int nchunks = cdiv(Tn, GN_TPB);
   dim3 grid(nchunks, S);
   if (dtype == MMD_BF16)
-    hipLaunchKernelGGL(gn_partial_kernel<__bf16>, grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks);
+    hipLaunchKernelGGL((gn_partial_kernel<__bf16, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks,
+                       gamma, beta, film, film_ld, eps, a_out, b_out);
   else
-    hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks);
+    hipLaunchKernelGGL((gn_partial_kernel<float, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks,
+                       gamma, beta, film, film_ld, eps, a_out, b_out);
   rc = mmd_check_launch("gn_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(S), dim3(256), 0, st, (const char*)x, dtype, ld, g, (const double*)workspace, nchunks, C, Tn, gamma, beta,

@@ -123,6 +123,19 @@ class UNetEngine:
         self._release(a, b, ws)
         return y
 
+    def _gn_pw(self, x, gn_prefix, geom, act, wkey, bkey, film=None, residual=None, out=None):
+        """GroupNorm32(+FiLM)(+SiLU) -> 1x1 conv with the normalisation applied inside the GEMM loader."""
+        C = x.shape[1]
+        a = self._alloc(geom.S, C, torch.float32)
+        b = self._alloc(geom.S, C, torch.float32)
+        ws = self._alloc(H.lib().mmd_gn_workspace_bytes(geom.S, geom.Tn) // 8, 1, torch.float64)
+        ops.gn_stats(x, self._f32(gn_prefix + ".GroupNorm.weight"), self._f32(gn_prefix + ".GroupNorm.bias"), geom,
+                     film=film, a=a, b=b, ws=ws)
+        y = self._alloc(x.shape[0], self.params[wkey].shape[0]) if out is None else out
+        ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y)
+        self._release(a, b, ws)
+        return y
+
     def _pw(self, x, wkey, bkey, residual=None, out=None):
         y = self._alloc(x.shape[0], self.params[wkey].shape[0]) if out is None else out
         return ops.conv_gemm(x, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y)
@@ -140,9 +153,7 @@ class UNetEngine:
             geom = Geom.temporal(N, F, Hh * Hh)
         else:
             geom = Geom.per_sample(N, rows // N)
-        n1 = self._gn(x, prefix + ".norm", geom, act=False)
-        qkv = self._pw(n1, prefix + ".qkv.weight", prefix + ".qkv.bias")
-        self._release(n1)
+        qkv = self._gn_pw(x, prefix + ".norm", geom, False, prefix + ".qkv.weight", prefix + ".qkv.bias")
         att = self._alloc(rows, C)
         if kind == "temporal":
             if F > 32:
@@ -197,12 +208,8 @@ class UNetEngine:
                 self._release(h)
                 h, xs = hp, xp
             geom = Geom.per_sample(N, rows_out // N)
-            if ss:
-                t2 = self._gn(h, f"{p}.{mod}_out_layers.0", geom, act=True, film=film)
-            else:
+            if not ss:
                 ops.add_rowbias(h, film, rows_out // N)
-                t2 = self._gn(h, f"{p}.{mod}_out_layers.0", geom, act=True)
-            self._release(h)
             conv = "video_conv" if vid else "audio_conv"
             if cin != cout:
                 sk = self._pw(xs, f"{p}.{mod}_skip_connection.{conv}.weight", f"{p}.{mod}_skip_connection.{conv}.bias")
@@ -210,8 +217,9 @@ class UNetEngine:
                 sk = xs
             attn_here = layer["vattn"] if vid else layer["aattn"]
             dest = self._alloc(rows_out, cout) if (attn_here or out is None) else out
-            self._pw(t2, f"{p}.{mod}_out_layers.3.{conv}.weight", f"{p}.{mod}_out_layers.3.{conv}.bias", residual=sk, out=dest)
-            self._release(t2)
+            self._gn_pw(h, f"{p}.{mod}_out_layers.0", geom, True, f"{p}.{mod}_out_layers.3.{conv}.weight",
+                        f"{p}.{mod}_out_layers.3.{conv}.bias", film=film if ss else None, residual=sk, out=dest)
+            self._release(h)
             if sk is not xs:
                 self._release(sk)
             if xs is not x:
@@ -242,12 +250,8 @@ class UNetEngine:
         HW, apf = Hh * Hh, int(L / F)
         if apf < 1:
             raise H.MMDError(f"cross attention needs at least one audio token per frame (L={L}, F={F})")
-        vn = self._gn(v, p + ".v_norm", Geom.per_sample(N, F * HW), act=False)
-        vqkv = self._pw(vn, p + ".v_qkv.weight", p + ".v_qkv.bias")
-        self._release(vn)
-        an = self._gn(a, p + ".a_norm", Geom.per_sample(N, L), act=False)
-        aqkv = self._pw(an, p + ".a_qkv.weight", p + ".a_qkv.bias")
-        self._release(an)
+        vqkv = self._gn_pw(v, p + ".v_norm", Geom.per_sample(N, F * HW), False, p + ".v_qkv.weight", p + ".v_qkv.bias")
+        aqkv = self._gn_pw(a, p + ".a_norm", Geom.per_sample(N, L), False, p + ".a_qkv.weight", p + ".a_qkv.bias")
         sh = self.shift_dev[layer["shift_idx"]: layer["shift_idx"] + 1] if layer["shift"] else None
         vatt, aatt = self._alloc(N * F * HW, C), self._alloc(N * L, C)
         ops.attn(vqkv, aqkv, vatt, heads, ch, N, F, F * HW, HW, L, apf, win, shift_dev=sh)

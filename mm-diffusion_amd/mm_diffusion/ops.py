@@ -143,6 +143,26 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     return out
 
 
+def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=0):
+    """1x1 conv of GroupNorm'd rows with the normalisation fused into the GEMM loader (include/mmd.h: mmd_gn_conv1x1)."""
+    _chk2d(x)
+    M, Cin = x.shape
+    Cout = w.shape[0]
+    if w.dtype != x.dtype or w.shape[1] != Cin or not w.is_contiguous():
+        raise H.MMDError(f"gn_conv1x1: weight {tuple(w.shape)} {w.dtype} does not match input {tuple(x.shape)} {x.dtype}")
+    out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    if tile == 0:
+        tile = 128 if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
+    es = x.element_size()
+    nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
+    _dispatch("mmd_gn_conv1x1", H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.inner,
+              geom.outer_stride, geom.inner_stride, w.data_ptr(), H.ptr(bias), H.ptr(residual),
+              0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, tile,
+              meta=(f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>", 2 * M * Cout * Cin, nbytes))
+    return out
+
+
 def attn(q, kv, out, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group, win,
          q_off=0, k_off=None, v_off=None, shift_dev=None, impl=0):
     """See include/mmd.h: mmd_attn_fwd.  q/kv are qkv GEMM outputs [rows, 3C]; out [q rows, C]."""

@@ -332,3 +332,42 @@ def test_ddpm_update(ops, learn_sigma):
     xq = torch.empty_like(out)
     ops.q_sample(x.cuda(), noise.cuda(), xq, torch.from_numpy(np.stack([S.sqrt_ac, S.sqrt_1mac])).float().cuda(), t.cuda())
     assert rel_l2(xq.cpu(), dref.q_sample(S, x, t, noise)) < 1e-6
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kind", ["per_sample", "spatial", "temporal"])
+def test_gn_fused_into_conv1x1(ops, dt, kind):
+    """GroupNorm(+FiLM)(+SiLU) applied inside the GEMM loader == separate apply kernel + GEMM."""
+    N, C, F, H, W, Cout = 2, 64, 4, 3, 5, 96
+    x = rnd(N, C, F, H, W, dt=dt, seed=60)
+    g, b = 1 + 0.1 * rnd(C, seed=61), rnd(C, seed=62)
+    w, bias, r = rnd(Cout, C, dt=dt, seed=63, scale=C ** -0.5), rnd(Cout, seed=64), rnd(N * F * H * W, Cout, dt=dt, seed=65)
+    xa = dev(rows_video(x), dt)
+    if kind == "per_sample":
+        geom, film = ops.Geom.per_sample(N, F * H * W), rnd(N, 2 * C, seed=66, scale=0.3)
+        xr = uref.group_norm(x, g, b) * (1 + film[:, :C, None, None, None]) + film[:, C:, None, None, None]
+        act = True
+        xr = F_.silu(xr)
+    elif kind == "spatial":
+        geom, film, act = ops.Geom.spatial(N, F, H * W), None, False
+        xs = x.permute(0, 2, 1, 3, 4).reshape(N * F, C, H * W)
+        xr = uref.group_norm(xs, g, b).reshape(N, F, C, H, W).permute(0, 2, 1, 3, 4)
+    else:
+        geom, film, act = ops.Geom.temporal(N, F, H * W), None, False
+        xt = x.permute(0, 3, 4, 1, 2).reshape(N * H * W, C, F)
+        xr = uref.group_norm(xt, g, b).reshape(N, H, W, C, F).permute(0, 3, 4, 1, 2)
+    a_, b_ = ops.gn_stats(xa, g.cuda(), b.cuda(), geom, film=None if film is None else film.cuda())
+    y = ops.gn_conv1x1(xa, a_, b_, geom, act, dev(w, dt), bias.cuda(), residual=dev(r, dt))
+    ref = rows_video(xr) @ w.t() + bias + r
+    assert rel_l2(y.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.5e-2)
+
+
+def test_groupnorm_two_stage_path(ops):
+    """Slices longer than one block's share (Tn > 256 rows) take the partial + finalize route."""
+    N, C, R = 2, 128, 1500
+    x = rnd(N * R, C, seed=67) * 1.5 - 0.3
+    g, b = 1 + 0.1 * rnd(C, seed=68), rnd(C, seed=69)
+    geom = ops.Geom.per_sample(N, R)
+    y = ops.gn_apply(x.cuda(), *ops.gn_stats(x.cuda(), g.cuda(), b.cuda(), geom), geom, act=False)
+    ref = uref.group_norm(x.reshape(N, R, C).permute(0, 2, 1), g, b).permute(0, 2, 1).reshape(-1, C)
+    assert rel_l2(y.cpu(), ref) < 2e-5
