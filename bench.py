@@ -47,7 +47,7 @@ def build(dtype_flag, respacing, batch, device):
     return fl, model, diff
 
 
-def kernel_breakdown(stepper, reps=3):
+def kernel_breakdown(stepper, reps=3, detail=False):
     """Per-kernel time of one step measured with HIP events on the launch stream (eager replay of the plan)."""
     from mm_diffusion import _hip as H
     import ctypes
@@ -72,6 +72,8 @@ def kernel_breakdown(stepper, reps=3):
         for i, (fn, args, name, meta) in enumerate(plan):
             H.call("mmd_event_elapsed_ms", evs[i], evs[i + 1], ctypes.byref(ms))
             label, flops, nbytes = meta
+            if not detail:
+                label = label.split("[")[0]
             a = agg.setdefault(label, dict(ms=0.0, calls=0, flops=0, bytes=0))
             a["ms"] += ms.value
             a["calls"] += 1
@@ -202,8 +204,9 @@ def main():
         if hb:
             res["hbm_kernels_gbs"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in hb.items()}
         if args.breakdown_out:
+            det = kernel_breakdown(stepper, reps=2, detail=True)
             with open(args.breakdown_out, "w") as f:
-                json.dump({k: v for k, v in agg.items()}, f, indent=1)
+                json.dump(dict(sorted(det.items(), key=lambda kv: -kv[1]["ms"])), f, indent=1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(fl)
     if rank == 0:

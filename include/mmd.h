@@ -55,8 +55,8 @@ int mmd_linear_fwd(const float* x, const float* W, const float* b, float* y, int
 /* GroupNorm32 statistics -> fused per-(slice,channel) affine (nn.py:16-33; FiLM unet:457-470).
  * Slice s normalises rows base(s) + j*tstride (j < Tn), base(s) = (s/inner)*outer_stride + (s%inner)*inner_stride.
  * a_out/b_out [S, C] fp32: y = x*a + b.  film (nullable) [S, >=2C] rows (scale | shift), row stride film_ld.
- * workspace: mmd_gn_workspace_bytes(S, Tn) bytes. */
-int64_t mmd_gn_workspace_bytes(int S, int Tn);
+ * workspace: mmd_gn_workspace_bytes(dtype, C, S, Tn) bytes (may be 0: slice handled by one block). */
+int64_t mmd_gn_workspace_bytes(int dtype, int C, int S, int Tn);
 int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int inner, int64_t outer_stride,
                  int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, const float* film,
                  int64_t film_ld, float eps, float* a_out, float* b_out, void* workspace, void* stream);

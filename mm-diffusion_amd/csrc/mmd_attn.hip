@@ -401,12 +401,28 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const SmallAttnParams p
   const bool active = item < (int64_t)p.S * p.heads;
   const int s = active ? (int)(item / p.heads) : 0, h = active ? (int)(item % p.heads) : 0;
   const int64_t base = (int64_t)(s / p.inner) * p.outer_stride + (int64_t)(s % p.inner) * p.inner_stride;
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  const bool vec_ok = (p.ld % EPV == 0) && (p.C % EPV == 0) && (((uintptr_t)p.QKV) % 16 == 0) && (ch % EPV == 0);
   if (active) {
-    for (int i = lane; i < Tn * ch; i += 64) {
-      const int j = i / ch, d = i % ch;
-      const int64_t row = base + (int64_t)j * p.tstride;
-      sK[j * ch + d] = Elt<T>::ld(p.QKV, row * p.ld + p.C + h * ch + d);
-      sV[j * ch + d] = Elt<T>::ld(p.QKV, row * p.ld + 2 * p.C + h * ch + d);
+    if (vec_ok) {
+      const int cvn = ch / EPV;
+      for (int i = lane; i < Tn * cvn; i += 64) {
+        const int j = i / cvn, v = i % cvn;
+        const int64_t row = base + (int64_t)j * p.tstride;
+        float fk[EPV], fv[EPV];
+        Elt<T>::unpack(*(const u32x4*)(p.QKV + (row * p.ld + p.C + h * ch + v * EPV) * ES), fk);
+        Elt<T>::unpack(*(const u32x4*)(p.QKV + (row * p.ld + 2 * p.C + h * ch + v * EPV) * ES), fv);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { sK[j * ch + v * EPV + e] = fk[e]; sV[j * ch + v * EPV + e] = fv[e]; }
+      }
+    } else {
+      for (int i = lane; i < Tn * ch; i += 64) {
+        const int j = i / ch, d = i % ch;
+        const int64_t row = base + (int64_t)j * p.tstride;
+        sK[j * ch + d] = Elt<T>::ld(p.QKV, row * p.ld + p.C + h * ch + d);
+        sV[j * ch + d] = Elt<T>::ld(p.QKV, row * p.ld + 2 * p.C + h * ch + d);
+      }
     }
   }
   __syncthreads();
@@ -418,8 +434,18 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const SmallAttnParams p
     float q[CHQ];
     {
       const int64_t row = base + (int64_t)(ok ? qi : 0) * p.tstride;
+      if (vec_ok && CHQ % EPV == 0) {
 #pragma unroll
-      for (int d = 0; d < CHQ; ++d) q[d] = Elt<T>::ld(p.QKV, row * p.ld + h * ch + dq * CHQ + d) * p.scale;
+        for (int d = 0; d < CHQ; d += EPV) {
+          float f[EPV];
+          Elt<T>::unpack(*(const u32x4*)(p.QKV + (row * p.ld + h * ch + dq * CHQ + d) * ES), f);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) q[(d + e) < CHQ ? (d + e) : 0] = f[e] * p.scale;
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < CHQ; ++d) q[d] = Elt<T>::ld(p.QKV, row * p.ld + h * ch + dq * CHQ + d) * p.scale;
+      }
     }
     float sc[32];
     float mx = -1e30f;
@@ -455,8 +481,18 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const SmallAttnParams p
     if (ok) {
       const float inv = 1.f / sum;
       const int64_t row = base + (int64_t)qi * p.tstride;
+      if (CHQ % EPV == 0 && p.ldo % EPV == 0 && ((uintptr_t)p.O) % 16 == 0) {
 #pragma unroll
-      for (int d = 0; d < CHQ; ++d) Elt<T>::st(p.O, row * p.ldo + h * ch + dq * CHQ + d, o[d] * inv);
+        for (int d = 0; d < CHQ; d += EPV) {
+          float f[EPV];
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) f[e] = o[(d + e) < CHQ ? (d + e) : 0] * inv;
+          *(u32x4*)(p.O + (row * p.ldo + h * ch + dq * CHQ + d) * ES) = Elt<T>::pack(f);
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < CHQ; ++d) Elt<T>::st(p.O, row * p.ldo + h * ch + dq * CHQ + d, o[d] * inv);
+      }
     }
   }
 }

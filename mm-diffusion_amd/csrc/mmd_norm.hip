@@ -9,16 +9,14 @@
 //   per-sample video/audio GN : S=N,     inner=1,  outer_stride=rows/sample, tstride=1, Tn=rows/sample
 //   spatial self-attn GN      : S=N*F,   inner=1,  outer_stride=HW,          tstride=1, Tn=HW
 //   temporal self-attn GN     : S=N*HW,  inner=HW, outer_stride=F*HW, inner_stride=1, tstride=HW, Tn=F
-// Stage 1 (gn_partial): per (chunk of 256 rows, slice) per-channel fp32 partial sums, combined in
+// Stage 1 (gn_partial): per (chunk of R rows, slice) per-channel fp32 partial sums, combined in
 //   fp64 in a fixed order (deterministic - no atomics) -> per-group (sum, sumsq) doubles.
 // Stage 2 (gn_finalize): mean / rstd per (slice, group) and the fused affine
 //   a[s,c] = rstd*gamma[c]*(1+scale[s,c]),  b[s,c] = (beta[c]-mean*rstd*gamma[c])*(1+scale[s,c]) + shift[s,c]
 // Stage 3 (gn_apply): y = act(x*a + b), 16-byte vector loads/stores (HBM-bound, 2 bytes moved per byte read).
 #include "mmd_common.h"
 
-#define GN_TPB 256      // rows per stage-1 block
 #define GN_GROUPS 32
-#define GN_ONE_MAX 256   // slices up to this many rows are reduced by a single block
 
 struct SliceGeom {
   int S, Tn, inner;
@@ -33,10 +31,12 @@ __device__ __forceinline__ int slice_of_row(const SliceGeom& g, int64_t m) {
   return (int)(o * g.inner + (rem / g.inner_stride) % g.inner);
 }
 
-// ONE = true: the block owns the whole slice (Tn <= GN_ONE_MAX rows) and writes the fused affine directly
-// (no partials, no second launch) - every attention GroupNorm and the deep-level per-sample ones.
+// Rows per block R is chosen on the host (gn_rows_per_block) so that even a 4-slice, 400-row GroupNorm fans
+// out over ~100 blocks and every thread keeps 4 independent 16-byte loads in flight (the first version ran
+// 256-row blocks with one load in flight: 56-800 GB/s).  ONE = true: one block owns the whole slice and
+// writes the fused affine directly (no partials, no second launch).
 template <typename T, bool ONE>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict__ x, int64_t ld, int C, SliceGeom g,
+__global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict__ x, int64_t ld, int C, SliceGeom g, int R,
                                                          double* __restrict__ part, int nchunks,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ film, int64_t film_ld, float eps,
@@ -54,26 +54,43 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
   float sum[EPV], sq[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) sum[j] = sq[j] = 0.f;
-  const int j0 = ONE ? 0 : chunk * GN_TPB;
-  const int j1 = ONE ? g.Tn : min(j0 + GN_TPB, g.Tn);
+  const int j0 = chunk * R;
+  const int j1 = min(j0 + R, g.Tn);
   const int64_t base = slice_base(g, s);
   // shifted-data sums: pivot = first element of the group in the slice's first row (kills the
   // E[x^2]-E[x]^2 cancellation when a group carries a large common offset)
   const int cpg = C / GN_GROUPS;
   float piv[EPV];
+  {
+    const int c0 = col * EPV;
+    const int g0 = c0 / cpg;
+    int gc = g0, rem = c0 - g0 * cpg;
 #pragma unroll
-  for (int e = 0; e < EPV; ++e) piv[e] = Elt<T>::ld(x, base * ld + (int64_t)((col * EPV + e) / cpg) * cpg);
-  if (rl < RPP) {
-    for (int j = j0 + rl; j < j1; j += RPP) {
-      const int64_t row = base + (int64_t)j * g.tstride;
-      float f[EPV];
-      Elt<T>::unpack(*(const u32x4*)(x + (row * ld + (int64_t)col * EPV) * ES), f);
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) { const float d = f[e] - piv[e]; sum[e] += d; sq[e] += d * d; }
+    for (int e = 0; e < EPV; ++e) {
+      piv[e] = Elt<T>::ld(x, base * ld + (int64_t)gc * cpg);
+      if (++rem == cpg) { rem = 0; ++gc; }
     }
   }
-  // per-channel combine over the RPP row lanes, in double, fixed order
   if (rl < RPP) {
+    const char* xp = x + (base * ld + (int64_t)col * EPV) * ES;
+    const int64_t rstride = g.tstride * ld * ES;
+    for (int jb = j0 + rl; jb < j1; jb += 4 * RPP) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = jb + u * RPP;
+        if (j < j1) v[u] = *(const u32x4*)(xp + (int64_t)j * rstride);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (jb + u * RPP < j1) {
+          float f[EPV];
+          Elt<T>::unpack(v[u], f);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { const float d = f[e] - piv[e]; sum[e] += d; sq[e] += d * d; }
+        }
+      }
+    }
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       s_sum[rl * C + col * EPV + e] = sum[e];
@@ -81,6 +98,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
     }
   }
   __syncthreads();
+  // per-channel combine over the RPP row lanes, in double, fixed order (deterministic)
   for (int c = tid; c < C; c += 256) {
     double a = 0.0, b = 0.0;
     for (int r = 0; r < RPP; ++r) { a += (double)s_sum[r * C + c]; b += (double)s_sq[r * C + c]; }
@@ -128,15 +146,34 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const char* __restrict
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ film, int64_t film_ld, float eps,
                                                           float* __restrict__ a_out, float* __restrict__ b_out) {
+  __shared__ double s_pa[8][GN_GROUPS], s_pb[8][GN_GROUPS];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int s = blockIdx.x, tid = threadIdx.x;
-  if (tid < GN_GROUPS) {
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-      const double* p = part + (((int64_t)s * nchunks + k) * GN_GROUPS + tid) * 2;
+  {   // 8 chunk lanes x 32 groups, each lane strides the chunks; combined below in a fixed order
+    const int gi = tid & 31, cl = tid >> 5;
+    double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
+    const double* p0 = part + ((int64_t)s * nchunks * GN_GROUPS + gi) * 2;
+    int k = cl;
+    for (; k + 8 < nchunks; k += 16) {          // two independent chains -> loads overlap
+      const double* p = p0 + (int64_t)k * GN_GROUPS * 2;
+      const double* q = p0 + (int64_t)(k + 8) * GN_GROUPS * 2;
+      a += p[0];
+      b += p[1];
+      a2 += q[0];
+      b2 += q[1];
+    }
+    if (k < nchunks) {
+      const double* p = p0 + (int64_t)k * GN_GROUPS * 2;
       a += p[0];
       b += p[1];
     }
+    s_pa[cl][gi] = a + a2;
+    s_pb[cl][gi] = b + b2;
+  }
+  __syncthreads();
+  if (tid < GN_GROUPS) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < 8; ++k) { a += s_pa[k][tid]; b += s_pb[k][tid]; }
     const double cnt = (double)Tn * (double)(C / GN_GROUPS);
     const int64_t pidx = slice_base(g, s) * ld + (int64_t)tid * (C / GN_GROUPS);
     const double piv = dtype == MMD_BF16 ? (double)Elt<__bf16>::ld(x, pidx) : (double)Elt<float>::ld(x, pidx);
@@ -221,8 +258,18 @@ static int check_geom(const char* who, int dtype, int C, int S, int Tn, int inne
   return MMD_OK;
 }
 
-extern "C" int64_t mmd_gn_workspace_bytes(int S, int Tn) {
-  return (int64_t)S * cdiv(Tn, GN_TPB) * GN_GROUPS * 2 * sizeof(double);
+// rows per stage-1 block: >= 4 rows per thread (4 loads in flight), grown until the grid is <= ~4096 blocks
+static int gn_rows_per_block(int dtype, int C, int S, int Tn) {
+  const int cv = C / (dtype == MMD_BF16 ? 8 : 4);
+  const int rpp = 256 / cv > 0 ? 256 / cv : 1;
+  int R = 4 * rpp;
+  while ((int64_t)S * cdiv(Tn, R) > 1280 && R < 1024) R *= 2;   // ~one resident wave of blocks (5/CU x 256 CUs)
+  return R;
+}
+
+extern "C" int64_t mmd_gn_workspace_bytes(int dtype, int C, int S, int Tn) {
+  if (C <= 0 || S <= 0 || Tn <= 0) return 0;
+  return (int64_t)S * cdiv(Tn, gn_rows_per_block(dtype, C, S, Tn)) * GN_GROUPS * 2 * sizeof(double);
 }
 
 extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int inner, int64_t outer_stride,
@@ -231,26 +278,28 @@ extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, 
                             void* stream) {
   int rc = check_geom("gn_stats", dtype, C, S, Tn, inner);
   if (rc) return rc;
-  MMD_REQUIRE(x && gamma && beta && a_out && b_out && workspace, "gn_stats: null pointer");
+  MMD_REQUIRE(x && gamma && beta && a_out && b_out, "gn_stats: null pointer");
   MMD_REQUIRE(((uintptr_t)x) % 16 == 0 && ld % (dtype == MMD_BF16 ? 8 : 4) == 0, "gn_stats: x must be 16-byte aligned rows");
   SliceGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};
   hipStream_t st = (hipStream_t)stream;
-  if (Tn <= GN_ONE_MAX) {
+  const int R = gn_rows_per_block(dtype, C, S, Tn);
+  const int nchunks = cdiv(Tn, R);
+  if (nchunks == 1) {
     if (dtype == MMD_BF16)
-      hipLaunchKernelGGL((gn_partial_kernel<__bf16, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, (double*)nullptr, 1,
+      hipLaunchKernelGGL((gn_partial_kernel<__bf16, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)nullptr, 1,
                          gamma, beta, film, film_ld, eps, a_out, b_out);
     else
-      hipLaunchKernelGGL((gn_partial_kernel<float, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, (double*)nullptr, 1,
+      hipLaunchKernelGGL((gn_partial_kernel<float, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)nullptr, 1,
                          gamma, beta, film, film_ld, eps, a_out, b_out);
     return mmd_check_launch("gn_stats_one");
   }
-  const int nchunks = cdiv(Tn, GN_TPB);
+  MMD_REQUIRE(workspace, "gn_stats: workspace required for multi-block slices");
   dim3 grid(nchunks, S);
   if (dtype == MMD_BF16)
-    hipLaunchKernelGGL((gn_partial_kernel<__bf16, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks,
+    hipLaunchKernelGGL((gn_partial_kernel<__bf16, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)workspace, nchunks,
                        gamma, beta, film, film_ld, eps, a_out, b_out);
   else
-    hipLaunchKernelGGL((gn_partial_kernel<float, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, (double*)workspace, nchunks,
+    hipLaunchKernelGGL((gn_partial_kernel<float, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)workspace, nchunks,
                        gamma, beta, film, film_ld, eps, a_out, b_out);
   rc = mmd_check_launch("gn_partial");
   if (rc) return rc;

@@ -114,8 +114,7 @@ class UNetEngine:
         C = x.shape[1]
         a = self._alloc(geom.S, C, torch.float32)
         b = self._alloc(geom.S, C, torch.float32)
-        nws = H.lib().mmd_gn_workspace_bytes(geom.S, geom.Tn)
-        ws = self._alloc(nws // 8, 1, torch.float64)
+        ws = self._alloc(ops.gn_workspace_bytes(x, geom) // 8, 1, torch.float64)
         ops.gn_stats(x, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), geom,
                      film=film, a=a, b=b, ws=ws)
         y = self._alloc(x.shape[0], C) if out is None else out
@@ -126,12 +125,20 @@ class UNetEngine:
     def _gn_pw(self, x, gn_prefix, geom, act, wkey, bkey, film=None, residual=None, out=None):
         """GroupNorm32(+FiLM)(+SiLU) -> 1x1 conv with the normalisation applied inside the GEMM loader."""
         C = x.shape[1]
+        Cout = self.params[wkey].shape[0]
+        if (Cout + 127) // 128 > 2:
+            # wide outputs (qkv, deep levels): every column tile would redo the normalisation in its loader
+            # (measured 2x slower than materialising once), so normalise once and run the plain GEMM
+            n1 = self._gn(x, gn_prefix, geom, act, film=film)
+            y = self._pw(n1, wkey, bkey, residual=residual, out=out)
+            self._release(n1)
+            return y
         a = self._alloc(geom.S, C, torch.float32)
         b = self._alloc(geom.S, C, torch.float32)
-        ws = self._alloc(H.lib().mmd_gn_workspace_bytes(geom.S, geom.Tn) // 8, 1, torch.float64)
+        ws = self._alloc(ops.gn_workspace_bytes(x, geom) // 8, 1, torch.float64)
         ops.gn_stats(x, self._f32(gn_prefix + ".GroupNorm.weight"), self._f32(gn_prefix + ".GroupNorm.bias"), geom,
                      film=film, a=a, b=b, ws=ws)
-        y = self._alloc(x.shape[0], self.params[wkey].shape[0]) if out is None else out
+        y = self._alloc(x.shape[0], Cout) if out is None else out
         ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y)
         self._release(a, b, ws)
         return y

@@ -76,9 +76,12 @@ def _chk2d(t):
     H.require_cuda(t)
 
 
-def gn_workspace(geom: Geom, device):
-    nbytes = H.lib().mmd_gn_workspace_bytes(geom.S, geom.Tn)
-    return torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+def gn_workspace_bytes(x, geom: Geom):
+    return max(8, int(H.lib().mmd_gn_workspace_bytes(H.dt_of(x), x.shape[1], geom.S, geom.Tn)))
+
+
+def gn_workspace(x, geom: Geom):
+    return torch.empty(gn_workspace_bytes(x, geom) // 8, dtype=torch.float64, device=x.device)
 
 
 def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None):
@@ -86,10 +89,10 @@ def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None):
     C = x.shape[1]
     a = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if a is None else a
     b = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if b is None else b
-    ws = gn_workspace(geom, x.device) if ws is None else ws
+    ws = gn_workspace(x, geom) if ws is None else ws
     _dispatch("mmd_gn_stats", H.dt_of(x), x.data_ptr(), x.stride(0), C, *geom.args(), gamma.data_ptr(), beta.data_ptr(),
            H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), ws.data_ptr(),
-           meta=("gn_stats", 0, geom.S * geom.Tn * C * x.element_size()))
+           meta=(f"gn_stats[S={geom.S},Tn={geom.Tn},C={C}]", 0, geom.S * geom.Tn * C * x.element_size()))
     return a, b
 
 
@@ -139,7 +142,7 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     _dispatch("mmd_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias),
            H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
            M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile,
-           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{tile}>", flops, nbytes))
+           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
     return out
 
 
@@ -159,7 +162,7 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     _dispatch("mmd_gn_conv1x1", H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.inner,
               geom.outer_stride, geom.inner_stride, w.data_ptr(), H.ptr(bias), H.ptr(residual),
               0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, tile,
-              meta=(f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>", 2 * M * Cout * Cin, nbytes))
+              meta=(f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes))
     return out
 
 
@@ -173,7 +176,7 @@ def attn(q, kv, out, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per
     _dispatch("mmd_attn_fwd", H.dt_of(q), q.data_ptr(), q.stride(0), q_off, kv.data_ptr(), kv.stride(0), k_off, v_off,
            out.data_ptr(), out.stride(0), heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group,
            win, H.ptr(shift_dev), impl,
-           meta=("attn_fwd", 4 * nb * q_rows_per_batch * win * k_per_group * C,
+           meta=(f"attn_fwd[ch={ch},q={q_per_group},k={win * k_per_group},G={nb * G},h={heads}]", 4 * nb * q_rows_per_batch * win * k_per_group * C,
                  q.element_size() * nb * (2 * q_rows_per_batch * C + 2 * G * win * k_per_group * C)))
     return out
 
