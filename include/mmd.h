@@ -74,18 +74,19 @@ int mmd_add_rowbias(int dtype, void* x, int64_t ld, int64_t rows, int C, int64_t
  * range -> zero padding.  Covers VideoConv 2d+1d spatial (D=(1,H,W), 9 taps) and temporal (D=(F,HW,1), 3 taps),
  * VideoConv '3d' k=1, AudioConv k=3 dilated (D=(L,1,1), taps (+-d,0,0)) and k=1, and every qkv/proj 1x1 conv
  * (unet:83-131,272,275,378,401,605-610).  W is [Cout][ntaps*Cin] in `dtype`; bias fp32 (nullable);
- * R (nullable) residual in `dtype`.  taps is a HOST pointer.  tile: 0 auto, 64 or 128. */
+ * R (nullable) residual in `dtype`.  taps is a HOST pointer.  tile: 0 auto, 64 or 128 (register-staged
+ * main loop) or 129 (128x128 tile, direct-to-LDS global_load_lds main loop); all variants are bitwise identical. */
 int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
                   void* stream);
 
-/* 1x1 conv whose input GroupNorm32(+FiLM)(+SiLU) is applied on the fly in the A-operand loader:
- *   Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R),  s(m) = (m / outer_stride) * inner + ((m % outer_stride) / inner_stride) % inner
- * gn_a / gn_b [S, Cin] come from mmd_gn_stats.  Replaces norm -> SiLU -> {out conv | qkv conv} pairs
- * (unet:284, 373-388, 664-665) without materialising the normalised tensor. */
-int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int inner,
-                   int64_t outer_stride, int64_t inner_stride, const void* W, const float* bias, const void* R, int64_t ldr,
-                   void* Y, int64_t ldy, int M, int Cout, int Cin, int tile, void* stream);
+/* 1x1 conv whose input GroupNorm32(+FiLM)(+SiLU) is applied on the way into LDS (no normalised tensor in HBM):
+ *   Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R),  s(m) = m / rows_per_slice  (S contiguous slices, S*rows == M,
+ *   rows_per_slice >= 128, Cin <= 256).  gn_a / gn_b [S, Cin] come from mmd_gn_stats.  Replaces the ResBlock tail
+ *   norm -> SiLU -> out conv -> + skip (unet:373-388,457-483). */
+int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
+                   int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                   int M, int Cout, int Cin, int tile, void* stream);
 
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).

@@ -26,13 +26,18 @@ struct ConvGemmParams {
   int M, Cout, Cin, ntaps;
   int D0, D1, D2;
   // optional GroupNorm(+SiLU) fused into the A loader (1x1 convs only): x' = act(x * a[s(m)] + b[s(m)])
-  const float* gn_a; const float* gn_b;
-  int gn_act, gn_inner;
-  int64_t gn_outer_stride, gn_inner_stride;
+  const float* gn_a; const float* gn_b;      // [S, Cin]; contiguous slices of gn_rows rows (>= BM), Cin <= 256
+  int gn_act, gn_S;
+  int64_t gn_rows;
   int taps[27 * 3];
 };
 
 #define ROWB 144   // LDS bytes per staged operand row
+
+// Padding taps / out-of-range rows read this zero page instead of branching around the load: every thread then issues a
+// STATIC number of global loads per K step, so the compiler can keep the newer register stage in flight with a counted
+// s_waitcnt vmcnt(N) (a load under a divergent branch forces vmcnt(0) and serialises the pipeline).
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
@@ -49,8 +54,63 @@ template <> struct Mma<float> {
   }
 };
 
+// Epilogue shared by both main loops: accumulators -> LDS (fp32, [m][co]) -> bias + residual -> 16-byte coalesced row stores.
+// Caller guarantees every wave is past its last operand read (sC aliases the operand buffers).
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&acc)[BN / 64][BM / 64], float* sC, int m0, int n0,
+                                              int tid, int wc, int wr, int half, int l31) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  constexpr int TCO = BN / 64, TMM = BM / 64;
+  constexpr int LDC = BN + 4;
+#pragma unroll
+  for (int a = 0; a < TCO; ++a)
+#pragma unroll
+    for (int b = 0; b < TMM; ++b) {
+      const int ml = wr * (BM / 2) + b * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = wc * (BN / 2) + a * 32 + 8 * q + 4 * half;
+        f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        *(f32x4*)(sC + ml * LDC + col) = v;
+      }
+    }
+  __syncthreads();
+  constexpr int CVN = BN / 8;          // 8-channel groups per row
+  constexpr int RP = 256 / CVN;        // rows per pass
+  const int cg = tid % CVN, rr = tid / CVN;
+  const int co = n0 + cg * 8;
+  if (co < p.Cout) {
+    float bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
+#pragma unroll 2
+    for (int ml = rr; ml < BM; ml += RP) {
+      const int m = m0 + ml;
+      if (m >= p.M) break;
+      float v[8];
+      const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + cg * 8);
+      const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + cg * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
+      if (p.R) {
+#pragma unroll
+        for (int h = 0; h < 8 / EPV; ++h) {
+          float rf[EPV];
+          Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 8 / EPV; ++h)
+        *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
+    }
+  }
+}
+
 template <typename T, int BM, int BN, bool GN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;            // element size in bytes
   constexpr int AR = BM / 32, WR = BN / 32;   // rows staged per thread
@@ -105,20 +165,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
   int tap = cv / CinV, civ = cv % CinV;
   int kv = cv;
-  int64_t gnoff[AR];
+  // fused GroupNorm: the block's rows touch at most two slices (gn_rows >= BM); their affine rows are cached in LDS
+  float* sGN = (float*)(smem + MAIN_B + 336);        // [2 slices][a|b][Cin]
+  int gsel[AR];
   if (GN) {
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int64_t m = arow[i] < p.M ? arow[i] : 0;
-      const int64_t o = m / p.gn_outer_stride, rem = m % p.gn_outer_stride;
-      gnoff[i] = (o * p.gn_inner + (rem / p.gn_inner_stride) % p.gn_inner) * p.Cin;
+    const int s0 = (int)(m0 / p.gn_rows);
+    for (int i = tid; i < 4 * p.Cin; i += 256) {
+      const int sl = i / (2 * p.Cin), ab = (i / p.Cin) & 1, c = i % p.Cin;
+      const int sidx = min(s0 + sl, p.gn_S - 1);
+      sGN[i] = (ab ? p.gn_b : p.gn_a)[(int64_t)sidx * p.Cin + c];
     }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) gsel[i] = min((int)(arow[i] / p.gn_rows) - s0, 1) * 2 * p.Cin;
   }
 
-  u32x4 ra[AR], rw[WR];
+  u32x4 ra0[AR], rw0[WR], ra1[AR], rw1[WR];   // two register stages: tiles it+1 and it+2 are in flight
   __syncthreads();   // s_taps visible
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](u32x4 (&ra)[AR], u32x4 (&rw)[WR], int& meta) {
+    int okmask = 0;
     const bool tapok = tap < p.ntaps;
     int o0 = 0, o1 = 0, o2 = 0;
     if (tapok) { o0 = s_taps[tap * 3]; o1 = s_taps[tap * 3 + 1]; o2 = s_taps[tap * 3 + 2]; }
@@ -127,40 +192,41 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     for (int i = 0; i < AR; ++i) {
       const bool ok = tapok && (unsigned)(pp0[i] + o0) < (unsigned)p.D0 &&
                       (unsigned)(pp1[i] + o1) < (unsigned)p.D1 && (unsigned)(pp2[i] + o2) < (unsigned)p.D2;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        v = *(const u32x4*)(p.A + ((arow[i] + roff) * p.lda + (int64_t)civ * EPV) * ES);
-        if (GN) {
-          float f[EPV];
-          Elt<T>::unpack(v, f);
-          const float* ap = p.gn_a + gnoff[i] + civ * EPV;
-          const float* bp = p.gn_b + gnoff[i] + civ * EPV;
-#pragma unroll
-          for (int e = 0; e < EPV; e += 4) {
-            const f32x4 av = *(const f32x4*)(ap + e), bv = *(const f32x4*)(bp + e);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float y = f[e + k] * av[k] + bv[k];
-              f[e + k] = p.gn_act ? silu_f(y) : y;
-            }
-          }
-          v = Elt<T>::pack(f);
-        }
-      }
+      const char* src = ok ? p.A + ((arow[i] + roff) * p.lda + (int64_t)civ * EPV) * ES : (const char*)g_zero_page;
+      u32x4 v = *(const u32x4*)src;
+      okmask |= (ok ? 1 : 0) << i;
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
       const int co = n0 + r0 + 32 * i;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (co < p.Cout && kv < KV) v = *(const u32x4*)(p.W + ((int64_t)co * K + (int64_t)kv * EPV) * ES);
-      rw[i] = v;
+      const char* src = (co < p.Cout && kv < KV) ? p.W + ((int64_t)co * K + (int64_t)kv * EPV) * ES : (const char*)g_zero_page;
+      rw[i] = *(const u32x4*)src;
     }
+    meta = okmask | (civ << 8);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const u32x4 (&ra)[AR], const u32x4 (&rw)[WR], int meta) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i)
-      *(u32x4*)(sA + buf * BM * ROWB + (r0 + 32 * i) * ROWB + cv * 16) = ra[i];
+    for (int i = 0; i < AR; ++i) {
+      u32x4 v = ra[i];
+      if (GN && ((meta >> i) & 1)) {       // GroupNorm(+FiLM)(+SiLU) on the way into LDS; padding rows stay zero
+        float f[EPV];
+        Elt<T>::unpack(v, f);
+        const float* ap = sGN + gsel[i] + (meta >> 8) * EPV;
+        const float* bp = ap + p.Cin;
+#pragma unroll
+        for (int e = 0; e < EPV; e += 4) {
+          const f32x4 av = *(const f32x4*)(ap + e), bv = *(const f32x4*)(bp + e);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float y = f[e + k] * av[k] + bv[k];
+            f[e + k] = p.gn_act ? silu_f(y) : y;
+          }
+        }
+        v = Elt<T>::pack(f);
+      }
+      *(u32x4*)(sA + buf * BM * ROWB + (r0 + 32 * i) * ROWB + cv * 16) = v;
+    }
 #pragma unroll
     for (int i = 0; i < WR; ++i)
       *(u32x4*)(sW + buf * BN * ROWB + (r0 + 32 * i) * ROWB + cv * 16) = rw[i];
@@ -179,13 +245,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-  int cur = 0;
-  for (int it = 0; it < nit; ++it) {
-    const bool more = it + 1 < nit;
-    if (more) { advance(); load_tile(); }
+  auto compute = [&](int cur) {
     const char* bW = sW + cur * BN * ROWB + (wc * (BN / 2) + l31) * ROWB + half * 16;
     const char* bA = sA + cur * BM * ROWB + (wr * (BM / 2) + l31) * ROWB + half * 16;
 #pragma unroll
@@ -200,63 +260,197 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
         for (int b = 0; b < TMM; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
     }
-    if (more) store_tile(cur ^ 1);
+  };
+
+  // 3-stage pipeline: LDS[cur] = tile it, one register set = tile it+1 (landing), the other = tile it+2 (issued now)
+  int meta0 = 0, meta1 = 0;
+  load_tile(ra0, rw0, meta0);
+  if (GN) __syncthreads();          // sGN visible
+  store_tile(0, ra0, rw0, meta0);
+  if (nit > 1) { advance(); load_tile(ra0, rw0, meta0); }
+  __syncthreads();
+  int cur = 0, it = 0;
+  while (true) {
+    if (it + 2 < nit) { advance(); load_tile(ra1, rw1, meta1); }
+    compute(cur);
+    if (it + 1 < nit) store_tile(cur ^ 1, ra0, rw0, meta0);
+    __syncthreads();
+    cur ^= 1;
+    if (++it >= nit) break;
+    if (it + 2 < nit) { advance(); load_tile(ra0, rw0, meta0); }
+    compute(cur);
+    if (it + 1 < nit) store_tile(cur ^ 1, ra1, rw1, meta1);
+    __syncthreads();
+    cur ^= 1;
+    if (++it >= nit) break;
+  }
+
+  gemm_epilogue<T, BM, BN>(p, acc, sC, m0, n0, tid, wc, wr, half, l31);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS main loop (global_load_lds_dwordx4): operands never pass through VGPRs, no ds_write pass.
+// LDS tile rows are 128 B unpadded; the 16-byte chunk index is XOR-swizzled with ((row >> 1) & 7) so the
+// ds_read_b128 fragment reads stay conflict free.  The DMA writes lane-linear (base + lane*16), so the swizzle is
+// applied to the per-lane SOURCE address: lane L of the instruction covering tile rows [8j, 8j+8) lands in row
+// 8j + L/8, physical chunk L%8, and therefore fetches logical chunk (L%8) ^ ((row >> 1) & 7).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmParams p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  constexpr int LDC = BN + 4;
+  constexpr int TILE_B = 128 * 128;
+  constexpr int MAIN_B = (4 * TILE_B > BM * LDC * 4) ? 4 * TILE_B : BM * LDC * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                       // [2][128 rows][128 B]
+  char* sW = smem + 2 * TILE_B;
+  float* sC = (float*)smem;
+  int* s_taps = (int*)(smem + MAIN_B);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  if (tid < p.ntaps * 3) s_taps[tid] = p.taps[tid];
+
+  const int Nt = (p.Cout + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wgid % Nt, mt = wgid / Nt;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int CinV = p.Cin / EPV;
+  const int KV = CinV * p.ntaps;
+  const int64_t K = (int64_t)p.Cin * p.ntaps;
+  const int nit = (KV + 7) >> 3;
+  const int D12 = p.D1 * p.D2;
+
+  const int lrow = lane >> 3, pc = lane & 7;
+  const int c_par[2] = {pc ^ (lane >> 4), pc ^ (lane >> 4) ^ 4};    // logical chunk for even / odd row groups
+  int tapP[2], civP[2], kvP[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { tapP[q] = c_par[q] / CinV; civP[q] = c_par[q] % CinV; kvP[q] = c_par[q]; }
+
+  int pp0[4], pp1[4], pp2[4];
+  int64_t arow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wave * 32 + 8 * i + lrow;
+    arow[i] = (int64_t)m;
+    if (m < p.M) {
+      pp2[i] = m % p.D2;
+      pp1[i] = (m / p.D2) % p.D1;
+      pp0[i] = (m / D12) % p.D0;
+    } else {
+      pp0[i] = pp1[i] = pp2[i] = -(1 << 28);
+    }
+  }
+  __syncthreads();   // s_taps visible
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue = [&](int buf) {
+    int o0[2], o1[2], o2[2];
+    bool tapok[2];
+    int64_t roff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      tapok[q] = tapP[q] < p.ntaps;
+      const int t3 = tapok[q] ? tapP[q] * 3 : 0;
+      o0[q] = s_taps[t3]; o1[q] = s_taps[t3 + 1]; o2[q] = s_taps[t3 + 2];
+      roff[q] = (int64_t)o0[q] * D12 + o1[q] * p.D2 + o2[q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i & 1;
+      const bool ok = tapok[q] && (unsigned)(pp0[i] + o0[q]) < (unsigned)p.D0 &&
+                      (unsigned)(pp1[i] + o1[q]) < (unsigned)p.D1 && (unsigned)(pp2[i] + o2[q]) < (unsigned)p.D2;
+      const char* src = ok ? p.A + ((arow[i] + roff[q]) * p.lda + (int64_t)civP[q] * EPV) * ES : (const char*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * TILE_B + (wave * 32 + 8 * i) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i & 1;
+      const int co = n0 + wave * 32 + 8 * i + lrow;
+      const char* src = (co < p.Cout && kvP[q] < KV) ? p.W + ((int64_t)co * K + (int64_t)kvP[q] * EPV) * ES : (const char*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + buf * TILE_B + (wave * 32 + 8 * i) * 128), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      kvP[q] += 8;
+      civP[q] += 8;
+      while (civP[q] >= CinV) { civP[q] -= CinV; ++tapP[q]; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int xsw = (l31 >> 1) & 7;
+  auto compute = [&](int buf) {
+    const char* bW = sW + buf * TILE_B + (wc * 64 + l31) * 128;
+    const char* bA = sA + buf * TILE_B + (wr * 64 + l31) * 128;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int phys = ((2 * c + half) ^ xsw) * 16;
+      u32x4 fw[2], fa[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fw[a] = *(const u32x4*)(bW + a * 32 * 128 + phys);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fa[b] = *(const u32x4*)(bA + b * 32 * 128 + phys);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
+    }
+  };
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) { advance(); issue(cur ^ 1); }     // DMA of the next K step runs under this step's MFMAs
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
+  gemm_epilogue<T, BM, BN>(p, acc, sC, m0, n0, tid, wc, wr, half, l31);
+}
 
-  // ---- epilogue: acc -> LDS (fp32, [m][co]) -> coalesced 16-byte row stores
-#pragma unroll
-  for (int a = 0; a < TCO; ++a)
-#pragma unroll
-    for (int b = 0; b < TMM; ++b) {
-      const int ml = wr * (BM / 2) + b * 32 + l31;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = wc * (BN / 2) + a * 32 + 8 * q + 4 * half;
-        f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-        *(f32x4*)(sC + ml * LDC + col) = v;
-      }
-    }
-  __syncthreads();
-  constexpr int CVN = BN / 8;          // 8-channel groups per row
-  constexpr int RP = 256 / CVN;        // rows per pass
-  const int cg = tid % CVN, rr = tid / CVN;
-  const int co = n0 + cg * 8;
-  if (co < p.Cout) {
-    float bs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
-#pragma unroll 2
-    for (int ml = rr; ml < BM; ml += RP) {
-      const int m = m0 + ml;
-      if (m >= p.M) break;
-      float v[8];
-      const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + cg * 8);
-      const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + cg * 8 + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
-      if (p.R) {
-#pragma unroll
-        for (int h = 0; h < 8 / EPV; ++h) {
-          float rf[EPV];
-          Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
-#pragma unroll
-          for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 8 / EPV; ++h)
-        *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
-    }
+template <typename T>
+static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
+  const size_t lds = 128 * 132 * sizeof(float) + 336;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_glds: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
   }
+  const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128);
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<T>), dim3(grid), dim3(256), lds, st, p);
+  return mmd_check_launch("conv_gemm_glds");
 }
 
 template <typename T, int BM, int BN, bool GN>
 static int launch_conv_gemm(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds_ops = 2 * (size_t)(BM + BN) * ROWB;
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
-  const size_t lds = (lds_ops > lds_c ? lds_ops : lds_c) + 336;   // + tap table
+  const size_t lds = (lds_ops > lds_c ? lds_ops : lds_c) + 336 + (GN ? 16 * 256 : 0);   // + tap table (+ GN affine cache, Cin <= 256)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<T, BM, BN, GN>,
@@ -275,14 +469,14 @@ static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st)
     if (tile == 128) return launch_conv_gemm<T, 128, 128, true>(p, st);
     return launch_conv_gemm<T, 64, 64, true>(p, st);
   }
+  if (tile == 129) return launch_conv_gemm_glds<T>(p, st);
   if (tile == 128) return launch_conv_gemm<T, 128, 128, false>(p, st);
   return launch_conv_gemm<T, 64, 64, false>(p, st);
 }
 
 static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                           void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
-                          int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_inner, int64_t gn_outer_stride,
-                          int64_t gn_inner_stride, void* stream) {
+                          int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_S, int64_t gn_rows, void* stream) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_gemm: bad dtype %d", dtype);
   MMD_REQUIRE(A && W && Y && M > 0 && Cout > 0 && Cin > 0, "conv_gemm: null/empty argument");
@@ -292,35 +486,35 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   MMD_REQUIRE(lda % epv == 0 && ldy % epv == 0 && (!R || ldr % epv == 0), "conv_gemm: row strides must be 16-byte multiples");
   MMD_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)R) % 16 == 0, "conv_gemm: pointers must be 16-byte aligned");
   MMD_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "conv_gemm: bad position dims");
-  MMD_REQUIRE(!gn_a || (gn_b && ntaps == 1 && gn_inner > 0 && gn_outer_stride > 0 && gn_inner_stride > 0 && Cin % 4 == 0),
-              "conv_gemm: fused GroupNorm needs a 1x1 conv and a valid slice geometry");
+  MMD_REQUIRE(!gn_a || (gn_b && ntaps == 1 && gn_S > 0 && gn_rows >= 128 && Cin <= 256 && (int64_t)gn_S * gn_rows == M),
+              "gn_conv1x1: needs contiguous slices of >= 128 rows covering M and Cin <= 256 (got S=%d rows=%ld Cin=%d M=%d)",
+              gn_S, (long)gn_rows, Cin, M);
   ConvGemmParams p;
   p.A = (const char*)A; p.lda = lda; p.W = (const char*)W; p.bias = bias;
   p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
-  p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = gn_act; p.gn_inner = gn_inner;
-  p.gn_outer_stride = gn_outer_stride; p.gn_inner_stride = gn_inner_stride;
+  p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = gn_act; p.gn_S = gn_S; p.gn_rows = gn_rows;
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
-  MMD_REQUIRE(tile == 64 || tile == 128, "conv_gemm: tile must be 0, 64 or 128");
+  MMD_REQUIRE(tile == 64 || tile == 128 || (tile == 129 && !gn_a), "conv_gemm: tile must be 0, 64, 128 or 129 (128 direct-to-LDS)");
   return dtype == MMD_BF16 ? dispatch_conv_gemm<__bf16>(p, tile, st) : dispatch_conv_gemm<float>(p, tile, st);
 }
 
 extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                              void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
                              int tile, void* stream) {
-  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 1,
-                        1, 1, stream);
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 0,
+                        0, stream);
 }
 
-// 1x1 conv of GroupNorm32(+SiLU)'d rows: Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R); gn_a/gn_b [S, Cin] from
-// mmd_gn_stats, slice(m) = (m / outer_stride) * inner + ((m % outer_stride) / inner_stride) % inner.
-extern "C" int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int inner,
-                              int64_t outer_stride, int64_t inner_stride, const void* W, const float* bias, const void* R,
-                              int64_t ldr, void* Y, int64_t ldy, int M, int Cout, int Cin, int tile, void* stream) {
+// 1x1 conv of GroupNorm32(+FiLM)(+SiLU)'d rows: Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R); gn_a/gn_b [S, Cin] from
+// mmd_gn_stats over S contiguous slices of `rows_per_slice` rows (s(m) = m / rows_per_slice).
+extern "C" int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
+                              int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y,
+                              int64_t ldy, int M, int Cout, int Cin, int tile, void* stream) {
   static const int tap0[3] = {0, 0, 0};
   MMD_REQUIRE(gn_a && gn_b, "gn_conv1x1: null GroupNorm affine");
-  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, inner,
-                        outer_stride, inner_stride, stream);
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, S,
+                        rows_per_slice, stream);
 }

@@ -124,6 +124,41 @@ def taps_audio(dilation):
     return [(-dilation, 0, 0), (0, 0, 0), (dilation, 0, 0)]                 # D = (L, 1, 1)
 
 
+# ---- per-shape tile choice: measured once per (dtype, M, K, N, taps, fused-GN) on the real buffers at plan-build time
+AUTOTUNE = True
+_tile_cache = {}
+
+
+def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129)):
+    """launch(tile) enqueues the GEMM on the current stream.  Returns the fastest of `candidates`
+    (64 / 128 = register-staged tiles, 129 = 128x128 direct-to-LDS main loop)."""
+    default = (129 if 129 in candidates else 128) if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
+    if not AUTOTUNE or _recorder is None:
+        return default
+    if key in _tile_cache:
+        return _tile_cache[key]
+    import ctypes
+    best, best_ms = default, None
+    ev = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for e in ev:
+        H.call("mmd_event_create", ctypes.byref(e))
+    st = H.stream_handle()
+    for tile in candidates:
+        launch(tile)                      # warm (function attributes, caches)
+        H.call("mmd_event_record", ev[0], st)
+        for _ in range(3):
+            launch(tile)
+        H.call("mmd_event_record", ev[1], st)
+        ms = ctypes.c_float()
+        H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
+        if best_ms is None or ms.value < best_ms:
+            best, best_ms = tile, ms.value
+    for e in ev:
+        H.lib().mmd_event_destroy(e)
+    _tile_cache[key] = best
+    return best
+
+
 def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0):
     """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None."""
     _chk2d(x)
@@ -134,16 +169,24 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     arr, nt = H.taps_array(taps)
-    if tile == 0:       # same rule as the library's auto choice, made explicit so launches can be labelled
-        tile = 128 if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
     es = x.element_size()
+    base = (H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), H.ptr(residual),
+            0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, nt, arr,
+            int(dims[0]), int(dims[1]), int(dims[2]))
+    if tile == 0:
+        tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False),
+                          lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout)
     flops = 2 * M * Cout * Cin * nt
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
-    _dispatch("mmd_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias),
-           H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
-           M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile,
-           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
+    _dispatch("mmd_conv_gemm", *base, tile,
+           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{'128glds' if tile == 129 else tile}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
     return out
+
+
+def gn_fusable(geom: Geom, Cin, Cout):
+    """Whether GroupNorm can ride in the 1x1 GEMM loader: contiguous slices of >= 128 rows, narrow K and N."""
+    return (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
+            and (Cout + 127) // 128 <= 2)
 
 
 def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=0):
@@ -155,13 +198,17 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
         raise H.MMDError(f"gn_conv1x1: weight {tuple(w.shape)} {w.dtype} does not match input {tuple(x.shape)} {x.dtype}")
     out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
-    if tile == 0:
-        tile = 128 if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
     es = x.element_size()
+    if not gn_fusable(geom, Cin, Cout):
+        raise H.MMDError("gn_conv1x1: needs contiguous slices of >= 128 rows, Cin <= 256 (use gn_apply + conv_gemm otherwise)")
+    base = (H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
+            w.data_ptr(), H.ptr(bias), H.ptr(residual),
+            0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
+    if tile == 0:
+        tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
+                          lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout, candidates=(64, 128))
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
-    _dispatch("mmd_gn_conv1x1", H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.inner,
-              geom.outer_stride, geom.inner_stride, w.data_ptr(), H.ptr(bias), H.ptr(residual),
-              0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, tile,
+    _dispatch("mmd_gn_conv1x1", *base, tile,
               meta=(f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes))
     return out
 

@@ -56,7 +56,7 @@ def unrows_video(r, N, F, H, W):
 
 # --------------------------------------------------------------------------- implicit-GEMM convs
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [64, 128, 129])
 @pytest.mark.parametrize("M,Cin,Cout", [(300, 64, 96), (1024, 128, 384), (77, 32, 8)])
 def test_pointwise(ops, dt, tile, M, Cin, Cout):
     x, w, b, r = rnd(M, Cin, dt=dt, seed=1), rnd(Cout, Cin, dt=dt, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3), rnd(M, Cout, dt=dt, seed=4)
@@ -87,7 +87,7 @@ def test_video_conv_2d1d(ops, dt, N, F, H, W, Cin, Cout):
     sd = {"p.video_conv_spatial.weight": ws, "p.video_conv_spatial.bias": bs,
           "p.video_conv_temporal.weight": wt, "p.video_conv_temporal.bias": bt}
     y1 = ops.conv_gemm(dev(rows_video(x), dt), dev(ops.pack_conv_weight(ws, torch.float32), dt), bs.cuda(),
-                       taps=ops.TAPS_SPATIAL, dims=(N * F, H, W))
+                       taps=ops.TAPS_SPATIAL, dims=(N * F, H, W), tile=129)     # direct-to-LDS main loop
     ref1 = F_.conv3d(x, ws[:, :, None], bs, padding=(0, 1, 1))
     assert rel_l2(unrows_video(y1.float().cpu(), N, F, H, W), ref1) < tol(dt)
     y2 = ops.conv_gemm(y1, dev(ops.pack_conv_weight(wt, torch.float32), dt), bt.cuda(), taps=ops.TAPS_TEMPORAL, dims=(F, H * W, 1))
@@ -102,6 +102,8 @@ def test_audio_conv_dilated(ops, dt, L, d):
     x = rnd(N, Cin, L, dt=dt, seed=14)
     w, b = rnd(Cout, Cin, 3, dt=dt, seed=15, scale=(3 * Cin) ** -0.5), rnd(Cout, seed=16)
     y = ops.conv_gemm(dev(rows_audio(x), dt), dev(ops.pack_conv_weight(w, torch.float32), dt), b.cuda(), taps=ops.taps_audio(d), dims=(L, 1, 1))
+    y2 = ops.conv_gemm(dev(rows_audio(x), dt), dev(ops.pack_conv_weight(w, torch.float32), dt), b.cuda(), taps=ops.taps_audio(d), dims=(L, 1, 1), tile=129)
+    assert torch.equal(y, y2)          # every main-loop variant accumulates in the same k order -> bitwise equal
     ref = uref.audio_conv(x, {"p.audio_conv.weight": w, "p.audio_conv.bias": b}, "p", d)
     assert rel_l2(y.float().cpu().reshape(N, L, Cout).permute(0, 2, 1), ref) < tol(dt)
 
@@ -335,31 +337,27 @@ def test_ddpm_update(ops, learn_sigma):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("kind", ["per_sample", "spatial", "temporal"])
-def test_gn_fused_into_conv1x1(ops, dt, kind):
-    """GroupNorm(+FiLM)(+SiLU) applied inside the GEMM loader == separate apply kernel + GEMM."""
-    N, C, F, H, W, Cout = 2, 64, 4, 3, 5, 96
-    x = rnd(N, C, F, H, W, dt=dt, seed=60)
+@pytest.mark.parametrize("N,C,F,H,W,Cout,film_on", [(2, 64, 4, 6, 6, 96, True), (3, 128, 2, 8, 8, 256, False), (2, 256, 1, 12, 12, 128, True)])
+def test_gn_fused_into_conv1x1(ops, dt, N, C, F, H, W, Cout, film_on):
+    """GroupNorm(+FiLM)+SiLU applied inside the GEMM loader == oracle GN -> SiLU -> 1x1 conv -> + residual.
+    Rows per sample (144) are not a multiple of the tile, so blocks straddle two samples."""
+    x = rnd(N, C, F, H, W, dt=dt, seed=60) * 1.3 + 0.2
+    x = x.to(dt).float()
     g, b = 1 + 0.1 * rnd(C, seed=61), rnd(C, seed=62)
     w, bias, r = rnd(Cout, C, dt=dt, seed=63, scale=C ** -0.5), rnd(Cout, seed=64), rnd(N * F * H * W, Cout, dt=dt, seed=65)
     xa = dev(rows_video(x), dt)
-    if kind == "per_sample":
-        geom, film = ops.Geom.per_sample(N, F * H * W), rnd(N, 2 * C, seed=66, scale=0.3)
-        xr = uref.group_norm(x, g, b) * (1 + film[:, :C, None, None, None]) + film[:, C:, None, None, None]
-        act = True
-        xr = F_.silu(xr)
-    elif kind == "spatial":
-        geom, film, act = ops.Geom.spatial(N, F, H * W), None, False
-        xs = x.permute(0, 2, 1, 3, 4).reshape(N * F, C, H * W)
-        xr = uref.group_norm(xs, g, b).reshape(N, F, C, H, W).permute(0, 2, 1, 3, 4)
-    else:
-        geom, film, act = ops.Geom.temporal(N, F, H * W), None, False
-        xt = x.permute(0, 3, 4, 1, 2).reshape(N * H * W, C, F)
-        xr = uref.group_norm(xt, g, b).reshape(N, H, W, C, F).permute(0, 3, 4, 1, 2)
+    geom = ops.Geom.per_sample(N, F * H * W)
+    film = rnd(N, 2 * C, seed=66, scale=0.3) if film_on else None
+    xr = uref.group_norm(x, g, b)
+    if film_on:
+        xr = xr * (1 + film[:, :C, None, None, None]) + film[:, C:, None, None, None]
+    xr = F_.silu(xr)
+    assert ops.gn_fusable(geom, C, Cout)
     a_, b_ = ops.gn_stats(xa, g.cuda(), b.cuda(), geom, film=None if film is None else film.cuda())
-    y = ops.gn_conv1x1(xa, a_, b_, geom, act, dev(w, dt), bias.cuda(), residual=dev(r, dt))
-    ref = rows_video(xr) @ w.t() + bias + r
-    assert rel_l2(y.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.5e-2)
+    for tile in (64, 128):
+        y = ops.gn_conv1x1(xa, a_, b_, geom, True, dev(w, dt), bias.cuda(), residual=dev(r, dt), tile=tile)
+        ref = rows_video(xr) @ w.t() + bias + r
+        assert rel_l2(y.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.5e-2)
 
 
 def test_groupnorm_two_stage_path(ops):
