@@ -53,7 +53,7 @@ def kernel_breakdown(stepper, reps=3, detail=False):
     import ctypes
     lib = H.lib()
     stream = H.stream_handle()
-    plan = (stepper.eng.plan_f32 if stepper.use_f32 else stepper.eng.plan) + stepper.update_plan
+    plan = [e for e in (stepper.eng.plan_f32 if stepper.use_f32 else stepper.eng.plan) + stepper.update_plan if e[0] is not None]
     evs = []
     for _ in range(len(plan) + 1):
         e = ctypes.c_void_p()
@@ -63,13 +63,13 @@ def kernel_breakdown(stepper, reps=3, detail=False):
     for rep in range(reps):
         torch.cuda.synchronize()
         lib.mmd_event_record(evs[0], stream)
-        for i, (fn, args, name, meta) in enumerate(plan):
+        for i, (fn, args, name, meta, _sid) in enumerate(plan):
             rc = fn(*args, stream)
             assert rc == 0, name
             lib.mmd_event_record(evs[i + 1], stream)
         torch.cuda.synchronize()
         ms = ctypes.c_float()
-        for i, (fn, args, name, meta) in enumerate(plan):
+        for i, (fn, args, name, meta, _sid) in enumerate(plan):
             H.call("mmd_event_elapsed_ms", evs[i], evs[i + 1], ctypes.byref(ms))
             label, flops, nbytes = meta
             if not detail:

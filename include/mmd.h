@@ -39,6 +39,7 @@ int mmd_graph_launch(void* exec, void* stream);
 int mmd_graph_destroy(void* exec);
 int mmd_event_create(void** ev);
 int mmd_event_record(void* ev, void* stream);
+int mmd_stream_wait_event(void* stream, void* ev);   /* fork/join of the video and audio launch streams (also under capture) */
 int mmd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 int mmd_event_destroy(void* ev);
 

@@ -59,6 +59,11 @@ extern "C" int mmd_event_record(void* ev, void* stream) {
   if (hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "event_record failed");
   return MMD_OK;
 }
+extern "C" int mmd_stream_wait_event(void* stream, void* ev) {
+  hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
+  if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "stream_wait_event: %s", hipGetErrorString(e));
+  return MMD_OK;
+}
 extern "C" int mmd_event_elapsed_ms(void* a, void* b, float* ms) {
   hipError_t e = hipEventSynchronize((hipEvent_t)b);
   if (e == hipSuccess) e = hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b);

@@ -21,6 +21,7 @@ _PROTOS = {
     "mmd_graph_destroy": (i32, [vp]),
     "mmd_event_create": (i32, [C.POINTER(vp)]),
     "mmd_event_record": (i32, [vp, vp]),
+    "mmd_stream_wait_event": (i32, [vp, vp]),
     "mmd_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
     "mmd_event_destroy": (i32, [vp]),
     "mmd_temb_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

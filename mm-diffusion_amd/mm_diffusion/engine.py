@@ -61,7 +61,8 @@ class UNetEngine:
             if v.device.type != "cuda":
                 raise H.MMDError(f"parameter {k} is on {v.device}: move the model to the GPU first (model.to('cuda'))")
         self._sig = self._signature()
-        self.pool = _Pool(self.device)
+        self.pools = [_Pool(self.device), _Pool(self.device)]   # one per launch stream (video / audio run concurrently)
+        self.aux = torch.cuda.Stream(device=self.device)          # audio-stream launches
         self.keep = []          # packed weights etc. (kept alive)
         self.plan = []
         self.graph = None
@@ -78,15 +79,16 @@ class UNetEngine:
     def _alloc(self, rows, C, dtype=None):
         dtype = dtype or self.dtype
         es = torch.empty(0, dtype=dtype).element_size()
-        raw = self.pool.get(rows * C * es)
+        pool = self.pools[ops.cur_sid]
+        raw = pool.get(rows * C * es)
         t = raw[: rows * C * es].view(dtype).view(rows, C)
-        t._raw = raw
+        t._raw, t._pool = raw, pool
         return t
 
     def _release(self, *ts):
         for t in ts:
             if t is not None and hasattr(t, "_raw"):
-                self.pool.put(t._raw)
+                t._pool.put(t._raw)
                 del t._raw
 
     def _static(self, shape, dtype):
@@ -245,8 +247,11 @@ class UNetEngine:
                 dest = fin
             return dest
 
+        ops.cur_sid = 0
         vo = stream(v, "video", N * F * Hh * Hh, N * F * Ho * Ho, out_v)
+        ops.cur_sid = 1
         ao = stream(a, "audio", N * L, N * Lo, out_a)
+        ops.cur_sid = 0
         return vo, ao, Ho, Lo
 
     def _cross(self, v, a, layer, Hh, L, out_v=None, out_a=None):
@@ -257,18 +262,31 @@ class UNetEngine:
         HW, apf = Hh * Hh, int(L / F)
         if apf < 1:
             raise H.MMDError(f"cross attention needs at least one audio token per frame (L={L}, F={F})")
+        ops.cur_sid = 0
         vqkv = self._gn_pw(v, p + ".v_norm", Geom.per_sample(N, F * HW), False, p + ".v_qkv.weight", p + ".v_qkv.bias")
+        ops.cur_sid = 1
         aqkv = self._gn_pw(a, p + ".a_norm", Geom.per_sample(N, L), False, p + ".a_qkv.weight", p + ".a_qkv.bias")
+        ops.record_sync(1, 0)      # video queries need the audio k/v ...
+        ops.record_sync(0, 1)      # ... and vice versa
         sh = self.shift_dev[layer["shift_idx"]: layer["shift_idx"] + 1] if layer["shift"] else None
-        vatt, aatt = self._alloc(N * F * HW, C), self._alloc(N * L, C)
+        ops.cur_sid = 0
+        vatt = self._alloc(N * F * HW, C)
         ops.attn(vqkv, aqkv, vatt, heads, ch, N, F, F * HW, HW, L, apf, win, shift_dev=sh)
+        ops.cur_sid = 1
+        aatt = self._alloc(N * L, C)
         ops.attn(aqkv, vqkv, aatt, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
+        ops.record_sync(0, 1)      # both attentions retired before either stream recycles the other's qkv buffer
+        ops.record_sync(1, 0)
         self._release(vqkv, aqkv)
+        ops.cur_sid = 0
         vo = out_v if out_v is not None else self._alloc(N * F * HW, C)
-        ao = out_a if out_a is not None else self._alloc(N * L, C)
         self._pw(vatt, p + ".video_proj_out.video_conv.weight", p + ".video_proj_out.video_conv.bias", residual=v, out=vo)
+        self._release(vatt)
+        ops.cur_sid = 1
+        ao = out_a if out_a is not None else self._alloc(N * L, C)
         self._pw(aatt, p + ".audio_proj_out.audio_conv.weight", p + ".audio_proj_out.audio_conv.bias", residual=a, out=ao)
-        self._release(vatt, aatt)
+        self._release(aatt)
+        ops.cur_sid = 0
         return vo, ao
 
     # ------------------------------------------------------------------ plan
@@ -314,15 +332,17 @@ class UNetEngine:
 
         # two plans that differ only in the timestep dtype read by the first kernel
         self.plan = record(self.t_i64)
-        self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name, meta) if name == "mmd_temb_fwd" else (fn, args, name, meta)
-                         for fn, args, name, meta in self.plan]
+        self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name, meta, sid) if name == "mmd_temb_fwd"
+                         else (fn, args, name, meta, sid) for fn, args, name, meta, sid in self.plan]
 
     def _record(self, t_tensor, arch_in, arch_mid, arch_out):
         m, N, F, dt = self.model, self.N, self.F, self.dtype
         mc = self.mc
+        ops.cur_sid = 0
         ops.temb(t_tensor, mc, self._f32("time_embed.0.weight"), self._f32("time_embed.0.bias"),
                  self._f32("time_embed.2.weight"), self._f32("time_embed.2.bias"), self.emb_silu)
         ops.linear(self.emb_silu, self.emb_W, self.emb_b, self.emb_all)
+        ops.record_sync(0, 1)      # fork: the audio stream starts once the FiLM table (and the host-side input copies) exist
 
         # consumer channel split of every skip: output block k reads [h (ch_prev) | skip (ich)]
         skip_cols = []
@@ -343,8 +363,11 @@ class UNetEngine:
             for layer in layers:
                 if layer["kind"] == "res" and layer["down"]:
                     Ho, Lo = Hh // 2, L // 4
+            ops.cur_sid = 0
             vcat = self._alloc(N * F * Ho * Ho, chp + ich)
+            ops.cur_sid = 1
             acat = self._alloc(N * Lo, chp + ich)
+            ops.cur_sid = 0
             cat_bufs.append((vcat, acat))
             ov, oa = vcat[:, chp:], acat[:, chp:]
             for j, layer in enumerate(layers):
@@ -361,10 +384,12 @@ class UNetEngine:
                                        self._f32(p + ".video_conv.video_conv_temporal.bias"), taps=ops.TAPS_TEMPORAL,
                                        dims=(F, Hh * Hh, 1), out=tv if tv is not None else self._alloc(N * F * Hh * Hh, C0))
                     self._release(s1)
+                    ops.cur_sid = 1
                     na = ta if ta is not None else self._alloc(N * L, C0)
                     ops.stem_conv(self.x_audio, self._edge_w(p + ".audio_conv.audio_conv.weight"),
                                   self._f32(p + ".audio_conv.audio_conv.bias"), na, N, 1, self.Ca_in, 1, L,
                                   [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+                    ops.cur_sid = 0
                 elif layer["kind"] == "res":
                     nv, na, Hh, L = self._res(v, a, layer, Hh, L, tv, ta)
                 else:
@@ -404,13 +429,17 @@ class UNetEngine:
             self._release(vcat, acat)
 
         # ---- heads: GN -> SiLU -> conv (unet:1003-1012), fp32 API-layout outputs
+        ops.cur_sid = 0
         hv = self._gn(v, "video_out.0", Geom.per_sample(N, F * Hh * Hh), act=True)
         ops.head_conv(hv, self._edge_w("video_out.2.video_conv.weight"), self._f32("video_out.2.video_conv.bias"),
                       self.out_video, N, F, Hh, Hh, ops.TAPS_3D)
+        ops.cur_sid = 1
         ha = self._gn(a, "audio_out.0", Geom.per_sample(N, L), act=True)
         ops.head_conv(ha, self._edge_w("audio_out.2.audio_conv.weight"), self._f32("audio_out.2.audio_conv.bias"),
                       self.out_audio, N, 1, 1, L, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+        ops.cur_sid = 0
         self._release(hv, ha, v, a)
+        # NOTE: no join here - the caller appends per-stream work (DDPM update) and then joins (join_plan)
 
     # ------------------------------------------------------------------ execution
     def set_inputs(self, video, audio, timesteps, shifts):
@@ -437,8 +466,19 @@ class UNetEngine:
                 self.shift_host[i] = int(s)
             self.shift_dev.copy_(self.shift_host, non_blocking=True)
 
+    def join_plan(self):
+        """Plan tail: the main stream waits for the audio stream (everything after it sees both outputs)."""
+        tail = []
+        with ops.recording(tail):
+            ops.record_sync(1, 0)
+        return tail
+
     def run(self, use_f32=False):
-        ops.run_plan(self.plan_f32 if use_f32 else self.plan, H.stream_handle())
+        if not hasattr(self, "_join"):
+            self._join = self.join_plan()
+        st = H.stream_handle()
+        self.aux.wait_stream(torch.cuda.current_stream(self.device))   # aux starts clean behind the inputs
+        ops.run_plan((self.plan_f32 if use_f32 else self.plan) + self._join, st, self.aux.cuda_stream)
 
     def forward(self, video, audio, timesteps, shifts):
         use_f32 = self.set_inputs(video, audio, timesteps, shifts)

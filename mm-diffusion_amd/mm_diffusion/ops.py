@@ -30,19 +30,40 @@ class recording:
         _recorder = self._prev
 
 
+cur_sid = 0      # launch stream of the ops being recorded: 0 = video/main stream, 1 = audio stream
+
+
 def _dispatch(name, *args, meta=None):
     """meta = (kernel label, algorithmic flops, algorithmic HBM bytes) of this launch (bench roofline accounting)."""
     if _recorder is not None:
-        _recorder.append((getattr(H.lib(), name), args, name, meta or (name, 0, 0)))
+        _recorder.append((getattr(H.lib(), name), args, name, meta or (name, 0, 0), cur_sid))
     else:
         H.call(name, *args, H.stream_handle())
 
 
-def run_plan(plan, stream):
-    for fn, args, name, _ in plan:
-        rc = fn(*args, stream)
+def record_sync(src, dst):
+    """Plan marker: stream `dst` waits for everything recorded so far on stream `src` (event record + wait)."""
+    import ctypes
+    ev = ctypes.c_void_p()
+    H.call("mmd_event_create", ctypes.byref(ev))
+    _recorder.append((None, (src, dst, ev), "sync", None, -1))
+
+
+def run_plan(plan, stream, aux_stream=None):
+    """Replay a recorded plan.  With aux_stream the audio-stream ops run there (fork/join through events, also
+    valid under stream capture); without it everything runs in recording order on `stream` (markers are no-ops)."""
+    lib = H.lib()
+    streams = (stream, aux_stream if aux_stream is not None else stream)
+    for fn, args, name, _, sid in plan:
+        if fn is None:
+            if aux_stream is not None:
+                src, dst, ev = args
+                if lib.mmd_event_record(ev, streams[src]) or lib.mmd_stream_wait_event(streams[dst], ev):
+                    raise H.MMDError(f"sync failed: {lib.mmd_last_error().decode()}")
+            continue
+        rc = fn(*args, streams[sid])
         if rc != 0:
-            raise H.MMDError(f"{name} failed ({rc}): {H.lib().mmd_last_error().decode()}")
+            raise H.MMDError(f"{name} failed ({rc}): {lib.mmd_last_error().decode()}")
 
 
 class Geom:

@@ -42,9 +42,13 @@ class GraphStepper:
         F, C, HW = e.F, e.Cv_in, e.H0 * e.W0
         self.update_plan = []
         with ops.recording(self.update_plan):
-            # in place: x_{t-1} overwrites x_t (purely elementwise)
+            # in place: x_{t-1} overwrites x_t (purely elementwise); each update rides its own stream, then join
+            ops.cur_sid = 0
             ops.ddpm_update(e.x_video, e.out_video, self.noise_v, e.x_video, self.tab, self.t_idx, F, C, HW, self.flags)
+            ops.cur_sid = 1
             ops.ddpm_update(e.x_audio, e.out_audio, self.noise_a, e.x_audio, self.tab, self.t_idx, 1, e.Ca_in, e.L0, self.flags)
+            ops.cur_sid = 0
+            ops.record_sync(1, 0)
         self.graph = None
         self.use_graph = use_graph
         self._host_t = th.zeros(self.N, dtype=th.int64).pin_memory()
@@ -58,8 +62,9 @@ class GraphStepper:
         return {"video": self.eng.x_video.clone(), "audio": self.eng.x_audio.clone()}
 
     def _launch_all(self, stream):
-        ops.run_plan(self.eng.plan_f32 if self.use_f32 else self.eng.plan, stream)
-        ops.run_plan(self.update_plan, stream)
+        aux = self.eng.aux.cuda_stream
+        ops.run_plan(self.eng.plan_f32 if self.use_f32 else self.eng.plan, stream, aux)
+        ops.run_plan(self.update_plan, stream, aux)
 
     def _capture(self):
         side = th.cuda.Stream(device=self.device)
@@ -109,6 +114,7 @@ class GraphStepper:
                 self.eng.x_audio.copy_(xa)
             H.call("mmd_graph_launch", self.graph, H.stream_handle())
         else:
+            self.eng.aux.wait_stream(th.cuda.current_stream(self.device))
             self._launch_all(H.stream_handle())
 
     def step(self, i, shifts=None, noise=None):
