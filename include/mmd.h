@@ -131,6 +131,14 @@ int mmd_ddpm_update(const float* x, const float* model_out, const float* noise, 
 int mmd_q_sample(const float* x0, const float* eps, float* out, const float* tab2, const int64_t* t, int T, int N,
                  int64_t per_sample, void* stream);
 
+/* Per-sample loss terms of multimodal_training_losses for one stream (gd:1114-1203; vb term _vb_terms_bpd gd:1048-1092,
+ * losses.py:12-77): mse_out[n] = mean((target - eps_hat)^2); with flag 4 also vb_out[n] (KL for t>0, decoder NLL at t==0,
+ * in bits, frozen mean, clip off) * vb_scale.  Layouts as mmd_ddpm_update; deterministic two-stage reduction. */
+int64_t mmd_loss_workspace_bytes(int N);
+int mmd_loss_terms(const float* x0, const float* xt, const float* model_out, const float* target, const float* tables,
+                   const int64_t* t, int T, int N, int F, int C, int HW, int flags, float vb_scale, float* mse_out, float* vb_out,
+                   void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

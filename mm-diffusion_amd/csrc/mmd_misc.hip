@@ -260,6 +260,85 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
   }
 }
 
+
+// ----------------------------------------------------------------------------- training-loss reductions (forward values)
+// Per-sample terms of multimodal_training_losses (gd:1114-1203) for one stream, API layout [N, F, Cm, HW]:
+//   mse[n]  = mean((target - eps_hat)^2)                      (target = noise, or x0 when the model predicts x0)
+//   vb[n]   = mean(KL(q(x_{t-1}|x_t,x_0) || p) ) / ln2  for t > 0, decoder NLL / ln2 at t == 0   (learned-range variance;
+//             _vb_terms_bpd gd:1048-1092 with the frozen mean, normal_kl / discretized_gaussian_log_likelihood losses.py:12-77)
+// One block per (sample, chunk); fixed-order tree reduction -> deterministic.  partial [N, nchunk, 2] doubles.
+struct LossParams {
+  const float* x0; const float* xt; const float* mo; const float* target;
+  const float* tables; const int64_t* t;
+  double* partial;
+  int T, N, F, C, HW, flags, nchunk;
+};
+__device__ __forceinline__ float approx_std_normal_cdf(float x) {
+  return 0.5f * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__global__ __launch_bounds__(256) void loss_terms_kernel(const LossParams p) {
+  __shared__ double s_a[256], s_b[256];
+  const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int64_t per = (int64_t)p.F * p.C * p.HW;
+  const int Cm = (p.flags & 4) ? 2 * p.C : p.C;
+  const int ti = (int)p.t[n];
+  const float cr = p.tables[ti], crm1 = p.tables[p.T + ti], c1 = p.tables[2 * p.T + ti], c2 = p.tables[3 * p.T + ti];
+  const float min_log = p.tables[5 * p.T + ti], max_log = p.tables[6 * p.T + ti];
+  double mse = 0.0, vb = 0.0;
+  const int64_t lo = per * chunk / p.nchunk, hi = per * (chunk + 1) / p.nchunk;
+  for (int64_t r = lo + tid; r < hi; r += 256) {
+    const int hw = (int)(r % p.HW), c = (int)((r / p.HW) % p.C);
+    const int64_t f = r / ((int64_t)p.HW * p.C);
+    const int64_t i = n * per + r;
+    const int64_t mbase = ((n * (int64_t)p.F + f) * Cm) * (int64_t)p.HW + hw;
+    const float o = p.mo[mbase + (int64_t)c * p.HW];
+    const float d = p.target[i] - o;
+    mse += (double)(d * d);
+    if (p.flags & 4) {
+      const float vv = p.mo[mbase + (int64_t)(c + p.C) * p.HW];
+      const float frac = (vv + 1.f) / 2.f;
+      const float logvar = frac * max_log + (1.f - frac) * min_log;
+      const float xv = p.xt[i], x0 = p.x0[i];
+      const float px0 = (p.flags & 2) ? o : cr * xv - crm1 * o;          // clip_denoised=False in the vb term
+      const float mean = c1 * px0 + c2 * xv;
+      const float tmean = c1 * x0 + c2 * xv;
+      float term;
+      if (ti == 0) {        // decoder NLL
+        const float cx = x0 - mean, inv = expf(-0.5f * logvar);
+        const float cdf_p = approx_std_normal_cdf(inv * (cx + 1.f / 255.f));
+        const float cdf_m = approx_std_normal_cdf(inv * (cx - 1.f / 255.f));
+        const float lp = logf(fmaxf(cdf_p, 1e-12f)), lm = logf(fmaxf(1.f - cdf_m, 1e-12f));
+        const float ld = logf(fmaxf(cdf_p - cdf_m, 1e-12f));
+        term = -(x0 < -0.999f ? lp : (x0 > 0.999f ? lm : ld));
+      } else {              // KL(q || p), true posterior log-variance = min_log (posterior_log_variance_clipped)
+        const float dm = tmean - mean;
+        term = 0.5f * (-1.0f + logvar - min_log + expf(min_log - logvar) + dm * dm * expf(-logvar));
+      }
+      vb += (double)term;
+    }
+  }
+  s_a[tid] = mse;
+  s_b[tid] = vb;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { s_a[tid] += s_a[tid + o]; s_b[tid] += s_b[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    p.partial[((int64_t)n * p.nchunk + chunk) * 2] = s_a[0];
+    p.partial[((int64_t)n * p.nchunk + chunk) * 2 + 1] = s_b[0];
+  }
+}
+__global__ void loss_finalize_kernel(const double* __restrict__ partial, int nchunk, double inv_count, float vb_scale,
+                                     float* __restrict__ mse_out, float* __restrict__ vb_out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (int)gridDim.x * (int)blockDim.x) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nchunk; ++k) { a += partial[((int64_t)n * nchunk + k) * 2]; b += partial[((int64_t)n * nchunk + k) * 2 + 1]; }
+  mse_out[n] = (float)(a * inv_count);
+  if (vb_out) vb_out[n] = (float)(b * inv_count / 0.6931471805599453) * vb_scale;
+}
+
 // ============================================================================= C-ABI
 static inline int ew_grid(int64_t total) { return (int)min((int64_t)4096, (total + 255) / 256); }
 
@@ -322,11 +401,110 @@ extern "C" int mmd_stem_conv(int dtype, const float* x, const float* w, const fl
   return mmd_check_launch("stem_conv");
 }
 
+// Cooperative head conv: LPR = Cin/EPV lanes share one output row (each lane owns one 16-byte channel chunk, so every
+// tap is ONE coalesced row read), partial dot products are reduced across the row's lanes with xor-shuffles.
+// Weights sit in LDS as [tap][quad j][lane chunk][4 floats] so the 16 lanes of a row read 256 contiguous bytes
+// (conflict-free) and the row groups of a wave broadcast.
+template <typename T, int CO, int LPR>
+__global__ __launch_bounds__(256) void head_conv_coop_kernel(const HeadConvParams p) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  constexpr int NQ = EPV * CO / 4;       // float4 quads of weights per (tap, lane)
+  constexpr int RPW = 64 / LPR;          // rows per wave pass
+  extern __shared__ __attribute__((aligned(16))) float sw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < p.ntaps * NQ * LPR * 4; i += 256) {
+    const int k = i & 3, cvi = (i >> 2) % LPR, j = ((i >> 2) / LPR) % NQ, t = (i >> 2) / (LPR * NQ);
+    const int ec = j * 4 + k, e = ec / CO, c = ec % CO;
+    sw[i] = c < p.Co ? p.w[((int64_t)t * p.Cin + cvi * EPV + e) * p.Co + c] : 0.f;
+  }
+  __syncthreads();
+  const int HW = p.H * p.W;
+  const int64_t rows = (int64_t)p.N * p.F * HW;
+  const int cvi = lane % LPR, rsel = lane / LPR;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t mb = wave_id * RPW; mb < rows; mb += nwaves * RPW) {
+    const int64_t m = mb + rsel;
+    const bool rok = m < rows;
+    const int64_t mm = rok ? m : 0;
+    const int w0 = (int)(mm % p.W), h0 = (int)((mm / p.W) % p.H), f0 = (int)((mm / HW) % p.F);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int df = p.taps[t * 3], dh = p.taps[t * 3 + 1], dw = p.taps[t * 3 + 2];
+      const bool ok = rok && (unsigned)(f0 + df) < (unsigned)p.F && (unsigned)(h0 + dh) < (unsigned)p.H &&
+                      (unsigned)(w0 + dw) < (unsigned)p.W;
+      const int64_t src = mm + (int64_t)df * HW + dh * p.W + dw;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *(const u32x4*)(p.x + (src * p.ldx + (int64_t)cvi * EPV) * ES);
+      float f[EPV];
+      Elt<T>::unpack(v, f);
+      const float* wq = sw + ((int64_t)t * NQ * LPR + cvi) * 4;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const f32x4 w4 = *(const f32x4*)(wq + j * LPR * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ec = j * 4 + k;
+          acc[ec % CO] += f[ec / CO] * w4[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+    }
+    if (rok && cvi == 0) {
+      const int64_t n = m / ((int64_t)HW * p.F);
+      const int hw = h0 * p.W + w0;
+      for (int c = 0; c < p.Co; ++c) p.y[((n * p.F + f0) * p.Co + c) * HW + hw] = acc[c] + (p.bias ? p.bias[c] : 0.f);
+    }
+  }
+}
+
+template <typename T, int CO>
+static int launch_head_coop(const HeadConvParams& p, int lpr, hipStream_t st) {
+  constexpr int EPV = Elt<T>::EPV;
+  const size_t lds = (size_t)p.ntaps * (EPV * CO / 4) * lpr * 4 * sizeof(float);
+  const int64_t rows = (int64_t)p.N * p.F * p.H * p.W;
+  const int grid = (int)min((int64_t)2048, (rows + 63) / 64);
+#define MMD_HEAD_LAUNCH(L)                                                                                         \
+  do {                                                                                                             \
+    if (lds > 64 * 1024) {                                                                                         \
+      hipError_t e = hipFuncSetAttribute((const void*)head_conv_coop_kernel<T, CO, L>,                             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+      if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "head_conv: set LDS attr: %s", hipGetErrorString(e)); \
+    }                                                                                                              \
+    hipLaunchKernelGGL((head_conv_coop_kernel<T, CO, L>), dim3(grid), dim3(256), lds, st, p);                      \
+  } while (0)
+  switch (lpr) {
+    case 4: MMD_HEAD_LAUNCH(4); break;
+    case 8: MMD_HEAD_LAUNCH(8); break;
+    case 16: MMD_HEAD_LAUNCH(16); break;
+    case 32: MMD_HEAD_LAUNCH(32); break;
+    case 64: MMD_HEAD_LAUNCH(64); break;
+    default: return mmd_set_error(MMD_ERR_UNSUPPORTED, "head_conv: lanes per row %d", lpr);
+  }
+#undef MMD_HEAD_LAUNCH
+  return mmd_check_launch("head_conv_coop");
+}
+
 template <typename T>
 static int launch_head(const HeadConvParams& p, hipStream_t st) {
   const int64_t rows = (int64_t)p.N * p.F * p.H * p.W;
   const int grid = (int)min((int64_t)8192, (rows + 255) / 256);
   const int CO = p.Co <= 2 ? 2 : (p.Co <= 4 ? 4 : 8);
+  {   // cooperative kernel whenever the channel chunks of a row map onto a power-of-two lane group
+    const int lpr = p.Cin / Elt<T>::EPV;
+    const size_t lds_c = (size_t)p.ntaps * (Elt<T>::EPV * CO / 4) * lpr * 4 * sizeof(float);
+    if (p.Cin % Elt<T>::EPV == 0 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32 || lpr == 64) && lds_c <= 150 * 1024) {
+      if (CO == 2) return launch_head_coop<T, 2>(p, lpr, st);
+      if (CO == 4) return launch_head_coop<T, 4>(p, lpr, st);
+      return launch_head_coop<T, 8>(p, lpr, st);
+    }
+  }
   const size_t lds = (size_t)p.ntaps * p.Cin * CO * sizeof(float);
   if (lds > 150 * 1024) return mmd_set_error(MMD_ERR_UNSUPPORTED, "head_conv: weights (%zu B) exceed LDS", lds);
   const void* fn = CO == 2 ? (const void*)head_conv_kernel<T, 2> : CO == 4 ? (const void*)head_conv_kernel<T, 4> : (const void*)head_conv_kernel<T, 8>;
@@ -372,4 +550,26 @@ extern "C" int mmd_q_sample(const float* x0, const float* eps, float* out, const
   const int64_t total = per_sample * N;
   hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x0, eps, out, tab2, t, T, per_sample, total);
   return mmd_check_launch("q_sample");
+}
+
+#define MMD_LOSS_CHUNKS 64
+extern "C" int64_t mmd_loss_workspace_bytes(int N) { return (int64_t)N * MMD_LOSS_CHUNKS * 2 * sizeof(double); }
+
+// Per-sample loss terms of one stream (see loss_terms_kernel).  x0/xt may be NULL without flag 4.  vb_scale = T/1000 for
+// RESCALED_MSE else 1.  mse_out/vb_out fp32 [N].
+extern "C" int mmd_loss_terms(const float* x0, const float* xt, const float* model_out, const float* target, const float* tables,
+                              const int64_t* t, int T, int N, int F, int C, int HW, int flags, float vb_scale, float* mse_out,
+                              float* vb_out, void* workspace, void* stream) {
+  MMD_REQUIRE(model_out && target && tables && t && mse_out && workspace && T > 0 && N > 0 && F > 0 && C > 0 && HW > 0, "loss_terms: bad argument");
+  MMD_REQUIRE(!(flags & 4) || (x0 && xt && vb_out), "loss_terms: the vb term needs x0, x_t and vb_out");
+  LossParams p;
+  p.x0 = x0; p.xt = xt; p.mo = model_out; p.target = target; p.tables = tables; p.t = t; p.partial = (double*)workspace;
+  p.T = T; p.N = N; p.F = F; p.C = C; p.HW = HW; p.flags = flags; p.nchunk = MMD_LOSS_CHUNKS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_terms_kernel, dim3(MMD_LOSS_CHUNKS, N), dim3(256), 0, st, p);
+  int rc = mmd_check_launch("loss_terms");
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(N), 0, st, (const double*)workspace, MMD_LOSS_CHUNKS,
+                     1.0 / ((double)F * C * HW), vb_scale, mse_out, (flags & 4) ? vb_out : nullptr);
+  return mmd_check_launch("loss_finalize");
 }

@@ -39,6 +39,8 @@ _PROTOS = {
     "mmd_stem_conv": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
     "mmd_head_conv": (i32, [i32, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
     "mmd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mmd_loss_workspace_bytes": (i64, [i32]),
+    "mmd_loss_terms": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     "mmd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
 }
 EXPORTS = tuple(_PROTOS)

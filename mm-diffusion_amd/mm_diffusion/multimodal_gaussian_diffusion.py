@@ -243,19 +243,31 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ training loss (forward value only for now)
     def multimodal_training_losses(self, model, x_start, t, model_kwargs=None, noise=None):
-        """gd:1114-1203: loss = mse_video + mse_audio per sample (eps- or x0-prediction).  The forward value is
-        computed on the HIP path; the learned-sigma vb term and the backward pass are not built yet."""
-        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
-            raise NotImplementedError("the vb term of learn_sigma training is not built yet (SURVEY 8a18)")
+        """gd:1114-1203: per-sample loss = mse_video + mse_audio (+ vb_video + vb_audio with learned-range variance; the
+        vb term uses the frozen mean and clip_denoised=False, gd:1147-1174).  Forward VALUES only: q_sample, the U-Net
+        forward and the loss reductions all run in libmmd; the backward pass is not built yet (cfg4, next)."""
         model_kwargs = model_kwargs or {}
+        if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
+            raise NotImplementedError("KL / RESCALED_KL losses produce no terms in the reference either (gd:1143)")
         if noise is None:
             noise = {"video": self._randn_like(x_start["video"]), "audio": self._randn_like(x_start["audio"])}
-        video_t = self.q_sample(x_start["video"], t, noise=noise["video"])
-        audio_t = self.q_sample(x_start["audio"], t, noise=noise["audio"])
-        video_output, audio_output = model(video_t, audio_t, self._scale_timesteps(t), **model_kwargs)
+        xt = {k: self.q_sample(x_start[k], t, noise=noise[k]) for k in ("video", "audio")}
+        video_output, audio_output = model(xt["video"], xt["audio"], self._scale_timesteps(t), **model_kwargs)
+        tab, _ = self.device_tables(xt["video"].device)
+        learned = self.model_var_type == ModelVarType.LEARNED_RANGE
+        flags = (2 if self.model_mean_type == ModelMeanType.START_X else 0) | (4 if learned else 0)
+        vb_scale = self.num_timesteps / 1000.0 if self.loss_type == LossType.RESCALED_MSE else 1.0
         tgt = x_start if self.model_mean_type == ModelMeanType.START_X else noise
-        term = {"loss": 0}
-        term["mse_video"] = mean_flat((tgt["video"] - video_output) ** 2)
-        term["mse_audio"] = mean_flat((tgt["audio"] - audio_output) ** 2)
-        term["loss"] = term["mse_video"] + term["mse_audio"]
+        t64 = t.to(th.int64).contiguous()
+        term = {}
+        for key, mo in (("video", video_output), ("audio", audio_output)):
+            F, C, HW = _geom(xt[key])
+            mse, vb = ops.loss_terms(mo.float().contiguous(), tgt[key].float().contiguous(), tab, t64, F, C, HW, flags,
+                                     x0=x_start[key].float().contiguous() if learned else None,
+                                     xt=xt[key] if learned else None, vb_scale=vb_scale)
+            if learned:
+                term[f"vb_{key}"] = vb
+            term[f"mse_{key}"] = mse
+        # same accumulation order as the reference: (vb_video + vb_audio) then (mse_video + mse_audio)
+        term["loss"] = (term["vb_video"] + term["vb_audio"] if learned else 0) + (term["mse_video"] + term["mse_audio"])
         return term

@@ -321,6 +321,19 @@ def q_sample(x0, eps, out, tab2, t):
     return out
 
 
+def loss_terms(model_out, target, tables, t, F, C, HW, flags, x0=None, xt=None, vb_scale=1.0):
+    """Per-sample (mse, vb) of one stream on API-layout fp32 tensors; vb is None without the learned-range flag (4)."""
+    H.require_cuda(model_out, target, tables, t)
+    N = model_out.shape[0]
+    mse = torch.empty(N, dtype=torch.float32, device=model_out.device)
+    vb = torch.empty(N, dtype=torch.float32, device=model_out.device) if flags & 4 else None
+    ws = torch.empty(H.lib().mmd_loss_workspace_bytes(N) // 8, dtype=torch.float64, device=model_out.device)
+    _dispatch("mmd_loss_terms", H.ptr(x0), H.ptr(xt), model_out.data_ptr(), target.data_ptr(), tables.data_ptr(), t.data_ptr(),
+              tables.shape[1], N, F, C, HW, flags, float(vb_scale), mse.data_ptr(), H.ptr(vb), ws.data_ptr(),
+              meta=("loss_terms", 0, 8 * target.numel()))
+    return mse, vb
+
+
 def pack_conv_weight(w: torch.Tensor, dtype) -> torch.Tensor:
     """[Cout, Cin, *k] (torch conv layout) -> [Cout, ntaps*Cin] with K index = tap*Cin + ci (tap = row-major k)."""
     Cout, Cin = w.shape[0], w.shape[1]

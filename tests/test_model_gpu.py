@@ -116,9 +116,11 @@ def test_full_config_two_step_matches_reference(dt):
     assert ev < LOOP_TOL[dt] and ea < LOOP_TOL[dt]
 
 
-def test_training_loss_forward_values():
-    g = gold("tiny_train_loss")
-    fl, model, diff = build("tiny", "tiny", torch.float32)
+@pytest.mark.parametrize("tag,keyset,over", [("tiny", "tiny", {}), ("tiny_ls", "tiny_learn_sigma", dict(learn_sigma=True))])
+def test_training_loss_forward_values(tag, keyset, over):
+    """multimodal_training_losses terms (mse, and vb with learned-range variance) vs the reference's values."""
+    g = gold(tag + "_train_loss")
+    fl, model, diff = build("tiny", keyset, torch.float32, **over)
     B, seed = int(g["B"]), int(g["seed"])
     gen = torch.Generator().manual_seed(seed)
     x0 = {"video": torch.rand(B, *fl["video_size"], generator=gen) * 2 - 1, "audio": torch.rand(B, *fl["audio_size"], generator=gen) * 2 - 1}
@@ -127,8 +129,8 @@ def test_training_loss_forward_values():
     with torch.no_grad():
         terms = diff.multimodal_training_losses(model, {k: v.cuda() for k, v in x0.items()}, torch.from_numpy(g["t"]).cuda(),
                                                 noise={k: v.cuda() for k, v in noise.items()})
-    for k in ("loss", "mse_video", "mse_audio"):
-        np.testing.assert_allclose(terms[k].cpu().numpy(), g[k], rtol=5e-4)
+    for k in ("loss", "mse_video", "mse_audio") + (("vb_video", "vb_audio") if over else ()):
+        np.testing.assert_allclose(terms[k].cpu().numpy(), g[k], rtol=5e-4, atol=1e-6)
 
 
 def test_batch_sharding_is_exact():

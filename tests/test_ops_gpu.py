@@ -369,3 +369,27 @@ def test_groupnorm_two_stage_path(ops):
     y = ops.gn_apply(x.cuda(), *ops.gn_stats(x.cuda(), g.cuda(), b.cuda(), geom), geom, act=False)
     ref = uref.group_norm(x.reshape(N, R, C).permute(0, 2, 1), g, b).permute(0, 2, 1).reshape(-1, C)
     assert rel_l2(y.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("learn_sigma", [False, True])
+def test_loss_terms(ops, learn_sigma):
+    """mse / vb reductions vs the oracle's training_losses, incl. the t == 0 decoder-NLL branch."""
+    from oracle import diffusion_ref as dref
+    S = dref.Schedule(respacing="10", learn_sigma=learn_sigma)
+    N, F, C, HW = 3, 4, 3, 50
+    g = torch.Generator().manual_seed(70)
+    x0 = {"video": torch.rand(N, F, C, 5, 10, generator=g) * 2 - 1, "audio": torch.rand(N, 1, 77, generator=g) * 2 - 1}
+    noise = {"video": torch.randn(N, F, C, 5, 10, generator=g), "audio": torch.randn(N, 1, 77, generator=g)}
+    mo = {"video": torch.randn(N, F, 2 * C if learn_sigma else C, 5, 10, generator=g), "audio": torch.randn(N, 2 if learn_sigma else 1, 77, generator=g)}
+    t = torch.tensor([0, 5, 9])
+    ref = dref.training_losses(S, lambda v, a, tt: (mo["video"], mo["audio"]), x0, t, noise)
+    tab = np.stack([S.sqrt_recip_ac, S.sqrt_recipm1_ac, S.post_c1, S.post_c2,
+                    np.log(np.append(S.post_var[1], S.betas[1:])), S.post_logvar_clipped, np.log(S.betas)])
+    tab = torch.from_numpy(tab).float().cuda()
+    for key, (Fk, Ck, HWk) in (("video", (F, C, HW)), ("audio", (1, 1, 77))):
+        xt = dref.q_sample(S, x0[key], t, noise[key])
+        mse, vb = ops.loss_terms(mo[key].cuda(), noise[key].cuda(), tab, t.cuda(), Fk, Ck, HWk, 4 if learn_sigma else 0,
+                                 x0=x0[key].cuda() if learn_sigma else None, xt=xt.cuda() if learn_sigma else None)
+        np.testing.assert_allclose(mse.cpu().numpy(), ref[f"mse_{key}"].numpy(), rtol=1e-5)
+        if learn_sigma:
+            np.testing.assert_allclose(vb.cpu().numpy(), ref[f"vb_{key}"].numpy(), rtol=2e-4, atol=1e-6)
