@@ -47,7 +47,7 @@ def build(dtype_flag, respacing, batch, device):
     return fl, model, diff
 
 
-def kernel_breakdown(stepper, reps=3, detail=False):
+def kernel_breakdown(stepper, reps=3, detail=False, by_tag=False):
     """Per-kernel time of one step measured with HIP events on the launch stream (eager replay of the plan)."""
     from mm_diffusion import _hip as H
     import ctypes
@@ -63,17 +63,31 @@ def kernel_breakdown(stepper, reps=3, detail=False):
     for rep in range(reps):
         torch.cuda.synchronize()
         lib.mmd_event_record(evs[0], stream)
-        for i, (fn, args, name, meta, _sid) in enumerate(plan):
+        for i, (fn, args, name, meta, _sid, _tag) in enumerate(plan):
             rc = fn(*args, stream)
             assert rc == 0, name
             lib.mmd_event_record(evs[i + 1], stream)
         torch.cuda.synchronize()
         ms = ctypes.c_float()
-        for i, (fn, args, name, meta, _sid) in enumerate(plan):
+        for i, (fn, args, name, meta, _sid, _tag) in enumerate(plan):
             H.call("mmd_event_elapsed_ms", evs[i], evs[i + 1], ctypes.byref(ms))
             label, flops, nbytes = meta
+            if by_tag:
+                if not _tag:
+                    continue
+                a = agg.setdefault(_tag, dict(ms=0.0, calls=0, flops=0, bytes=0, attn_ms=0.0, attn_flops=0))
+                a["ms"] += ms.value
+                a["calls"] += 1
+                a["flops"] += flops
+                a["bytes"] += nbytes
+                if label.startswith("attn_fwd"):
+                    a["attn_ms"] += ms.value
+                    a["attn_flops"] += flops
+                continue
             if not detail:
                 label = label.split("[")[0]
+            else:
+                label += "@a" if _sid == 1 else "@v"
             a = agg.setdefault(label, dict(ms=0.0, calls=0, flops=0, bytes=0))
             a["ms"] += ms.value
             a["calls"] += 1
@@ -195,14 +209,34 @@ def main():
         a = agg[dom]
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        traffic = None
+        try:       # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/, separate --pmc runs)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(dom)
+        except Exception:
+            pass
         res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                           "traffic": None, "launches_per_step": a["calls"], "avg_launch_ms": a["ms"] / max(a["calls"], 1),
+                           "traffic": traffic, "launches_per_step": a["calls"], "avg_launch_ms": a["ms"] / max(a["calls"], 1),
                            "algorithmic_gflop_per_launch": a["flops"] / max(a["calls"], 1) / 1e9,
                            "share_of_step": a["ms"] / total_ms}
         res["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         hb = {k: v for k, v in agg.items() if v["flops"] == 0 and v["bytes"] > 0}
         if hb:
             res["hbm_kernels_gbs"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in hb.items()}
+        # the two kernels BASELINE.md grades (batch 4, bf16): fused video ResBlock ds=1 128->128 and RS cross-attention ds=2
+        tags = kernel_breakdown(stepper, reps=3, by_tag=True)
+        rb, xa = tags.get("input_blocks.1.0:video"), tags.get("input_blocks.4.1:cross")
+        if rb and xa:
+            E = args.batch * 16 * 128 * 64 * 64 * 2          # one ds=1 activation tensor in bytes (bf16)
+            res["graded"] = {
+                "video_resblock_ds1_128to128": {
+                    "ms": rb["ms"], "launches": rb["calls"], "min_traffic_MB": 6 * E / 1e6,
+                    "hbm_GBs_at_min_traffic": 6 * E / (rb["ms"] * 1e-3) / 1e9, "frac_of_8TBs": 6 * E / (rb["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "TFLOPs": rb["flops"] / (rb["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": rb["flops"] / (rb["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+                "rs_cross_attention_ds2": {
+                    "block_ms": xa["ms"], "attn_kernels_ms": xa["attn_ms"], "attn_GFLOP": xa["attn_flops"] / 1e9,
+                    "attn_TFLOPs": xa["attn_flops"] / (xa["attn_ms"] * 1e-3) / 1e12,
+                    "frac_of_mfma_peak": xa["attn_flops"] / (xa["attn_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}}
         if args.breakdown_out:
             det = kernel_breakdown(stepper, reps=2, detail=True)
             with open(args.breakdown_out, "w") as f:

@@ -15,6 +15,7 @@ SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libmmd.so")
 SOURCES = ["mmd_core.hip", "mmd_gemm.hip", "mmd_norm.hip", "mmd_attn.hip", "mmd_misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS += os.environ.get("MMD_EXTRA_CXXFLAGS", "").split()      # ablation builds (tools/*_bench.py), never set for the product
 
 
 def _stale():

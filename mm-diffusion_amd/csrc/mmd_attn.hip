@@ -51,6 +51,27 @@ __device__ __forceinline__ GroupInfo group_info(const AttnParams& p, int bg) {
   gi.k_start = (int)(((int64_t)(g + shift) * p.k_per_group) % gi.k_mod);
   return gi;
 }
+// XCD-aware block remap.  Workgroups are dealt round-robin to the 8 XCDs by flat id, and blockIdx.x (the query tile) is
+// the fastest index: by default the query tiles of one (head, group) land on 8 DIFFERENT XCDs and each private L2 fetches
+// the same K/V window from HBM again.  Remap so all query tiles of a (head, group) share flat-id mod 8 (same XCD, and
+// adjacent in dispatch order).  Returns (query tile, head, batch-group).
+__device__ __forceinline__ void attn_block_coords(int& qt, int& h, int& bg) {
+  const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+  const int hz_count = ny * nz;
+  int hz;
+  if ((hz_count & 7) == 0 && nx > 1) {
+    const int f = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int k = f >> 3, r = f & 7;
+    qt = k % nx;
+    hz = r + 8 * (k / nx);
+  } else {
+    qt = blockIdx.x;
+    hz = blockIdx.y + ny * blockIdx.z;
+  }
+  h = hz % ny;
+  bg = hz / ny;
+}
+
 __device__ __forceinline__ int64_t key_row(const GroupInfo& gi, int kk) {
   int r = gi.k_start + kk;
   if (r >= gi.k_mod) r -= gi.k_mod;
@@ -73,9 +94,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y;
-  const GroupInfo gi = group_info(p, blockIdx.z);
-  const int q0 = blockIdx.x * 128;
+  int qt, h, bg;
+  attn_block_coords(qt, h, bg);
+  const GroupInfo gi = group_info(p, bg);
+  const int q0 = qt * 128;
   if (q0 >= gi.q_count) return;        // uniform per block
 
   // zero the V^T rows beyond D once (D=16/48: upper half of a 32-row tile is never staged)
@@ -144,6 +166,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
           const int j = (id & 31) + 32 * ((id >> 6) & 1);
           const int v = 2 * (id >> 7) + ((id >> 5) & 1);
           uint16_t* dst = (uint16_t*)(sVt + (8 * v) * SVT_STRIDE + 2 * j);
+#if defined(ATTN_ABLATE) && ATTN_ABLATE == 2
+          if (rv[i][0] == 0x12345678u)
+#endif
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             dst[e * (SVT_STRIDE / 2)] = (uint16_t)((rv[i][e >> 1] >> ((e & 1) * 16)) & 0xffffu);
@@ -162,16 +187,16 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     // ---- S^T = K Q^T : two 32-key sub-tiles
     f32x16 s[2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      const char* kb = sK + (kt * 32 + l31) * SK + half * 16;
 #pragma unroll
-      for (int st = 0; st < KST; ++st) {
-        const u32x4 kf = *(const u32x4*)(kb + st * 32);
+    for (int st = 0; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {      // two independent accumulator chains interleaved
+        const u32x4 kf = *(const u32x4*)(sK + (kt * 32 + l31) * SK + half * 16 + st * 32);
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[st]), s[kt], 0, 0, 0);
       }
-    }
     // ---- online softmax (lane-local row; partner lane^32 holds the other 32 keys)
     const int kbase = t * 64 + 4 * half;
     float mx = -1e30f;
@@ -193,7 +218,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#if defined(ATTN_ABLATE) && ATTN_ABLATE == 1
+        const float e = s[kt][r] - m_new;
+#else
         const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+#endif
         s[kt][r] = e;
         ps += e;
       }
@@ -218,7 +247,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
           const u32x2 v0 = *(const u32x2*)(vb);
           const u32x2 v1 = *(const u32x2*)(vb + 16);
           u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+#if defined(ATTN_ABLATE) && ATTN_ABLATE == 3
+          o[dt][0] += __uint_as_float(vf[0]) * (float)pf[0];
+#else
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+#endif
         }
       }
   }
@@ -256,9 +289,10 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
   float* sAl = sL + 64;                // [64] rescale of this tile
 
   const int tid = threadIdx.x;
-  const int h = blockIdx.y;
-  const GroupInfo gi = group_info(p, blockIdx.z);
-  const int q0 = blockIdx.x * 64;
+  int qt, h, bg;
+  attn_block_coords(qt, h, bg);
+  const GroupInfo gi = group_info(p, bg);
+  const int q0 = qt * 64;
   if (q0 >= gi.q_count) return;
   const int ty = tid >> 4, tx = tid & 15;
 

@@ -405,6 +405,8 @@ extern "C" int mmd_stem_conv(int dtype, const float* x, const float* w, const fl
 // tap is ONE coalesced row read), partial dot products are reduced across the row's lanes with xor-shuffles.
 // Weights sit in LDS as [tap][quad j][lane chunk][4 floats] so the 16 lanes of a row read 256 contiguous bytes
 // (conflict-free) and the row groups of a wave broadcast.
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page_misc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 template <typename T, int CO, int LPR>
 __global__ __launch_bounds__(256) void head_conv_coop_kernel(const HeadConvParams p) {
   constexpr int EPV = Elt<T>::EPV;
@@ -431,23 +433,34 @@ __global__ __launch_bounds__(256) void head_conv_coop_kernel(const HeadConvParam
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    for (int t = 0; t < p.ntaps; ++t) {
-      const int df = p.taps[t * 3], dh = p.taps[t * 3 + 1], dw = p.taps[t * 3 + 2];
-      const bool ok = rok && (unsigned)(f0 + df) < (unsigned)p.F && (unsigned)(h0 + dh) < (unsigned)p.H &&
-                      (unsigned)(w0 + dw) < (unsigned)p.W;
-      const int64_t src = mm + (int64_t)df * HW + dh * p.W + dw;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *(const u32x4*)(p.x + (src * p.ldx + (int64_t)cvi * EPV) * ES);
-      float f[EPV];
-      Elt<T>::unpack(v, f);
-      const float* wq = sw + ((int64_t)t * NQ * LPR + cvi) * 4;
+    // taps in groups of 9: all 9 row reads are issued branch-free (padding -> zero page) before any is consumed
+    for (int tg = 0; tg < p.ntaps; tg += 9) {
+      u32x4 v[9];
 #pragma unroll
-      for (int j = 0; j < NQ; ++j) {
-        const f32x4 w4 = *(const f32x4*)(wq + j * LPR * 4);
+      for (int u = 0; u < 9; ++u) {
+        const int t = min(tg + u, p.ntaps - 1);
+        const int df = p.taps[t * 3], dh = p.taps[t * 3 + 1], dw = p.taps[t * 3 + 2];
+        const bool ok = rok && (tg + u < p.ntaps) && (unsigned)(f0 + df) < (unsigned)p.F && (unsigned)(h0 + dh) < (unsigned)p.H &&
+                        (unsigned)(w0 + dw) < (unsigned)p.W;
+        const int64_t src = mm + (int64_t)df * HW + dh * p.W + dw;
+        const char* sp = ok ? p.x + (src * p.ldx + (int64_t)cvi * EPV) * ES : (const char*)g_zero_page_misc;
+        v[u] = *(const u32x4*)sp;
+      }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int ec = j * 4 + k;
-          acc[ec % CO] += f[ec / CO] * w4[k];
+      for (int u = 0; u < 9; ++u) {
+        if (tg + u < p.ntaps) {
+          float f[EPV];
+          Elt<T>::unpack(v[u], f);
+          const float* wq = sw + ((int64_t)(tg + u) * NQ * LPR + cvi) * 4;
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) {
+            const f32x4 w4 = *(const f32x4*)(wq + j * LPR * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int ec = j * 4 + k;
+              acc[ec % CO] += f[ec / CO] * w4[k];
+            }
+          }
         }
       }
     }

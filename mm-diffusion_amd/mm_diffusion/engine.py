@@ -247,11 +247,11 @@ class UNetEngine:
                 dest = fin
             return dest
 
-        ops.cur_sid = 0
+        ops.cur_sid, ops.cur_tag = 0, p + ":video"
         vo = stream(v, "video", N * F * Hh * Hh, N * F * Ho * Ho, out_v)
-        ops.cur_sid = 1
+        ops.cur_sid, ops.cur_tag = 1, p + ":audio"
         ao = stream(a, "audio", N * L, N * Lo, out_a)
-        ops.cur_sid = 0
+        ops.cur_sid, ops.cur_tag = 0, ""
         return vo, ao, Ho, Lo
 
     def _cross(self, v, a, layer, Hh, L, out_v=None, out_a=None):
@@ -262,6 +262,7 @@ class UNetEngine:
         HW, apf = Hh * Hh, int(L / F)
         if apf < 1:
             raise H.MMDError(f"cross attention needs at least one audio token per frame (L={L}, F={F})")
+        ops.cur_tag = p + ":cross"
         ops.cur_sid = 0
         vqkv = self._gn_pw(v, p + ".v_norm", Geom.per_sample(N, F * HW), False, p + ".v_qkv.weight", p + ".v_qkv.bias")
         ops.cur_sid = 1
@@ -286,7 +287,7 @@ class UNetEngine:
         ao = out_a if out_a is not None else self._alloc(N * L, C)
         self._pw(aatt, p + ".audio_proj_out.audio_conv.weight", p + ".audio_proj_out.audio_conv.bias", residual=a, out=ao)
         self._release(aatt)
-        ops.cur_sid = 0
+        ops.cur_sid, ops.cur_tag = 0, ""
         return vo, ao
 
     # ------------------------------------------------------------------ plan
@@ -332,8 +333,8 @@ class UNetEngine:
 
         # two plans that differ only in the timestep dtype read by the first kernel
         self.plan = record(self.t_i64)
-        self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name, meta, sid) if name == "mmd_temb_fwd"
-                         else (fn, args, name, meta, sid) for fn, args, name, meta, sid in self.plan]
+        self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name, meta, sid, tag) if name == "mmd_temb_fwd"
+                         else (fn, args, name, meta, sid, tag) for fn, args, name, meta, sid, tag in self.plan]
 
     def _record(self, t_tensor, arch_in, arch_mid, arch_out):
         m, N, F, dt = self.model, self.N, self.F, self.dtype

@@ -31,12 +31,13 @@ class recording:
 
 
 cur_sid = 0      # launch stream of the ops being recorded: 0 = video/main stream, 1 = audio stream
+cur_tag = ""     # which reference module the recorded launches belong to (bench: per-block roofline accounting)
 
 
 def _dispatch(name, *args, meta=None):
     """meta = (kernel label, algorithmic flops, algorithmic HBM bytes) of this launch (bench roofline accounting)."""
     if _recorder is not None:
-        _recorder.append((getattr(H.lib(), name), args, name, meta or (name, 0, 0), cur_sid))
+        _recorder.append((getattr(H.lib(), name), args, name, meta or (name, 0, 0), cur_sid, cur_tag))
     else:
         H.call(name, *args, H.stream_handle())
 
@@ -46,7 +47,7 @@ def record_sync(src, dst):
     import ctypes
     ev = ctypes.c_void_p()
     H.call("mmd_event_create", ctypes.byref(ev))
-    _recorder.append((None, (src, dst, ev), "sync", None, -1))
+    _recorder.append((None, (src, dst, ev), "sync", None, -1, ""))
 
 
 def run_plan(plan, stream, aux_stream=None):
@@ -54,7 +55,7 @@ def run_plan(plan, stream, aux_stream=None):
     valid under stream capture); without it everything runs in recording order on `stream` (markers are no-ops)."""
     lib = H.lib()
     streams = (stream, aux_stream if aux_stream is not None else stream)
-    for fn, args, name, _, sid in plan:
+    for fn, args, name, _, sid, _tag in plan:
         if fn is None:
             if aux_stream is not None:
                 src, dst, ev = args

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of mmd_attn_fwd on the attention shapes of the Landscape model at batch 4 (bf16)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mm-diffusion_amd"))
+import torch  # noqa: E402
+from mm_diffusion import _hip as H, ops  # noqa: E402
+
+N, F = 4, 16
+SHAPES = [  # name, q rows/batch, q/group, k rows/batch, k/group, win, heads, ch
+    ("spatial ds2 T=1024", F * 1024, 1024, F * 1024, 1024, 1, 4, 64),
+    ("cross v<-a ds2", F * 1024, 1024, 6400, 400, 1, 4, 64),
+    ("cross a<-v ds2", 6400, 400, F * 1024, 1024, 1, 4, 64),
+    ("spatial ds4 T=256", F * 256, 256, F * 256, 256, 1, 4, 96),
+    ("cross v<-a ds4 w4", F * 256, 256, 1600, 100, 4, 6, 64),
+    ("cross a<-v ds4 w4", 1600, 100, F * 256, 256, 4, 6, 64),
+]
+
+
+def main():
+    dt = torch.bfloat16
+    ev = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for e in ev:
+        H.call("mmd_event_create", ctypes.byref(e))
+    st = H.stream_handle()
+    for name, qr, qg, kr, kg, win, heads, ch in SHAPES:
+        C = heads * ch
+        g = torch.Generator(device="cuda").manual_seed(0)
+        q = torch.randn(N * qr, 3 * C, device="cuda", generator=g).to(dt)
+        kv = torch.randn(N * kr, 3 * C, device="cuda", generator=g).to(dt)
+        out = torch.empty(N * qr, C, device="cuda", dtype=dt)
+        sh = torch.tensor([3], dtype=torch.int32, device="cuda")
+        flops = 4.0 * N * qr * win * kg * C
+        for _ in range(2):
+            ops.attn(q, kv, out, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh)
+        H.call("mmd_event_record", ev[0], st)
+        n = 10
+        for _ in range(n):
+            ops.attn(q, kv, out, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh)
+        H.call("mmd_event_record", ev[1], st)
+        ms = ctypes.c_float()
+        H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
+        us = ms.value / n * 1000
+        print(f"{name:22s} {us:8.1f} us  {flops/us/1e6:6.0f} TF/s  ({flops/1e9:.1f} GF)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
