@@ -17,6 +17,7 @@
 // attn_generic_kernel (fp32 math, any ch <= 128): LDS-tiled VALU flash attention - fp32 mode and odd shapes.
 // attn_small_kernel: one wave per (slice, head) for short sequences (temporal attention, T = F <= 32).
 #include "mmd_common.h"
+#include <type_traits>
 
 struct AttnParams {
   const char* Q; int64_t ldq;
@@ -81,8 +82,10 @@ __device__ __forceinline__ int64_t key_row(const GroupInfo& gi, int kk) {
 // ============================================================================= MFMA flash attention (bf16)
 #define SVT_STRIDE 136   // bytes per V^T row (64 keys * 2 B + 8): (stride/8) odd -> conflict-free ds_read_b64
 
+// launch bound 2 waves/SIMD (<= 256 registers): keeps the S / O accumulators in the unified VGPR file - with the default
+// bound hipcc parks them in AGPRs and every softmax / rescale touch costs a v_accvgpr_read + write pair (224 moves per tile).
 template <int D>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const AttnParams p) {
   constexpr int DV = D / 8;            // 16-byte vecs per row
   constexpr int SK = D * 2 + 16;       // bytes per K row in LDS ((SK/16) odd)
   constexpr int KST = D / 16;          // k-steps of the S MFMA
@@ -178,11 +181,20 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
   };
 
   load_kv(0);
-  for (int t = 0; t < ntiles; ++t) {
+  // full 64-key tiles never need the key mask: the body is instantiated twice so the (wave-uniform) ragged last tile
+  // does not leave 68 v_cmp/v_cndmask per tile in the hot loop (hipcc if-converts a plain `if`)
+  auto tile_body = [&](int t, auto ragged) {
     __syncthreads();          // previous tile fully consumed
+#if defined(ATTN_ABLATE) && ATTN_ABLATE == 5
+    if (t == 0)
+#endif
     store_kv();
     __syncthreads();
+#if defined(ATTN_ABLATE) && ATTN_ABLATE == 4
+    if (t + 1 < ntiles && gi.k_count < 0) load_kv((t + 1) * 64);
+#else
     if (t + 1 < ntiles) load_kv((t + 1) * 64);   // in flight during the MFMAs below
+#endif
 
     // ---- S^T = K Q^T : two 32-key sub-tiles
     f32x16 s[2];
@@ -197,21 +209,26 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
         const u32x4 kf = *(const u32x4*)(sK + (kt * 32 + l31) * SK + half * 16 + st * 32);
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[st]), s[kt], 0, 0, 0);
       }
-    // ---- online softmax (lane-local row; partner lane^32 holds the other 32 keys)
-    const int kbase = t * 64 + 4 * half;
-    float mx = -1e30f;
+    // ---- online softmax (lane-local row; partner lane^32 holds the other 32 keys).  VALU diet: the key mask is applied only
+    //      in the (wave-uniform) ragged last tile, the softmax scale rides in the exp2 fma, and the O rescale is skipped
+    //      when no lane's running max moved (alpha == 1 for the whole wave).
+    if constexpr (decltype(ragged)::value) {
+      const int kbase = t * 64 + 4 * half;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = kbase + 32 * kt + (r & 3) + 8 * (r >> 2);
+          s[kt][r] = kk < gi.k_count ? s[kt][r] : -3e38f;
+        }
+    }
+    float mx = -3e38f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = kbase + 32 * kt + (r & 3) + 8 * (r >> 2);
-        float v = s[kt][r] * sc;
-        v = kk < gi.k_count ? v : -1e30f;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * sc);        // sc > 0: max commutes with the scale
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float ps = 0.f;
 #pragma unroll
@@ -219,20 +236,22 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #if defined(ATTN_ABLATE) && ATTN_ABLATE == 1
-        const float e = s[kt][r] - m_new;
+        const float e = s[kt][r] * sc - m_new;
 #else
-        const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
 #endif
         s[kt][r] = e;
         ps += e;
       }
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
+    if (__any(m_new != m_run)) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
     m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     // ---- O^T += V^T P^T : P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -254,7 +273,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 #endif
         }
       }
-  }
+  };
+  const int nfull = gi.k_count >> 6;
+  for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+  if (nfull < ntiles) tile_body(nfull, std::true_type{});
   // ---- normalise and store: lane owns query qi, d = 32*dt + (r&3) + 8*(r>>2) + 4*half
   if (qok) {
     const float inv = 1.f / l_run;
