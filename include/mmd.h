@@ -55,12 +55,12 @@ int mmd_linear_fwd(const float* x, const float* W, const float* b, float* y, int
 
 /* GroupNorm32 statistics -> fused per-(slice,channel) affine (nn.py:16-33; FiLM unet:457-470).
  * Slice s normalises rows base(s) + j*tstride (j < Tn), base(s) = (s/inner)*outer_stride + (s%inner)*inner_stride.
- * a_out/b_out [S, C] fp32: y = x*a + b.  film (nullable) [S, >=2C] rows (scale | shift), row stride film_ld.
+ * a_out/b_out [S, C] fp32: y = x*a + b; mr_out (nullable) [S, 32, 2] = (mean, rstd) for the backward.  film (nullable) [S, >=2C] rows (scale | shift), row stride film_ld.
  * workspace: mmd_gn_workspace_bytes(dtype, C, S, Tn) bytes (may be 0: slice handled by one block). */
 int64_t mmd_gn_workspace_bytes(int dtype, int C, int S, int Tn);
 int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int inner, int64_t outer_stride,
                  int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, const float* film,
-                 int64_t film_ld, float eps, float* a_out, float* b_out, void* workspace, void* stream);
+                 int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out, void* workspace, void* stream);
 /* y = act(x*a[slice(row)] + b[slice(row)]), act: 0 none, 1 SiLU (nn.SiLU after every GroupNorm32). */
 int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn, int inner,
                  int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a, const float* b, int act,
@@ -106,7 +106,7 @@ int mmd_attn_small_fwd(int dtype, const void* QKV, int64_t ld, void* O, int64_t 
 /* Downsample (avg-pool, mode 0) / Upsample (nearest, mode 1) by (1, fh, fw) on rows (nf, h, w)
  * (unet:133-208: video (1,2,2); audio F=1,H=1,W=L, fw=4).  H, W describe the INPUT. */
 int mmd_resample(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int NF, int H, int W, int fh, int fw,
-                 int mode, void* stream);
+                 int mode, float scale, void* stream);   /* y = scale * resample(x): backward of one mode is the other mode, rescaled */
 /* 2-D strided copy (skip-connection concat th.cat, unet:1093-1094). */
 int mmd_copy2d(const void* x, int64_t ldx_bytes, void* y, int64_t ldy_bytes, int64_t rows, int64_t row_bytes, void* stream);
 
@@ -138,6 +138,30 @@ int64_t mmd_loss_workspace_bytes(int N);
 int mmd_loss_terms(const float* x0, const float* xt, const float* model_out, const float* target, const float* tables,
                    const int64_t* t, int T, int N, int F, int C, int HW, int flags, float vb_scale, float* mse_out, float* vb_out,
                    void* workspace, void* stream);
+
+/* ---------------------------------------------------------------- training step: backward kernels (gd:1114-1203 backward)
+ * conv wgrad: dW fp32 [Cout][ntaps*Cin] += dY^T gather(X) (same tap semantics as mmd_conv_gemm; caller zeroes dW), db
+ * (nullable, fp32 [Cout]) += column sums of dY.  conv dgrad = mmd_conv_gemm(dY, W^T-packed, taps negated). */
+int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, float* db, int M, int Cout, int Cin,
+                   int ntaps, const int* taps, int D0, int D1, int D2, void* stream);
+/* GroupNorm32(+FiLM)(+SiLU) backward; a, b, mr from the forward mmd_gn_stats; dgamma/dbeta accumulate; dfilm (nullable)
+ * [S, >=2C] receives (dscale | dshift); workspace (S*C*2 + S*64) floats. */
+int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C, int S,
+               int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a, const float* b,
+               const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld, int act, float* dgamma,
+               float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream);
+/* Attention backward for every attention of the model (strided + windowed row descriptor, see mmd_attn_bwd.hip). */
+int mmd_attn_bwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off, int v_off, const void* O,
+                 int64_t ldo, const void* dO, int64_t lddo, void* dQ, int64_t lddq, int dq_off, void* dKV, int64_t lddkv, int dk_off,
+                 int dv_off, float* lse_ws, float* dsum_ws, int heads, int ch, int nb, int G, int q_inner, int64_t q_outer,
+                 int64_t q_istride, int64_t q_tstride, int q_total, int q_per_group, int k_inner, int64_t k_outer, int64_t k_istride,
+                 int64_t k_tstride, int k_mod, int k_per_group, int win, const int* shift_dev, void* stream);
+/* out = silu(x) (dy NULL) or dy*silu'(x); d(mse loss)/d(out); AdamW (+EMA, nn.py:128-138) on flat fp32 buffers. */
+int mmd_timestep_embedding(const void* t, int t_kind, int N, int dim, float* out, void* stream);   /* nn.py:192-210 */
+int mmd_silu(int dtype, const void* x, const void* dy, void* out, int64_t n, void* stream);
+int mmd_mse_grad(const float* out, const float* target, const float* w, float* g, int N, int64_t per_sample, void* stream);
+int mmd_adamw_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float ema_rate, void* stream);
 
 #ifdef __cplusplus
 }

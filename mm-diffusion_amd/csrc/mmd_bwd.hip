@@ -1,0 +1,407 @@
+// Backward kernels of the training step (multimodal_training_losses backward, reference gd:1114-1203 through the U-Net).
+//
+//   conv wgrad   dW[co, tap*Cin + ci] += sum_m dY[m, co] * X[src(m, tap), ci]        (implicit GEMM, reduction over rows)
+//   conv dgrad   = mmd_conv_gemm on dY with the transposed weight and mirrored taps   (no new kernel)
+//   colsum       db[c] += sum_m dY[m, c]
+//   GroupNorm    backward of y = act((x - mu) rstd gamma (1 + scale) ... ) in the fused-affine form of mmd_norm.hip
+//   elementwise  SiLU forward/backward, d(mse)/d(out), AdamW (+EMA)
+// Accumulation into dW / db uses fp32 L2 atomics over row splits (like the vendor conv backward, run-to-run bit
+// differences of the last ulp are possible); everything else is deterministic.
+#include "mmd_common.h"
+
+// ============================================================================= conv wgrad (implicit GEMM-TN on MFMA)
+struct WgradParams {
+  const char* dY; int64_t lddy;      // [M, Cout]
+  const char* X; int64_t ldx;        // [rows, Cin]
+  float* dW;                         // fp32 [Cout][ntaps*Cin], accumulated with atomics
+  int M, Cout, Cin, ntaps;
+  int D0, D1, D2;
+  int rows_per_split;
+  int taps[27 * 3];
+};
+
+// Block = 64 (co) x 64 (ci of ONE tap) output tile x one row split; 4 waves, each a 32x32 MFMA tile.
+// The reduction index is the row m, so both operands are needed "column-wise" (8 consecutive rows of one channel):
+// tiles are staged row-major in LDS (coalesced 16-B loads) and the fragments are gathered with 2-byte LDS reads
+// (bf16) / 4-byte reads (fp32), which are conflict free because adjacent lanes read adjacent channels.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  constexpr int MT = 64;                       // rows per staged chunk
+  constexpr int LDT = 64 * ES + 16;            // bytes per staged row (64 channels + pad)
+  __shared__ __attribute__((aligned(16))) char sdy[MT * LDT];
+  __shared__ __attribute__((aligned(16))) char sx[MT * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;     // wave tile: co 32*wi, ci 32*wj
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = (p.Cin + 63) / 64;
+  const int kt = blockIdx.y;                   // (tap, ci tile)
+  const int tap = kt / ci_tiles, ci0 = (kt % ci_tiles) * 64;
+  const int co0 = blockIdx.x * 64;
+  const int o0 = p.taps[tap * 3], o1 = p.taps[tap * 3 + 1], o2 = p.taps[tap * 3 + 2];
+  const int D12 = p.D1 * p.D2;
+  const int64_t roff = (int64_t)o0 * D12 + o1 * p.D2 + o2;
+  const int m_begin = blockIdx.z * p.rows_per_split;
+  const int m_end = min(m_begin + p.rows_per_split, p.M);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  constexpr int VPR = 64 / EPV;                // 16-byte vecs per staged row
+  for (int mc = m_begin; mc < m_end; mc += MT) {
+    __syncthreads();
+    for (int i = tid; i < MT * VPR; i += 256) {
+      const int r = i / VPR, v = i % VPR;
+      const int m = mc + r;
+      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+      if (m < m_end) {
+        if (co0 + v * EPV < p.Cout) a = *(const u32x4*)(p.dY + ((int64_t)m * p.lddy + co0 + v * EPV) * ES);
+        const int p2 = m % p.D2, p1 = (m / p.D2) % p.D1, p0 = (m / D12) % p.D0;
+        if (ci0 + v * EPV < p.Cin && (unsigned)(p0 + o0) < (unsigned)p.D0 && (unsigned)(p1 + o1) < (unsigned)p.D1 &&
+            (unsigned)(p2 + o2) < (unsigned)p.D2)
+          b = *(const u32x4*)(p.X + (((int64_t)m + roff) * p.ldx + ci0 + v * EPV) * ES);
+      }
+      *(u32x4*)(sdy + r * LDT + v * 16) = a;
+      *(u32x4*)(sx + r * LDT + v * 16) = b;
+    }
+    __syncthreads();
+    if constexpr (EPV == 8) {
+#pragma unroll
+      for (int ks = 0; ks < MT / 16; ++ks) {        // 16 rows per MFMA: lane (channel l31, half) takes rows ks*16 + 8*half + j
+        bf16x8 fa, fb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = ks * 16 + 8 * half + j;
+          fa[j] = *(const __bf16*)(sdy + r * LDT + (wi * 32 + l31) * 2);
+          fb[j] = *(const __bf16*)(sx + r * LDT + (wj * 32 + l31) * 2);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll 8
+      for (int ks = 0; ks < MT / 2; ++ks) {         // 2 rows per MFMA: lane half takes row 2*ks + half
+        const int r = ks * 2 + half;
+        const float fa = *(const float*)(sdy + r * LDT + (wi * 32 + l31) * 4);
+        const float fb = *(const float*)(sx + r * LDT + (wj * 32 + l31) * 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+      }
+    }
+  }
+  // D[row = co][col = ci]: lane holds ci = l31, co = (r&3) + 8*(r>>2) + 4*half
+  const int64_t K = (int64_t)p.Cin * p.ntaps;
+  const int ci = ci0 + wj * 32 + l31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (co < p.Cout && ci < p.Cin) atomicAdd(p.dW + (int64_t)co * K + (int64_t)tap * p.Cin + ci, acc[r]);
+  }
+}
+
+// db[c] += sum over rows of dY[m, c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const char* __restrict__ dy, int64_t ld, int M, int C, float* __restrict__ out,
+                                                     int rows_per_block) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  __shared__ float s_sum[256 * EPV];
+  const int tid = threadIdx.x;
+  const int CV = C / EPV, RPP = 256 / CV;
+  const int col = tid % CV, rl = tid / CV;
+  float sum[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) sum[e] = 0.f;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(m0 + rows_per_block, M);
+  if (rl < RPP) {
+    for (int m = m0 + rl; m < m1; m += RPP) {
+      float f[EPV];
+      Elt<T>::unpack(*(const u32x4*)(dy + ((int64_t)m * ld + col * EPV) * ES), f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) sum[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) s_sum[rl * C + col * EPV + e] = sum[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int r = 0; r < RPP; ++r) a += s_sum[r * C + c];
+    atomicAdd(out + c, a);
+  }
+}
+
+// ============================================================================= GroupNorm backward
+// Forward (mmd_norm.hip): v = x*a[s,c] + b[s,c], y = act(v) with a = rstd*gamma*(1+sc), b = (beta - mu*rstd*gamma)(1+sc) + sh.
+// With z = (x - mu) rstd:   P[s,c] = sum_rows dv,  Q[s,c] = sum_rows dv*z   (dv = dy * act'(v))
+//   dshift = P, dscale = gamma*Q + beta*P, dbeta += (1+sc) P, dgamma += (1+sc) Q
+//   dx = rstd * ( (1+sc) gamma dv - mean_g[(1+sc) gamma P]/... )   -> per (slice, group) m1 = sum_c g_c P_c / cnt, m2 = sum_c g_c Q_c / cnt
+//   dx = rstd * (g_c dv - m1 - z m2),  g_c = (1+sc_c) gamma_c
+struct GnBwdGeom {
+  int S, Tn, inner;
+  int64_t outer_stride, inner_stride, tstride;
+};
+__device__ __forceinline__ int64_t gnb_base(const GnBwdGeom& g, int s) {
+  return (int64_t)(s / g.inner) * g.outer_stride + (int64_t)(s % g.inner) * g.inner_stride;
+}
+
+// stage 1: per (slice, row chunk) partial P, Q per channel -> atomics into PQ[S][C][2] (fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const char* __restrict__ x, int64_t ldx, const char* __restrict__ dy, int64_t lddy,
+                                                            int C, GnBwdGeom g, const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ mr, int act, int R, float* __restrict__ PQ) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  __shared__ float s_p[256 * EPV], s_q[256 * EPV];
+  const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int CV = C / EPV, RPP = 256 / CV;
+  const int col = tid % CV, rl = tid / CV;
+  const int cpg = C / 32;
+  const int64_t base = gnb_base(g, s);
+  float P[EPV], Q[EPV], av[EPV], bv[EPV], mu[EPV], rs[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    const int c = col * EPV + e;
+    P[e] = Q[e] = 0.f;
+    av[e] = a[(int64_t)s * C + c];
+    bv[e] = b[(int64_t)s * C + c];
+    mu[e] = mr[((int64_t)s * 32 + c / cpg) * 2];
+    rs[e] = mr[((int64_t)s * 32 + c / cpg) * 2 + 1];
+  }
+  const int j0 = chunk * R, j1 = min(j0 + R, g.Tn);
+  if (rl < RPP) {
+    for (int j = j0 + rl; j < j1; j += RPP) {
+      const int64_t row = base + (int64_t)j * g.tstride;
+      float fx[EPV], fd[EPV];
+      Elt<T>::unpack(*(const u32x4*)(x + (row * ldx + col * EPV) * ES), fx);
+      Elt<T>::unpack(*(const u32x4*)(dy + (row * lddy + col * EPV) * ES), fd);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        float dv = fd[e];
+        if (act) {
+          const float v = fx[e] * av[e] + bv[e];
+          const float sg = 1.f / (1.f + __expf(-v));
+          dv *= sg * (1.f + v * (1.f - sg));
+        }
+        P[e] += dv;
+        Q[e] += dv * (fx[e] - mu[e]) * rs[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s_p[rl * C + col * EPV + e] = P[e]; s_q[rl * C + col * EPV + e] = Q[e]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float pa = 0.f, qa = 0.f;
+    for (int r = 0; r < RPP; ++r) { pa += s_p[r * C + c]; qa += s_q[r * C + c]; }
+    atomicAdd(PQ + ((int64_t)s * C + c) * 2, pa);
+    atomicAdd(PQ + ((int64_t)s * C + c) * 2 + 1, qa);
+  }
+}
+
+// stage 2: parameter / FiLM gradients and the per-(slice, group) means m1, m2   (one block per slice)
+__global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restrict__ PQ, int C, int Tn, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ film, int64_t film_ld,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dfilm,
+                                                            int64_t dfilm_ld, float* __restrict__ m12) {
+  __shared__ float s_g1[1024], s_g2[1024];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / 32;
+  for (int c = tid; c < C; c += 256) {
+    const float P = PQ[((int64_t)s * C + c) * 2], Q = PQ[((int64_t)s * C + c) * 2 + 1];
+    const float sc1 = film ? 1.f + film[(int64_t)s * film_ld + c] : 1.f;
+    const float gc = sc1 * gamma[c];
+    s_g1[c] = gc * P;
+    s_g2[c] = gc * Q;
+    atomicAdd(dgamma + c, sc1 * Q);
+    atomicAdd(dbeta + c, sc1 * P);
+    if (dfilm) {
+      dfilm[(int64_t)s * dfilm_ld + c] = gamma[c] * Q + beta[c] * P;        // d scale
+      dfilm[(int64_t)s * dfilm_ld + C + c] = P;                             // d shift
+    }
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a1 += s_g1[c]; a2 += s_g2[c]; }
+    const float cnt = (float)Tn * (float)cpg;
+    m12[((int64_t)s * 32 + tid) * 2] = a1 / cnt;
+    m12[((int64_t)s * 32 + tid) * 2 + 1] = a2 / cnt;
+  }
+}
+
+// stage 3: dx = rstd * (g_c dv - m1 - z m2)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const char* __restrict__ x, int64_t ldx, const char* __restrict__ dy, int64_t lddy,
+                                                           char* __restrict__ dx, int64_t lddx, int64_t rows, int C, GnBwdGeom g,
+                                                           const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mr,
+                                                           const float* __restrict__ m12, const float* __restrict__ gamma,
+                                                           const float* __restrict__ film, int64_t film_ld, int act) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  const int CV = C / EPV, cpg = C / 32;
+  const int64_t total = rows * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / CV;
+    const int cvi = (int)(i % CV);
+    const int64_t o = m / g.outer_stride, rem = m % g.outer_stride;
+    const int s = (int)(o * g.inner + (rem / g.inner_stride) % g.inner);
+    float fx[EPV], fd[EPV], out[EPV];
+    Elt<T>::unpack(*(const u32x4*)(x + (m * ldx + (int64_t)cvi * EPV) * ES), fx);
+    Elt<T>::unpack(*(const u32x4*)(dy + (m * lddy + (int64_t)cvi * EPV) * ES), fd);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const int c = cvi * EPV + e, gi = c / cpg;
+      float dv = fd[e];
+      if (act) {
+        const float v = fx[e] * a[(int64_t)s * C + c] + b[(int64_t)s * C + c];
+        const float sg = 1.f / (1.f + __expf(-v));
+        dv *= sg * (1.f + v * (1.f - sg));
+      }
+      const float mu = mr[((int64_t)s * 32 + gi) * 2], rs = mr[((int64_t)s * 32 + gi) * 2 + 1];
+      const float gc = (film ? 1.f + film[(int64_t)s * film_ld + c] : 1.f) * gamma[c];
+      const float z = (fx[e] - mu) * rs;
+      out[e] = rs * (gc * dv - m12[((int64_t)s * 32 + gi) * 2] - z * m12[((int64_t)s * 32 + gi) * 2 + 1]);
+    }
+    *(u32x4*)(dx + (m * lddx + (int64_t)cvi * EPV) * ES) = Elt<T>::pack(out);
+  }
+}
+
+// ============================================================================= elementwise
+template <typename T>
+__global__ __launch_bounds__(256) void silu_kernel(const char* __restrict__ x, const char* __restrict__ dy, char* __restrict__ out, int64_t nvec) {
+  constexpr int EPV = Elt<T>::EPV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    float f[EPV], d[EPV];
+    Elt<T>::unpack(((const u32x4*)x)[i], f);
+    if (dy) Elt<T>::unpack(((const u32x4*)dy)[i], d);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float sg = 1.f / (1.f + __expf(-f[e]));
+      f[e] = dy ? d[e] * sg * (1.f + f[e] * (1.f - sg)) : f[e] * sg;
+    }
+    ((u32x4*)out)[i] = Elt<T>::pack(f);
+  }
+}
+
+// d loss / d out for loss = sum_n w[n] * mean_n((target - out)^2):  g = 2 (out - target) * w[n] / per
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                       const float* __restrict__ w, float* __restrict__ g, int64_t per, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    g[i] = 2.f * (out[i] - target[i]) * w[i / per] / (float)per;
+}
+
+// AdamW step (torch.optim.AdamW semantics: decoupled weight decay) + optional EMA update (nn.py:128-138)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    float* __restrict__ ema, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2, float ema_rate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float w = p[i] * (1.f - lr * wd);
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = w;
+    if (ema) ema[i] = ema[i] * ema_rate + w * (1.f - ema_rate);
+  }
+}
+
+// ============================================================================= C-ABI
+static inline int ew_grid_b(int64_t total) { return (int)min((int64_t)4096, (total + 255) / 256); }
+
+// dW (fp32 [Cout][ntaps*Cin], caller zeroes it) += dY^T * gather(X); db (nullable, fp32 [Cout], zeroed) += colsum(dY).
+extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, float* db, int M, int Cout,
+                              int Cin, int ntaps, const int* taps, int D0, int D1, int D2, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_wgrad: bad dtype");
+  MMD_REQUIRE(dY && X && dW && taps && M > 0 && ntaps >= 1 && ntaps <= 27, "conv_wgrad: bad argument");
+  MMD_REQUIRE(Cin % epv == 0 && Cout % epv == 0 && lddy % epv == 0 && ldx % epv == 0, "conv_wgrad: channel counts / strides must be 16-byte multiples");
+  MMD_REQUIRE(((uintptr_t)dY | (uintptr_t)X) % 16 == 0, "conv_wgrad: unaligned pointer");
+  WgradParams p;
+  p.dY = (const char*)dY; p.lddy = lddy; p.X = (const char*)X; p.ldx = ldx; p.dW = dW;
+  p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
+  for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
+  const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64) * ntaps;
+  int splits = max(1, min(cdiv(M, 256), 2048 / max(tiles, 1)));
+  p.rows_per_split = cdiv(cdiv(M, splits), 64) * 64;
+  splits = cdiv(M, p.rows_per_split);
+  dim3 grid(cdiv(Cout, 64), cdiv(Cin, 64) * ntaps, splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16) hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, p);
+  int rc = mmd_check_launch("conv_wgrad");
+  if (rc || !db) return rc;
+  MMD_REQUIRE(Cout / epv <= 256, "conv_wgrad: Cout too wide for colsum");
+  const int rpb = 512;
+  if (dtype == MMD_BF16) hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
+  return mmd_check_launch("colsum");
+}
+
+// GroupNorm(+FiLM)(+SiLU) backward.  a, b [S,C] and mr [S,32,2] (mean, rstd) come from the forward mmd_gn_stats.
+// dgamma / dbeta fp32 [C] are ACCUMULATED (caller zeroes); dfilm (nullable) [S, >= 2C] receives (dscale | dshift);
+// workspace: (S*C*2 + S*64) floats, zeroed by this call.
+extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C,
+                          int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
+                          const float* b, const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld,
+                          int act, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "gn_bwd: bad dtype");
+  MMD_REQUIRE(x && dy && dx && a && b && mr && gamma && beta && dgamma && dbeta && workspace, "gn_bwd: null pointer");
+  MMD_REQUIRE(C % 32 == 0 && C % epv == 0 && C / epv <= 256 && C <= 1024, "gn_bwd: unsupported channel count %d", C);
+  GnBwdGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};
+  hipStream_t st = (hipStream_t)stream;
+  float* PQ = workspace;
+  float* m12 = workspace + (int64_t)S * C * 2;
+  if (hipMemsetAsync(PQ, 0, (size_t)S * C * 2 * sizeof(float), st) != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "gn_bwd: memset failed");
+  const int rpp = max(1, 256 / (C / epv));
+  int R = 4 * rpp;
+  while ((int64_t)S * cdiv(Tn, R) > 1280 && R < 1024) R *= 2;
+  dim3 grid(cdiv(Tn, R), S);
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<__bf16>, grid, dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, C, g, a, b, mr, act, R, PQ);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, C, g, a, b, mr, act, R, PQ);
+  int rc = mmd_check_launch("gn_bwd_reduce");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(S), dim3(256), 0, st, (const float*)PQ, C, Tn, gamma, beta, film, film_ld, dgamma, dbeta, dfilm,
+                     dfilm_ld, m12);
+  rc = mmd_check_launch("gn_bwd_params");
+  if (rc) return rc;
+  const int grid3 = ew_grid_b(rows * (C / epv));
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, dim3(grid3), dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, (char*)dx, lddx, rows, C, g,
+                       a, b, mr, (const float*)m12, gamma, film, film_ld, act);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid3), dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, (char*)dx, lddx, rows, C, g,
+                       a, b, mr, (const float*)m12, gamma, film, film_ld, act);
+  return mmd_check_launch("gn_bwd_apply");
+}
+
+// out = silu(x) (dy == NULL) or dy * silu'(x); contiguous buffers of n elements (n % (16/elsize) == 0)
+extern "C" int mmd_silu(int dtype, const void* x, const void* dy, void* out, int64_t n, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE((dtype == MMD_BF16 || dtype == MMD_F32) && x && out && n > 0 && n % epv == 0, "silu: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16) hipLaunchKernelGGL(silu_kernel<__bf16>, dim3(ew_grid_b(n / epv)), dim3(256), 0, st, (const char*)x, (const char*)dy, (char*)out, n / epv);
+  else hipLaunchKernelGGL(silu_kernel<float>, dim3(ew_grid_b(n / epv)), dim3(256), 0, st, (const char*)x, (const char*)dy, (char*)out, n / epv);
+  return mmd_check_launch("silu");
+}
+
+extern "C" int mmd_mse_grad(const float* out, const float* target, const float* w, float* g, int N, int64_t per_sample, void* stream) {
+  MMD_REQUIRE(out && target && w && g && N > 0 && per_sample > 0, "mse_grad: bad argument");
+  const int64_t total = per_sample * N;
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(ew_grid_b(total)), dim3(256), 0, (hipStream_t)stream, out, target, w, g, per_sample, total);
+  return mmd_check_launch("mse_grad");
+}
+
+extern "C" int mmd_adamw_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, float ema_rate, void* stream) {
+  MMD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad argument");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid_b(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, lr, beta1, beta2, eps, weight_decay,
+                     bc1, bc2, ema_rate);
+  return mmd_check_launch("adamw_step");
+}

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 // F=1, H=1, W=L, fw=4.  Geometry given for the INPUT; output dims = in / factor (pool) or in * factor (up).
 template <typename T>
 __global__ __launch_bounds__(256) void resample_kernel(const char* __restrict__ x, int64_t ldx, char* __restrict__ y, int64_t ldy,
-                                                       int C, int NF, int H, int W, int fh, int fw, int mode) {
+                                                       int C, int NF, int H, int W, int fh, int fw, int mode, float scale) {
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
   const int CV = C / EPV;
@@ -97,13 +97,20 @@ __global__ __launch_bounds__(256) void resample_kernel(const char* __restrict__ 
 #pragma unroll
           for (int e = 0; e < EPV; ++e) acc[e] += f[e];
         }
-      const float inv = 1.f / (float)(fh * fw);
+      const float inv = scale / (float)(fh * fw);
 #pragma unroll
       for (int e = 0; e < EPV; ++e) acc[e] *= inv;
       *(u32x4*)(y + (orow * ldy + (int64_t)cv * EPV) * ES) = Elt<T>::pack(acc);
     } else {
       const int64_t irow = (nf * H + ho / fh) * W + wo / fw;
-      *(u32x4*)(y + (orow * ldy + (int64_t)cv * EPV) * ES) = *(const u32x4*)(x + (irow * ldx + (int64_t)cv * EPV) * ES);
+      u32x4 v = *(const u32x4*)(x + (irow * ldx + (int64_t)cv * EPV) * ES);
+      if (scale != 1.f) {
+        Elt<T>::unpack(v, acc);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc[e] *= scale;
+        v = Elt<T>::pack(acc);
+      }
+      *(u32x4*)(y + (orow * ldy + (int64_t)cv * EPV) * ES) = v;
     }
   }
 }
@@ -358,7 +365,7 @@ extern "C" int mmd_linear_fwd(const float* x, const float* W, const float* b, fl
 }
 
 extern "C" int mmd_resample(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int NF, int H, int W, int fh,
-                            int fw, int mode, void* stream) {
+                            int fw, int mode, float scale, void* stream) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "resample: bad dtype");
   MMD_REQUIRE(x && y && C % epv == 0 && NF > 0 && H > 0 && W > 0 && fh > 0 && fw > 0, "resample: bad argument");
@@ -367,9 +374,9 @@ extern "C" int mmd_resample(int dtype, const void* x, int64_t ldx, void* y, int6
   const int grid = ew_grid(orows * (C / epv));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MMD_BF16)
-    hipLaunchKernelGGL(resample_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, NF, H, W, fh, fw, mode);
+    hipLaunchKernelGGL(resample_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, NF, H, W, fh, fw, mode, scale);
   else
-    hipLaunchKernelGGL(resample_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, NF, H, W, fh, fw, mode);
+    hipLaunchKernelGGL(resample_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, NF, H, W, fh, fw, mode, scale);
   return mmd_check_launch("resample");
 }
 
@@ -585,4 +592,28 @@ extern "C" int mmd_loss_terms(const float* x0, const float* xt, const float* mod
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(N), 0, st, (const double*)workspace, MMD_LOSS_CHUNKS,
                      1.0 / ((double)F * C * HW), vb_scale, mse_out, (flags & 4) ? vb_out : nullptr);
   return mmd_check_launch("loss_finalize");
+}
+
+// sinusoidal timestep embedding alone (nn.py:192-210): out[N, dim] fp32 (training path keeps the MLP as separate linears)
+__global__ void timestep_embedding_kernel(const void* __restrict__ t, int t_kind, int dim, float* __restrict__ out) {
+  const int n = blockIdx.x;
+  float tv;
+  if (t_kind == 0) tv = (float)((const int64_t*)t)[n];
+  else if (t_kind == 1) tv = (float)((const int32_t*)t)[n];
+  else tv = ((const float*)t)[n];
+  const int half = dim / 2;
+  for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+    float v = 0.f;
+    if (i < 2 * half) {
+      const int k = i < half ? i : i - half;
+      const float a = tv * expf(-logf(10000.f) * (float)k / (float)half);
+      v = i < half ? cosf(a) : sinf(a);
+    }
+    out[(int64_t)n * dim + i] = v;
+  }
+}
+extern "C" int mmd_timestep_embedding(const void* t, int t_kind, int N, int dim, float* out, void* stream) {
+  MMD_REQUIRE(t && out && N > 0 && dim > 0 && t_kind >= 0 && t_kind <= 2, "timestep_embedding: bad argument");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, t, t_kind, dim, out);
+  return mmd_check_launch("timestep_embedding");
 }

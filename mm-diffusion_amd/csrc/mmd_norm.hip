@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
                                                          double* __restrict__ part, int nchunks,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ film, int64_t film_ld, float eps,
-                                                         float* __restrict__ a_out, float* __restrict__ b_out) {
+                                                         float* __restrict__ a_out, float* __restrict__ b_out, float* __restrict__ mr_out) {
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
   __shared__ float s_sum[256 * EPV];
@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
       if (var < 0.0) var = 0.0;
       s_csum[tid] = piv0 + dm;                         // mean
       s_csq[tid] = 1.0 / sqrt(var + (double)eps);      // rstd
+      if (mr_out) {
+        mr_out[((int64_t)s * GN_GROUPS + tid) * 2] = (float)s_csum[tid];
+        mr_out[((int64_t)s * GN_GROUPS + tid) * 2 + 1] = (float)s_csq[tid];
+      }
     }
   }
   if (ONE) {
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const char* __restrict
                                                           const double* __restrict__ part, int nchunks, int C, int Tn,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ film, int64_t film_ld, float eps,
-                                                          float* __restrict__ a_out, float* __restrict__ b_out) {
+                                                          float* __restrict__ a_out, float* __restrict__ b_out, float* __restrict__ mr_out) {
   __shared__ double s_pa[8][GN_GROUPS], s_pb[8][GN_GROUPS];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -182,6 +186,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const char* __restrict
     if (var < 0.0) var = 0.0;
     s_mean[tid] = (float)(piv + dm);
     s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mr_out) {
+      mr_out[((int64_t)s * GN_GROUPS + tid) * 2] = s_mean[tid];
+      mr_out[((int64_t)s * GN_GROUPS + tid) * 2 + 1] = s_rstd[tid];
+    }
   }
   __syncthreads();
   const int cpg = C / GN_GROUPS;
@@ -274,8 +282,8 @@ extern "C" int64_t mmd_gn_workspace_bytes(int dtype, int C, int S, int Tn) {
 
 extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int inner, int64_t outer_stride,
                             int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta,
-                            const float* film, int64_t film_ld, float eps, float* a_out, float* b_out, void* workspace,
-                            void* stream) {
+                            const float* film, int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out,
+                            void* workspace, void* stream) {
   int rc = check_geom("gn_stats", dtype, C, S, Tn, inner);
   if (rc) return rc;
   MMD_REQUIRE(x && gamma && beta && a_out && b_out, "gn_stats: null pointer");
@@ -287,24 +295,24 @@ extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, 
   if (nchunks == 1) {
     if (dtype == MMD_BF16)
       hipLaunchKernelGGL((gn_partial_kernel<__bf16, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)nullptr, 1,
-                         gamma, beta, film, film_ld, eps, a_out, b_out);
+                         gamma, beta, film, film_ld, eps, a_out, b_out, mr_out);
     else
       hipLaunchKernelGGL((gn_partial_kernel<float, true>), dim3(1, S), dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)nullptr, 1,
-                         gamma, beta, film, film_ld, eps, a_out, b_out);
+                         gamma, beta, film, film_ld, eps, a_out, b_out, mr_out);
     return mmd_check_launch("gn_stats_one");
   }
   MMD_REQUIRE(workspace, "gn_stats: workspace required for multi-block slices");
   dim3 grid(nchunks, S);
   if (dtype == MMD_BF16)
     hipLaunchKernelGGL((gn_partial_kernel<__bf16, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)workspace, nchunks,
-                       gamma, beta, film, film_ld, eps, a_out, b_out);
+                       gamma, beta, film, film_ld, eps, a_out, b_out, (float*)nullptr);
   else
     hipLaunchKernelGGL((gn_partial_kernel<float, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)workspace, nchunks,
-                       gamma, beta, film, film_ld, eps, a_out, b_out);
+                       gamma, beta, film, film_ld, eps, a_out, b_out, (float*)nullptr);
   rc = mmd_check_launch("gn_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(S), dim3(256), 0, st, (const char*)x, dtype, ld, g, (const double*)workspace, nchunks, C, Tn, gamma, beta,
-                     film, film_ld, eps, a_out, b_out);
+                     film, film_ld, eps, a_out, b_out, mr_out);
   return mmd_check_launch("gn_finalize");
 }
 

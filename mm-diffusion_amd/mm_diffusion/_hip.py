@@ -27,20 +27,28 @@ _PROTOS = {
     "mmd_temb_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "mmd_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mmd_gn_workspace_bytes": (i64, [i32, i32, i32, i32]),
-    "mmd_gn_stats": (i32, [i32, vp, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, i64, f32, vp, vp, vp, vp]),
+    "mmd_gn_stats": (i32, [i32, vp, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, i64, f32, vp, vp, vp, vp, vp]),
     "mmd_gn_apply": (i32, [i32, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, i32, vp]),
     "mmd_add_rowbias": (i32, [i32, vp, i64, i64, i32, i64, vp, i64, vp]),
     "mmd_conv_gemm": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_gn_conv1x1": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "mmd_attn_fwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, i64, i32, i64, i32, i32, vp, i32, vp]),
     "mmd_attn_small_fwd": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
-    "mmd_resample": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mmd_resample": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "mmd_copy2d": (i32, [vp, i64, vp, i64, i64, i64, vp]),
     "mmd_stem_conv": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
     "mmd_head_conv": (i32, [i32, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
     "mmd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_loss_workspace_bytes": (i64, [i32]),
     "mmd_loss_terms": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "mmd_conv_wgrad": (i32, [i32, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, vp]),
+    "mmd_gn_bwd": (i32, [i32, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp]),
+    "mmd_attn_bwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32,
+                           i32, i64, i64, i64, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp]),
+    "mmd_timestep_embedding": (i32, [vp, i32, i32, i32, vp, vp]),
+    "mmd_silu": (i32, [i32, vp, vp, vp, i64, vp]),
+    "mmd_mse_grad": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+    "mmd_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "mmd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
 }
 EXPORTS = tuple(_PROTOS)

@@ -106,14 +106,14 @@ def gn_workspace(x, geom: Geom):
     return torch.empty(gn_workspace_bytes(x, geom) // 8, dtype=torch.float64, device=x.device)
 
 
-def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None):
+def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None, mr=None):
     _chk2d(x)
     C = x.shape[1]
     a = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if a is None else a
     b = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if b is None else b
     ws = gn_workspace(x, geom) if ws is None else ws
     _dispatch("mmd_gn_stats", H.dt_of(x), x.data_ptr(), x.stride(0), C, *geom.args(), gamma.data_ptr(), beta.data_ptr(),
-           H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), ws.data_ptr(),
+           H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), H.ptr(mr), ws.data_ptr(),
            meta=(f"gn_stats[S={geom.S},Tn={geom.Tn},C={C}]", 0, geom.S * geom.Tn * C * x.element_size()))
     return a, b
 
@@ -257,11 +257,11 @@ def attn_small(qkv, out, C, heads, geom: Geom):
     return out
 
 
-def resample(x, out, NF, Hh, Ww, fh, fw, mode):
+def resample(x, out, NF, Hh, Ww, fh, fw, mode, scale=1.0):
     """mode 0 avg-pool / 1 nearest-upsample by (1, fh, fw); Hh, Ww describe the input rows (nf, h, w)."""
     _chk2d(x), _chk2d(out)
     _dispatch("mmd_resample", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], NF, Hh, Ww,
-           fh, fw, mode, meta=("resample", 0, (x.shape[0] + out.shape[0]) * x.shape[1] * x.element_size()))
+           fh, fw, mode, float(scale), meta=("resample", 0, (x.shape[0] + out.shape[0]) * x.shape[1] * x.element_size()))
     return out
 
 
@@ -333,6 +333,64 @@ def loss_terms(model_out, target, tables, t, F, C, HW, flags, x0=None, xt=None, 
               tables.shape[1], N, F, C, HW, flags, float(vb_scale), mse.data_ptr(), H.ptr(vb), ws.data_ptr(),
               meta=("loss_terms", 0, 8 * target.numel()))
     return mse, vb
+
+
+# ------------------------------------------------------------------ training step (backward) wrappers
+def conv_wgrad(dy, x, dW, db, taps, dims):
+    """dW fp32 [Cout, ntaps*Cin] += dy^T gather(x); db fp32 [Cout] += colsum(dy)  (both pre-zeroed by the caller)."""
+    _chk2d(dy), _chk2d(x)
+    arr, nt = H.taps_array(taps)
+    _dispatch("mmd_conv_wgrad", H.dt_of(x), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), H.ptr(db),
+              dy.shape[0], dy.shape[1], x.shape[1], nt, arr, int(dims[0]), int(dims[1]), int(dims[2]),
+              meta=("conv_wgrad", 2 * dy.shape[0] * dy.shape[1] * x.shape[1] * nt, 0))
+
+
+def gn_bwd(x, dy, dx, geom: Geom, a, b, mr, gamma, beta, film, act, dgamma, dbeta, dfilm):
+    _chk2d(x), _chk2d(dy), _chk2d(dx)
+    C = x.shape[1]
+    ws = torch.empty(geom.S * C * 2 + geom.S * 64, dtype=torch.float32, device=x.device)
+    _dispatch("mmd_gn_bwd", H.dt_of(x), x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), dx.data_ptr(), dx.stride(0),
+              x.shape[0], C, *geom.args(), a.data_ptr(), b.data_ptr(), mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              H.ptr(film), 0 if film is None else film.stride(0), 1 if act else 0, dgamma.data_ptr(), dbeta.data_ptr(),
+              H.ptr(dfilm), 0 if dfilm is None else dfilm.stride(0), ws.data_ptr(), meta=("gn_bwd", 0, 3 * x.numel() * x.element_size()))
+
+
+def attn_bwd(q, q_off, kv, k_off, v_off, o, do, dq, dq_off, dkv, dk_off, dv_off, heads, ch, nb, G, qgeo, q_total, q_per_group,
+             kgeo, k_mod, k_per_group, win, shift_dev):
+    """See include/mmd.h: mmd_attn_bwd.  qgeo / kgeo = (inner, outer_stride, inner_stride, tstride) of the unit bases."""
+    for t in (q, kv, o, do, dq, dkv):
+        _chk2d(t)
+    lse = torch.empty(q.shape[0] * heads, dtype=torch.float32, device=q.device)
+    dsum = torch.empty(q.shape[0] * heads, dtype=torch.float32, device=q.device)
+    _dispatch("mmd_attn_bwd", H.dt_of(q), q.data_ptr(), q.stride(0), q_off, kv.data_ptr(), kv.stride(0), k_off, v_off,
+              o.data_ptr(), o.stride(0), do.data_ptr(), do.stride(0), dq.data_ptr(), dq.stride(0), dq_off, dkv.data_ptr(),
+              dkv.stride(0), dk_off, dv_off, lse.data_ptr(), dsum.data_ptr(), heads, ch, nb, G, *[int(v) for v in qgeo], q_total,
+              q_per_group, *[int(v) for v in kgeo], k_mod, k_per_group, win, H.ptr(shift_dev),
+              meta=("attn_bwd", 10 * nb * q_total * win * k_per_group * heads * ch, 0))
+
+
+def silu(x, dy, out):
+    _dispatch("mmd_silu", H.dt_of(x), x.data_ptr(), H.ptr(dy), out.data_ptr(), x.numel(), meta=("silu", 0, 2 * x.numel() * x.element_size()))
+    return out
+
+
+def mse_grad(out, target, w, g):
+    _dispatch("mmd_mse_grad", out.data_ptr(), target.data_ptr(), w.data_ptr(), g.data_ptr(), out.shape[0], out[0].numel(),
+              meta=("mse_grad", 0, 12 * out.numel()))
+    return g
+
+
+def adamw_step(p, g, m, v, ema, lr, beta1, beta2, eps, weight_decay, step, ema_rate=0.0):
+    _dispatch("mmd_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), H.ptr(ema), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), float(weight_decay), int(step), float(ema_rate), meta=("adamw", 0, 28 * p.numel()))
+
+
+def timestep_embedding(t, dim, out):
+    kind = {torch.int64: 0, torch.int32: 1, torch.float32: 2}.get(t.dtype)
+    if kind is None:
+        raise H.MMDError(f"timesteps must be int64/int32/float32, got {t.dtype}")
+    _dispatch("mmd_timestep_embedding", t.data_ptr(), kind, t.shape[0], dim, out.data_ptr())
+    return out
 
 
 def pack_conv_weight(w: torch.Tensor, dtype) -> torch.Tensor:

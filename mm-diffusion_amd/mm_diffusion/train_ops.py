@@ -1,0 +1,246 @@
+"""Differentiable wrappers (torch.autograd.Function) of the libmmd ops for the training step.
+
+torch's autograd engine only ORDERS the backward calls and accumulates gradients at fan-out points; every forward
+and backward computation is a libmmd kernel (mmd_conv_gemm / mmd_conv_wgrad / mmd_gn_bwd / mmd_attn_bwd / ...).
+Activations are channels-last rows [rows, C] as in the inference engine; parameters stay in the reference layouts so
+their .grad lands on the nn.Parameters the optimizer / DDP see.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _hip as H
+from . import ops
+from .ops import Geom
+
+
+def _neg(taps):
+    return [(-a, -b, -c) for a, b, c in taps]
+
+
+class ConvFn(Function):
+    """Y = conv(X) (+ R): implicit-GEMM forward, dgrad = same kernel on the transposed weight with mirrored taps,
+    wgrad/bias grad = mmd_conv_wgrad.  weight in torch conv layout [Cout, Cin, *k]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, taps, dims):
+        x = x.contiguous() if x.stride(1) != 1 else x
+        wp = ops.pack_conv_weight(weight.detach().float(), x.dtype)
+        y = ops.conv_gemm(x, wp, bias.detach().float().contiguous(), taps=taps, dims=dims,
+                          residual=None if residual is None else residual)
+        ctx.save_for_backward(x, weight)
+        ctx.taps, ctx.dims, ctx.has_res = taps, dims, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        taps, dims = ctx.taps, ctx.dims
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        nt = len(taps)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().float().reshape(Cout, Cin, nt).permute(1, 2, 0).reshape(Cin, nt * Cout).to(x.dtype).contiguous()
+            dx = ops.conv_gemm(dy, wt, None, taps=_neg(taps), dims=dims)
+        dW32 = torch.zeros(Cout, nt * Cin, dtype=torch.float32, device=x.device)
+        db32 = torch.zeros(Cout, dtype=torch.float32, device=x.device)
+        ops.conv_wgrad(dy, x, dW32, db32, taps, dims)
+        dW = dW32.reshape(Cout, nt, Cin).permute(0, 2, 1).reshape(weight.shape).to(weight.dtype)
+        return dx, dW, db32.to(weight.dtype), (dy if ctx.has_res else None), None, None
+
+
+def conv(x, weight, bias, taps=ops.TAPS_1, dims=(1, 1, 1), residual=None):
+    return ConvFn.apply(x, weight, bias, residual, taps, dims)
+
+
+class GroupNormFn(Function):
+    """y = act(GroupNorm32(x) [* (1 + scale) + shift]) on slices `geom`; film = [S, 2C] (scale | shift) or None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, film, geom, act):
+        x = x.contiguous() if x.stride(1) != 1 else x
+        C = x.shape[1]
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        f32 = None if film is None else film.detach().float()
+        mr = torch.empty(geom.S, 32, 2, dtype=torch.float32, device=x.device)
+        a, b = ops.gn_stats(x, g32, b32, geom, film=f32, mr=mr)
+        y = ops.gn_apply(x, a, b, geom, act=act)
+        ctx.save_for_backward(x, a, b, mr, g32, b32, f32 if f32 is not None else torch.empty(0, device=x.device))
+        ctx.geom, ctx.act, ctx.has_film = geom, act, film is not None
+        ctx.film_shape = None if film is None else tuple(film.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a, b, mr, g32, b32, f32 = ctx.saved_tensors
+        geom = ctx.geom
+        dy = dy.contiguous()
+        C = x.shape[1]
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros(C, dtype=torch.float32, device=x.device)
+        dfilm = torch.empty(geom.S, 2 * C, dtype=torch.float32, device=x.device) if ctx.has_film else None
+        ops.gn_bwd(x, dy, dx, geom, a, b, mr, g32, b32, f32 if ctx.has_film else None, ctx.act, dgamma, dbeta, dfilm)
+        return dx, dgamma, dbeta, dfilm, None, None
+
+
+def group_norm(x, gamma, beta, geom, act, film=None):
+    return GroupNormFn.apply(x, gamma, beta, film, geom, act)
+
+
+class SelfAttnFn(Function):
+    """softmax(q k^T / sqrt(ch)) v on qkv rows [rows, 3C]; kind: 'spatial' (units = (n, f), T = HW), 'temporal'
+    (units = (n, pixel), rows strided by HW, T = F) or 'audio' (units = n)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, kind, N, F, HW):
+        qkv = qkv.contiguous()
+        rows, C3 = qkv.shape
+        C = C3 // 3
+        out = torch.empty(rows, C, dtype=qkv.dtype, device=qkv.device)
+        if kind == "temporal":
+            ops.attn_small(qkv, out, C, heads, Geom.temporal(N, F, HW))
+            desc = dict(nb=N * HW, inner=HW, outer=F * HW, istride=1, tstride=HW, T=F)
+        else:
+            T = HW if kind == "spatial" else rows // N
+            nb = N * F if kind == "spatial" else N
+            ops.attn(qkv, qkv, out, heads, C // heads, nb, 1, T, T, T, T, 1)
+            desc = dict(nb=nb, inner=1, outer=T, istride=1, tstride=1, T=T)
+        ctx.save_for_backward(qkv, out)
+        ctx.heads, ctx.desc = heads, desc
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out = ctx.saved_tensors
+        d, heads = ctx.desc, ctx.heads
+        C = out.shape[1]
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv, 0, qkv, C, 2 * C, out, dout.contiguous(), dqkv, 0, dqkv, C, 2 * C, heads, C // heads, d["nb"], 1,
+                     (d["inner"], d["outer"], d["istride"], d["tstride"]), d["T"], d["T"],
+                     (d["inner"], d["outer"], d["istride"], d["tstride"]), d["T"], d["T"], 1, None)
+        return dqkv, None, None, None, None, None
+
+
+class CrossAttnFn(Function):
+    """Random-shift windowed cross-modal attention, both directions (reference unit QKVAttention.forward):
+    video queries attend the audio window, audio queries the video window.  shift: python int (this call's draw)."""
+
+    @staticmethod
+    def forward(ctx, vqkv, aqkv, heads, N, F, HW, L, win, shift):
+        vqkv, aqkv = vqkv.contiguous(), aqkv.contiguous()
+        C = vqkv.shape[1] // 3
+        apf = int(L / F)
+        sh = torch.tensor([shift], dtype=torch.int32, device=vqkv.device)
+        vatt = torch.empty(N * F * HW, C, dtype=vqkv.dtype, device=vqkv.device)
+        aatt = torch.empty(N * L, C, dtype=vqkv.dtype, device=vqkv.device)
+        ops.attn(vqkv, aqkv, vatt, heads, C // heads, N, F, F * HW, HW, L, apf, win, shift_dev=sh)
+        ops.attn(aqkv, vqkv, aatt, heads, C // heads, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
+        ctx.save_for_backward(vqkv, aqkv, vatt, aatt, sh)
+        ctx.cfg = (heads, N, F, HW, L, apf, win)
+        return vatt, aatt
+
+    @staticmethod
+    def backward(ctx, dvatt, daatt):
+        vqkv, aqkv, vatt, aatt, sh = ctx.saved_tensors
+        heads, N, F, HW, L, apf, win = ctx.cfg
+        C = vatt.shape[1]
+        dv, da = torch.empty_like(vqkv), torch.empty_like(aqkv)
+        vgeo, ageo = (1, F * HW, 1, 1), (1, L, 1, 1)
+        # video queries <- audio keys: dQ -> dv[:, :C], dK/dV -> da[:, C:]
+        ops.attn_bwd(vqkv, 0, aqkv, C, 2 * C, vatt, dvatt.contiguous(), dv, 0, da, C, 2 * C, heads, C // heads, N, F,
+                     vgeo, F * HW, HW, ageo, L, apf, win, sh)
+        # audio queries <- video keys: dQ -> da[:, :C], dK/dV -> dv[:, C:]
+        ops.attn_bwd(aqkv, 0, vqkv, C, 2 * C, aatt, daatt.contiguous(), da, 0, dv, C, 2 * C, heads, C // heads, N, F,
+                     ageo, L, apf, vgeo, F * HW, HW, win, sh)
+        return dv, da, None, None, None, None, None, None, None
+
+
+class ResampleFn(Function):
+    """avg-pool (mode 0) / nearest upsample (mode 1) by (1, fh, fw); the backward of one is the other, rescaled."""
+
+    @staticmethod
+    def forward(ctx, x, NF, Hh, Ww, fh, fw, mode):
+        x = x.contiguous() if x.stride(1) != 1 else x
+        rows = NF * (Hh // fh) * (Ww // fw) if mode == 0 else NF * Hh * fh * Ww * fw
+        y = torch.empty(rows, x.shape[1], dtype=x.dtype, device=x.device)
+        ops.resample(x, y, NF, Hh, Ww, fh, fw, mode)
+        ctx.cfg = (NF, Hh, Ww, fh, fw, mode, x.shape[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        NF, Hh, Ww, fh, fw, mode, rows_in = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty(rows_in, dy.shape[1], dtype=dy.dtype, device=dy.device)
+        if mode == 0:      # d avg-pool = nearest upsample / (fh*fw)
+            ops.resample(dy, dx, NF, Hh // fh, Ww // fw, fh, fw, 1, scale=1.0 / (fh * fw))
+        else:              # d nearest-upsample = sum over the replicated cells = avg-pool * (fh*fw)
+            ops.resample(dy, dx, NF, Hh * fh, Ww * fw, fh, fw, 0, scale=float(fh * fw))
+        return dx, None, None, None, None, None, None
+
+
+class LinearFn(Function):
+    """fp32 y = x W^T + b (emb layers / time_embed); backward through the same small kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.float().contiguous()
+        y = torch.empty(x.shape[0], weight.shape[0], dtype=torch.float32, device=x.device)
+        ops.linear(x, weight.detach().float().contiguous(), bias.detach().float().contiguous(), y)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        J, K = weight.shape
+        dx = torch.empty_like(x)
+        ops.linear(dy, weight.detach().float().t().contiguous(), None, dx)
+        dW = torch.zeros(J, K, dtype=torch.float32, device=x.device)
+        db = torch.zeros(J, dtype=torch.float32, device=x.device)
+        Jp = (J + 3) // 4 * 4
+        for j0 in range(0, J, 1024):        # column sums handle <= 1024 channels per call
+            j1 = min(j0 + 1024, J)
+            ops.conv_wgrad(dy[:, j0:j1].contiguous(), x, dW[j0:j1], db[j0:j1], ops.TAPS_1, (1, 1, 1))
+        return dx, dW.to(weight.dtype), db.to(weight.dtype)
+
+
+class SiluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ops.silu(x, None, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        ops.silu(x, dy.contiguous(), dx)
+        return dx
+
+
+class MseLossFn(Function):
+    """per-sample mean((target - out)^2) on API-layout fp32 tensors; grad = 2 (out - target) / per * dloss[n]."""
+
+    @staticmethod
+    def forward(ctx, out, target):
+        out, target = out.float().contiguous(), target.float().contiguous()
+        N = out.shape[0]
+        per = out[0].numel()
+        dummy = torch.zeros(7, 1, dtype=torch.float32, device=out.device)
+        mse, _ = ops.loss_terms(out.reshape(N, 1, 1, per), target.reshape(N, 1, 1, per), dummy,
+                                torch.zeros(N, dtype=torch.int64, device=out.device), 1, 1, per, 0)
+        ctx.save_for_backward(out, target)
+        return mse
+
+    @staticmethod
+    def backward(ctx, dloss):
+        out, target = ctx.saved_tensors
+        g = torch.empty_like(out)
+        ops.mse_grad(out, target, dloss.float().contiguous(), g)
+        return g, None
