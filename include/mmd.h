@@ -159,6 +159,7 @@ int mmd_attn_bwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* K
 /* out = silu(x) (dy NULL) or dy*silu'(x); d(mse loss)/d(out); AdamW (+EMA, nn.py:128-138) on flat fp32 buffers. */
 int mmd_timestep_embedding(const void* t, int t_kind, int N, int dim, float* out, void* stream);   /* nn.py:192-210 */
 int mmd_silu(int dtype, const void* x, const void* dy, void* out, int64_t n, void* stream);
+int mmd_dropout(int dtype, const void* x, const uint8_t* mask, float scale, void* out, int64_t n, void* stream);   /* nn.Dropout, unet:376 */
 int mmd_mse_grad(const float* out, const float* target, const float* w, float* g, int N, int64_t per_sample, void* stream);
 int mmd_adamw_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float ema_rate, void* stream);

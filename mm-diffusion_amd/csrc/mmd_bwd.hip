@@ -284,6 +284,20 @@ __global__ __launch_bounds__(256) void silu_kernel(const char* __restrict__ x, c
   }
 }
 
+// inverted dropout: out = x * mask * scale (mask bytes 0/1, drawn by the caller); the backward is the same kernel on dy
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const char* __restrict__ x, const uint8_t* __restrict__ mask, float scale,
+                                                      char* __restrict__ out, int64_t nvec) {
+  constexpr int EPV = Elt<T>::EPV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    float f[EPV];
+    Elt<T>::unpack(((const u32x4*)x)[i], f);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) f[e] = mask[i * EPV + e] ? f[e] * scale : 0.f;
+    ((u32x4*)out)[i] = Elt<T>::pack(f);
+  }
+}
+
 // d loss / d out for loss = sum_n w[n] * mean_n((target - out)^2):  g = 2 (out - target) * w[n] / per
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ out, const float* __restrict__ target,
                                                        const float* __restrict__ w, float* __restrict__ g, int64_t per, int64_t total) {
@@ -388,6 +402,15 @@ extern "C" int mmd_silu(int dtype, const void* x, const void* dy, void* out, int
   if (dtype == MMD_BF16) hipLaunchKernelGGL(silu_kernel<__bf16>, dim3(ew_grid_b(n / epv)), dim3(256), 0, st, (const char*)x, (const char*)dy, (char*)out, n / epv);
   else hipLaunchKernelGGL(silu_kernel<float>, dim3(ew_grid_b(n / epv)), dim3(256), 0, st, (const char*)x, (const char*)dy, (char*)out, n / epv);
   return mmd_check_launch("silu");
+}
+
+extern "C" int mmd_dropout(int dtype, const void* x, const uint8_t* mask, float scale, void* out, int64_t n, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4;
+  MMD_REQUIRE((dtype == MMD_BF16 || dtype == MMD_F32) && x && mask && out && n > 0 && n % epv == 0, "dropout: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16) hipLaunchKernelGGL(dropout_kernel<__bf16>, dim3(ew_grid_b(n / epv)), dim3(256), 0, st, (const char*)x, mask, scale, (char*)out, n / epv);
+  else hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_grid_b(n / epv)), dim3(256), 0, st, (const char*)x, mask, scale, (char*)out, n / epv);
+  return mmd_check_launch("dropout");
 }
 
 extern "C" int mmd_mse_grad(const float* out, const float* target, const float* w, float* g, int N, int64_t per_sample, void* stream) {

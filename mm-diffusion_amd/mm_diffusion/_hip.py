@@ -47,6 +47,7 @@ _PROTOS = {
                            i32, i64, i64, i64, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp]),
     "mmd_timestep_embedding": (i32, [vp, i32, i32, i32, vp, vp]),
     "mmd_silu": (i32, [i32, vp, vp, vp, i64, vp]),
+    "mmd_dropout": (i32, [i32, vp, vp, f32, vp, i64, vp]),
     "mmd_mse_grad": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "mmd_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "mmd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),

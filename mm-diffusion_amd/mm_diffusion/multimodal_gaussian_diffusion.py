@@ -260,6 +260,15 @@ class GaussianDiffusion:
         tgt = x_start if self.model_mean_type == ModelMeanType.START_X else noise
         t64 = t.to(th.int64).contiguous()
         term = {}
+        if th.is_grad_enabled() and (video_output.requires_grad or audio_output.requires_grad):
+            # differentiable loss: per-sample mse with its gradient kernel (the vb term's backward is not built yet)
+            if learned:
+                raise NotImplementedError("gradients of the learned-sigma vb term are not built yet; train with learn_sigma=False")
+            from .train_ops import MseLossFn
+            term["mse_video"] = MseLossFn.apply(video_output, tgt["video"])
+            term["mse_audio"] = MseLossFn.apply(audio_output, tgt["audio"])
+            term["loss"] = term["mse_video"] + term["mse_audio"]
+            return term
         for key, mo in (("video", video_output), ("audio", audio_output)):
             F, C, HW = _geom(xt[key])
             mse, vb = ops.loss_terms(mo.float().contiguous(), tgt[key].float().contiguous(), tab, t64, F, C, HW, flags,

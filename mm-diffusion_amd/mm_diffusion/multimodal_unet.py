@@ -314,10 +314,11 @@ class MultimodalUNet(nn.Module):
             raise MMDError("MultimodalUNet runs on the MI355X HIP path only: move the model and inputs to the GPU "
                            "(there is no CPU/torch fallback; the CPU restatement lives in oracle/ for tests)")
         if torch.is_grad_enabled() and (video.requires_grad or audio.requires_grad or
-                                        (self.training and any(p.requires_grad for p in self.parameters()))):
-            raise NotImplementedError("backward kernels are not built yet (SURVEY.md section 8 row cfg4, 'next'): "
-                                      "call the model under torch.no_grad() / model.eval()")
+                                        any(p.requires_grad for p in self.parameters())):
+            # differentiable path: eager walk over autograd Functions whose forward AND backward are libmmd kernels
+            from .train_forward import train_forward
+            return train_forward(self, video, audio, timesteps)
         if self.training and self.dropout > 0:
-            raise NotImplementedError("training-mode dropout is not built yet; call model.eval()")
+            raise NotImplementedError("dropout needs the differentiable path (call with grad enabled) or model.eval()")
         eng = self.engine(video.shape[0], video.device)
         return eng.forward(video, audio, timesteps, self.draw_shifts())

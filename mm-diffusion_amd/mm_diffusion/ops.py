@@ -374,6 +374,12 @@ def silu(x, dy, out):
     return out
 
 
+def dropout(x, mask, scale, out):
+    _dispatch("mmd_dropout", H.dt_of(x), x.data_ptr(), mask.data_ptr(), float(scale), out.data_ptr(), x.numel(),
+              meta=("dropout", 0, 2 * x.numel() * x.element_size()))
+    return out
+
+
 def mse_grad(out, target, w, g):
     _dispatch("mmd_mse_grad", out.data_ptr(), target.data_ptr(), w.data_ptr(), g.data_ptr(), out.shape[0], out[0].numel(),
               meta=("mse_grad", 0, 12 * out.numel()))

@@ -244,3 +244,47 @@ class MseLossFn(Function):
         g = torch.empty_like(out)
         ops.mse_grad(out, target, dloss.float().contiguous(), g)
         return g, None
+
+
+class DropoutFn(Function):
+    """nn.Dropout(p) (reference unet:376,384): the Bernoulli mask is drawn by torch's generator (noise input), the scaling
+    runs in libmmd; backward re-applies the same mask."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        mask = (torch.rand(x.shape, device=x.device) >= p).to(torch.uint8)
+        y = torch.empty_like(x)
+        ops.dropout(x, mask, 1.0 / (1.0 - p), y)
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dx = torch.empty_like(dy)
+        ops.dropout(dy.contiguous(), mask, 1.0 / (1.0 - ctx.p), dx)
+        return dx, None
+
+
+class RecomputeFn(Function):
+    """Activation recompute with the reference's semantics (nn.py:233-279): forward under no_grad, backward re-runs
+    `run` (which re-draws the cross-attention window shift, quirk Q3) and differentiates the recomputed graph."""
+
+    @staticmethod
+    def forward(ctx, run, n_in, *args):
+        ctx.run = run
+        ctx.inputs = list(args[:n_in])
+        ctx.params = list(args[n_in:])
+        with torch.no_grad():
+            out = run(*ctx.inputs)
+        return out
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ins = [x.detach().requires_grad_(True) for x in ctx.inputs]
+        with torch.enable_grad():
+            outs = ctx.run(*ins)
+        grads = torch.autograd.grad(outs, ins + ctx.params, gouts, allow_unused=True)
+        return (None, None) + grads
