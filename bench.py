@@ -129,6 +129,69 @@ def cpu_baseline(fl, seconds_budget=30.0):
             "sample": f"{n} p_sample step(s) of the Landscape base model at batch 1, fp32, oracle/unet_ref.py on {cores} host threads ({dt:.1f} s)"}
 
 
+def train_bench(args, world, rank, device):
+    """BASELINE configs[3]: multimodal_training_losses step (forward + backward + flat AdamW/EMA, gradient all-reduce when
+    world > 1) of the AIST++/Landscape base model, per-GPU batch --batch, bf16 activations, dropout 0.1, t ~ U{0..999}."""
+    import random
+    import torch.distributed as dist
+    from mm_diffusion import logger, multimodal_script_util as msu
+    from mm_diffusion.optim import FlatAdamW
+    from mm_diffusion.synth import synth_init_
+    logger.set_quiet(True)
+    fl = msu.model_and_diffusion_defaults()
+    fl.update(FULL)
+    fl.update(use_fp16=(args.dtype == "bf16"), dropout=0.1)
+    model, diff = msu.create_model_and_diffusion(**fl)
+    synth_init_(model)
+    model.to(device).train()
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0, ema_rates=[0.9999])
+    g = torch.Generator().manual_seed(4321 + rank)
+    random.seed(4321 + rank)
+    torch.manual_seed(4321 + rank)
+    B = args.batch
+    x0 = {"video": (torch.rand(B, *fl["video_size"], generator=g) * 2 - 1).to(device),
+          "audio": (torch.rand(B, *fl["audio_size"], generator=g) * 2 - 1).to(device)}
+
+    def one_step():
+        t = torch.randint(0, diff.num_timesteps, (B,), generator=g).to(device)
+        opt.zero_grad()
+        loss = diff.multimodal_training_losses(model, x0, t)["loss"].mean()
+        loss.backward()
+        opt.all_reduce_grads()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training steps/sec (multimodal_training_losses fwd+bwd+AdamW, video+audio pairs)", "value": args.steps * B * world / elapsed,
+            "unit": "pair-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: base model training step, per-GPU batch {B}, dropout 0.1, flat-buffer gradient all-reduce",
+                       "global_batch": B * world, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9},
+            "model_tflops": 3 * MODEL_FLOPS_PER_PAIR * B * args.steps / elapsed / 1e12}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +200,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]: 4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--respacing", default="250")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"], help="sample = headline DDPM step (default); train = configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-out", default="")
@@ -152,6 +216,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
     device = dist_util.dev()
+    if args.mode == "train":
+        return train_bench(args, world, rank, device)
 
     fl, model, diff = build(args.dtype, args.respacing, args.batch, device)
     from mm_diffusion.sampler import GraphStepper

@@ -156,6 +156,16 @@ int mmd_attn_bwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* K
                  int dv_off, float* lse_ws, float* dsum_ws, int heads, int ch, int nb, int G, int q_inner, int64_t q_outer,
                  int64_t q_istride, int64_t q_tstride, int q_total, int q_per_group, int k_inner, int64_t k_outer, int64_t k_istride,
                  int64_t k_tstride, int k_mod, int k_per_group, int win, const int* shift_dev, void* stream);
+/* bf16 MFMA pair for contiguous-row attention: the training forward also returns the log2-domain log-sum-exp per (query
+ * row, head); the backward recomputes P from it (no stored probabilities).  Same row / window arguments as mmd_attn_fwd. */
+int mmd_attn_fwd_lse(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off, int v_off, void* O,
+                     int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch, int q_per_group,
+                     int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev, float* lse2_out, void* stream);
+int mmd_attn_bwd_mfma(const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off, int v_off, const void* O,
+                      int64_t ldo, const void* dO, int64_t lddo, void* dQ, int64_t lddq, int dq_off, void* dKV, int64_t lddkv,
+                      int dk_off, int dv_off, const float* lse2, float* dsum_ws, int heads, int ch, int nb, int G,
+                      int64_t q_rows_per_batch, int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win,
+                      const int* shift_dev, void* stream);
 /* out = silu(x) (dy NULL) or dy*silu'(x); d(mse loss)/d(out); AdamW (+EMA, nn.py:128-138) on flat fp32 buffers. */
 int mmd_timestep_embedding(const void* t, int t_kind, int N, int dim, float* out, void* stream);   /* nn.py:192-210 */
 int mmd_silu(int dtype, const void* x, const void* dy, void* out, int64_t n, void* stream);

@@ -32,6 +32,7 @@ struct AttnParams {
   int k_per_group, win;
   const int* shift_ptr;
   float scale;                // ch^-1/2  (= (ch^-1/4)^2, reference scales q and k separately)
+  float* lse2;                // optional [q rows, heads]: log2-domain log-sum-exp of scale*log2e*scores (training forward)
 };
 
 struct GroupInfo {
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
   // ---- normalise and store: lane owns query qi, d = 32*dt + (r&3) + 8*(r>>2) + 4*half
   if (qok) {
     const float inv = 1.f / l_run;
+    if (p.lse2 && half == 0) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);   // v_log_f32 = log2
     char* op = p.O + ((gi.q_row0 + qi) * p.ldo + h * D) * 2;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -578,11 +580,10 @@ static int launch_generic(const AttnParams& p, int qmax, hipStream_t st) {
   return mmd_check_launch("attn_generic");
 }
 
-// impl: 0 = auto (MFMA when dtype is bf16 and ch is supported), 1 = force generic VALU kernel
-extern "C" int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off,
-                            int v_off, void* O, int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch,
-                            int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev,
-                            int impl, void* stream) {
+static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off,
+                         int v_off, void* O, int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch,
+                         int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev,
+                         int impl, float* lse2_out, void* stream) {
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "attn_fwd: bad dtype %d", dtype);
   MMD_REQUIRE(Q && KV && O, "attn_fwd: null pointer");
   MMD_REQUIRE(heads > 0 && ch > 0 && ch <= 128 && nb > 0 && G > 0, "attn_fwd: bad heads/ch/nb/G (%d,%d,%d,%d)", heads, ch, nb, G);
@@ -594,6 +595,7 @@ extern "C" int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, co
   p.q_rows_per_batch = q_rows_per_batch; p.q_per_group = q_per_group; p.k_rows_per_batch = k_rows_per_batch;
   p.k_per_group = k_per_group; p.win = win; p.shift_ptr = shift_dev;
   p.scale = 1.0f / sqrtf((float)ch);
+  p.lse2 = lse2_out;
   const int qmax = (int)(q_rows_per_batch - (int64_t)(G - 1) * q_per_group);   // last group is the largest
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 &&
@@ -609,8 +611,29 @@ extern "C" int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, co
       default: break;
     }
   }
+  if (lse2_out) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd_lse: needs the bf16 MFMA path (ch in {16,32,48,64,96,128}, aligned rows)");
   if (dtype == MMD_BF16) return launch_generic<__bf16>(p, qmax, st);
   return launch_generic<float>(p, qmax, st);
+}
+
+// impl: 0 = auto (MFMA when dtype is bf16 and ch is supported), 1 = force generic VALU kernel
+extern "C" int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off,
+                            int v_off, void* O, int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch,
+                            int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev,
+                            int impl, void* stream) {
+  return attn_fwd_impl(dtype, Q, ldq, q_off, KV, ldkv, k_off, v_off, O, ldo, heads, ch, nb, G, q_rows_per_batch, q_per_group,
+                       k_rows_per_batch, k_per_group, win, shift_dev, impl, nullptr, stream);
+}
+
+// Training forward (bf16 MFMA path only): as mmd_attn_fwd, plus lse2_out [q rows, heads] = log2-domain log-sum-exp of
+// (scale * log2 e * q.k) per query row, consumed by mmd_attn_bwd_mfma.
+extern "C" int mmd_attn_fwd_lse(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off,
+                                int v_off, void* O, int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch,
+                                int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev,
+                                float* lse2_out, void* stream) {
+  MMD_REQUIRE(lse2_out, "attn_fwd_lse: null lse buffer");
+  return attn_fwd_impl(dtype, Q, ldq, q_off, KV, ldkv, k_off, v_off, O, ldo, heads, ch, nb, G, q_rows_per_batch, q_per_group,
+                       k_rows_per_batch, k_per_group, win, shift_dev, 0, lse2_out, stream);
 }
 
 template <typename T, int CHQ>

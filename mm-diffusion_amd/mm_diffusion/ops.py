@@ -369,6 +369,35 @@ def attn_bwd(q, q_off, kv, k_off, v_off, o, do, dq, dq_off, dkv, dk_off, dv_off,
               meta=("attn_bwd", 10 * nb * q_total * win * k_per_group * heads * ch, 0))
 
 
+MFMA_HEADS = (16, 32, 48, 64, 96, 128)
+
+
+def attn_mfma_ok(t, ch):
+    return t.dtype == torch.bfloat16 and ch in MFMA_HEADS and t.stride(0) % 8 == 0
+
+
+def attn_lse(q, kv, out, lse, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group, win, shift_dev=None):
+    """bf16 MFMA forward that also returns the per-(row, head) log2-domain log-sum-exp (training forward)."""
+    _chk2d(q), _chk2d(kv), _chk2d(out)
+    C = heads * ch
+    _dispatch("mmd_attn_fwd_lse", H.dt_of(q), q.data_ptr(), q.stride(0), 0, kv.data_ptr(), kv.stride(0), C, 2 * C, out.data_ptr(),
+              out.stride(0), heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group, win, H.ptr(shift_dev),
+              lse.data_ptr(), meta=("attn_fwd_lse", 4 * nb * q_rows_per_batch * win * k_per_group * C, 0))
+    return out
+
+
+def attn_bwd_mfma(q, kv, o, do, dq, dq_off, dkv, dk_off, dv_off, lse, heads, ch, nb, G, q_rows_per_batch, q_per_group,
+                  k_rows_per_batch, k_per_group, win, shift_dev=None):
+    for t in (q, kv, o, do, dq, dkv):
+        _chk2d(t)
+    C = heads * ch
+    dsum = torch.empty(q.shape[0] * heads, dtype=torch.float32, device=q.device)
+    _dispatch("mmd_attn_bwd_mfma", q.data_ptr(), q.stride(0), 0, kv.data_ptr(), kv.stride(0), C, 2 * C, o.data_ptr(), o.stride(0),
+              do.data_ptr(), do.stride(0), dq.data_ptr(), dq.stride(0), dq_off, dkv.data_ptr(), dkv.stride(0), dk_off, dv_off,
+              lse.data_ptr(), dsum.data_ptr(), heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group, win,
+              H.ptr(shift_dev), meta=("attn_bwd_mfma", 10 * nb * q_rows_per_batch * win * k_per_group * C, 0))
+
+
 def silu(x, dy, out):
     _dispatch("mmd_silu", H.dt_of(x), x.data_ptr(), H.ptr(dy), out.data_ptr(), x.numel(), meta=("silu", 0, 2 * x.numel() * x.element_size()))
     return out

@@ -104,16 +104,29 @@ class SelfAttnFn(Function):
         else:
             T = HW if kind == "spatial" else rows // N
             nb = N * F if kind == "spatial" else N
-            ops.attn(qkv, qkv, out, heads, C // heads, nb, 1, T, T, T, T, 1)
             desc = dict(nb=nb, inner=1, outer=T, istride=1, tstride=1, T=T)
+            if ops.attn_mfma_ok(qkv, C // heads):      # bf16: MFMA forward (+ log-sum-exp) and MFMA backward
+                lse = torch.empty(rows * heads, dtype=torch.float32, device=qkv.device)
+                ops.attn_lse(qkv, qkv, out, lse, heads, C // heads, nb, 1, T, T, T, T, 1)
+                ctx.save_for_backward(qkv, out, lse)
+                ctx.heads, ctx.desc, ctx.mfma = heads, desc, True
+                return out
+            ops.attn(qkv, qkv, out, heads, C // heads, nb, 1, T, T, T, T, 1)
         ctx.save_for_backward(qkv, out)
-        ctx.heads, ctx.desc = heads, desc
+        ctx.heads, ctx.desc, ctx.mfma = heads, desc, False
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out = ctx.saved_tensors
         d, heads = ctx.desc, ctx.heads
+        if ctx.mfma:
+            qkv, out, lse = ctx.saved_tensors
+            C = out.shape[1]
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd_mfma(qkv, qkv, out, dout.contiguous(), dqkv, 0, dqkv, C, 2 * C, lse, heads, C // heads, d["nb"], 1,
+                              d["T"], d["T"], d["T"], d["T"], 1)
+            return dqkv, None, None, None, None, None
+        qkv, out = ctx.saved_tensors
         C = out.shape[1]
         dqkv = torch.empty_like(qkv)
         ops.attn_bwd(qkv, 0, qkv, C, 2 * C, out, dout.contiguous(), dqkv, 0, dqkv, C, 2 * C, heads, C // heads, d["nb"], 1,
@@ -134,16 +147,33 @@ class CrossAttnFn(Function):
         sh = torch.tensor([shift], dtype=torch.int32, device=vqkv.device)
         vatt = torch.empty(N * F * HW, C, dtype=vqkv.dtype, device=vqkv.device)
         aatt = torch.empty(N * L, C, dtype=vqkv.dtype, device=vqkv.device)
+        ctx.cfg = (heads, N, F, HW, L, apf, win)
+        ctx.mfma = ops.attn_mfma_ok(vqkv, C // heads) and ops.attn_mfma_ok(aqkv, C // heads)
+        if ctx.mfma:
+            vlse = torch.empty(N * F * HW * heads, dtype=torch.float32, device=vqkv.device)
+            alse = torch.empty(N * L * heads, dtype=torch.float32, device=vqkv.device)
+            ops.attn_lse(vqkv, aqkv, vatt, vlse, heads, C // heads, N, F, F * HW, HW, L, apf, win, shift_dev=sh)
+            ops.attn_lse(aqkv, vqkv, aatt, alse, heads, C // heads, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
+            ctx.save_for_backward(vqkv, aqkv, vatt, aatt, sh, vlse, alse)
+            return vatt, aatt
         ops.attn(vqkv, aqkv, vatt, heads, C // heads, N, F, F * HW, HW, L, apf, win, shift_dev=sh)
         ops.attn(aqkv, vqkv, aatt, heads, C // heads, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
         ctx.save_for_backward(vqkv, aqkv, vatt, aatt, sh)
-        ctx.cfg = (heads, N, F, HW, L, apf, win)
         return vatt, aatt
 
     @staticmethod
     def backward(ctx, dvatt, daatt):
-        vqkv, aqkv, vatt, aatt, sh = ctx.saved_tensors
         heads, N, F, HW, L, apf, win = ctx.cfg
+        if ctx.mfma:
+            vqkv, aqkv, vatt, aatt, sh, vlse, alse = ctx.saved_tensors
+            C = vatt.shape[1]
+            dv, da = torch.empty_like(vqkv), torch.empty_like(aqkv)
+            ops.attn_bwd_mfma(vqkv, aqkv, vatt, dvatt.contiguous(), dv, 0, da, C, 2 * C, vlse, heads, C // heads, N, F, F * HW, HW,
+                              L, apf, win, shift_dev=sh)
+            ops.attn_bwd_mfma(aqkv, vqkv, aatt, daatt.contiguous(), da, 0, dv, C, 2 * C, alse, heads, C // heads, N, F, L, apf,
+                              F * HW, HW, win, shift_dev=sh)
+            return dv, da, None, None, None, None, None, None, None
+        vqkv, aqkv, vatt, aatt, sh = ctx.saved_tensors
         C = vatt.shape[1]
         dv, da = torch.empty_like(vqkv), torch.empty_like(aqkv)
         vgeo, ageo = (1, F * HW, 1, 1), (1, L, 1, 1)

@@ -129,7 +129,8 @@ def _attend_rows(q, k, v, heads):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("kind,T_,heads,ch", [("spatial", 70, 2, 32), ("spatial", 64, 4, 16), ("audio", 100, 2, 64), ("temporal", 8, 4, 16), ("temporal", 16, 2, 48)])
+@pytest.mark.parametrize("kind,T_,heads,ch", [("spatial", 70, 2, 32), ("spatial", 64, 4, 16), ("audio", 100, 2, 64), ("temporal", 8, 4, 16), ("temporal", 16, 2, 48),
+                                              ("spatial", 300, 2, 64), ("audio", 200, 1, 128), ("spatial", 130, 1, 96)])
 def test_self_attention_backward(T, dt, kind, T_, heads, ch):
     ops, tr = T
     C = heads * ch
@@ -164,7 +165,8 @@ def test_self_attention_backward(T, dt, kind, T_, heads, ch):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("F,HW,L,win,shift,heads,ch", [(8, 16, 64, 1, 5, 2, 32), (8, 16, 64, 4, 3, 2, 32), (8, 4, 8, 8, 0, 2, 16), (16, 4, 100, 4, 12, 2, 32)])
+@pytest.mark.parametrize("F,HW,L,win,shift,heads,ch", [(8, 16, 64, 1, 5, 2, 32), (8, 16, 64, 4, 3, 2, 32), (8, 4, 8, 8, 0, 2, 16), (16, 4, 100, 4, 12, 2, 32),
+                                                     (4, 256, 400, 2, 1, 2, 64), (4, 64, 403, 3, 2, 1, 128)])
 def test_cross_attention_backward(T, dt, F, HW, L, win, shift, heads, ch):
     ops, tr = T
     N, C = 2, heads * ch
