@@ -166,6 +166,9 @@ int mmd_attn_bwd_mfma(const void* Q, int64_t ldq, int q_off, const void* KV, int
                       int dk_off, int dv_off, const float* lse2, float* dsum_ws, int heads, int ch, int nb, int G,
                       int64_t q_rows_per_batch, int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win,
                       const int* shift_dev, void* stream);
+/* backward of mmd_attn_small_fwd (temporal attention): dQKV rows [dq | dk | dv], same slice geometry. */
+int mmd_attn_small_bwd(int dtype, const void* QKV, int64_t ld, const void* dO, int64_t lddo, void* dQKV, int64_t ldd, int C, int heads,
+                       int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, void* stream);
 /* out = silu(x) (dy NULL) or dy*silu'(x); d(mse loss)/d(out); AdamW (+EMA, nn.py:128-138) on flat fp32 buffers. */
 int mmd_timestep_embedding(const void* t, int t_kind, int N, int dim, float* out, void* stream);   /* nn.py:192-210 */
 int mmd_silu(int dtype, const void* x, const void* dy, void* out, int64_t n, void* stream);

@@ -396,3 +396,195 @@ extern "C" int mmd_attn_bwd(int dtype, const void* Q, int64_t ldq, int q_off, co
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, g2, dim3(256), lds, st, p);
   return mmd_check_launch("attn_bwd_dkv");
 }
+
+// ============================================================================= short-sequence (temporal) backward
+// Backward of attn_small_kernel (mmd_attn.hip): one wave per (slice, head), Tn <= 32 rows strided by tstride.
+// Phase 1, lane = (query, channel quarter): s_j, dp_j = dO.v_j, P = softmax(s), D = sum_j P_j dp_j,
+// dS_j = scale P_j (dp_j - D), dQ = dS K (written), P / dS parked in LDS.
+// Phase 2, lane = (key, channel quarter): dK_j = sum_i dS_ij Q_i, dV_j = sum_i P_ij dO_i.
+struct SmallAttnBwdParams {
+  const char* QKV; int64_t ld;
+  const char* dO; int64_t lddo;
+  char* dQKV; int64_t ldd;
+  int C, heads, ch;
+  int S, Tn, inner;
+  int64_t outer_stride, inner_stride, tstride;
+  float scale;
+};
+
+template <typename T, int CHQ>
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int ch = CHQ * 4;
+  constexpr int EPV = Elt<T>::EPV, ES = 16 / EPV;
+  const int Tn = p.Tn, TP = Tn + 1;
+  const int per_wave = 4 * Tn * ch + 2 * Tn * TP;
+  float* sQ = (float*)smem + (size_t)wave * per_wave;   // [Tn][ch] each
+  float* sK = sQ + Tn * ch;
+  float* sV = sK + Tn * ch;
+  float* sG = sV + Tn * ch;                              // dO
+  float* sP = sG + Tn * ch;                              // [Tn][Tn+1]
+  float* sS = sP + Tn * TP;                              // dS (scale folded in)
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  const bool active = item < (int64_t)p.S * p.heads;
+  const int s = active ? (int)(item / p.heads) : 0, h = active ? (int)(item % p.heads) : 0;
+  const int64_t base = (int64_t)(s / p.inner) * p.outer_stride + (int64_t)(s % p.inner) * p.inner_stride;
+  const bool vec_ok = (p.ld % EPV == 0) && (p.lddo % EPV == 0) && (p.ldd % EPV == 0) && (p.C % EPV == 0) && (ch % EPV == 0) &&
+                      (((uintptr_t)p.QKV | (uintptr_t)p.dO | (uintptr_t)p.dQKV) % 16 == 0);
+  if (active) {
+    if (vec_ok) {
+      constexpr int cvn = ch / EPV > 0 ? ch / EPV : 1;
+      for (int i = lane; i < Tn * cvn; i += 64) {
+        const int j = i / cvn, v = i % cvn;
+        const int64_t row = base + (int64_t)j * p.tstride;
+        const u32x4 xq = *(const u32x4*)(p.QKV + (row * p.ld + h * ch + v * EPV) * ES);
+        const u32x4 xk = *(const u32x4*)(p.QKV + (row * p.ld + p.C + h * ch + v * EPV) * ES);
+        const u32x4 xv = *(const u32x4*)(p.QKV + (row * p.ld + 2 * p.C + h * ch + v * EPV) * ES);
+        const u32x4 xg = *(const u32x4*)(p.dO + (row * p.lddo + h * ch + v * EPV) * ES);
+        float fq[EPV], fk[EPV], fv[EPV], fg[EPV];
+        Elt<T>::unpack(xq, fq); Elt<T>::unpack(xk, fk); Elt<T>::unpack(xv, fv); Elt<T>::unpack(xg, fg);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const int o = j * ch + v * EPV + e;
+          sQ[o] = fq[e]; sK[o] = fk[e]; sV[o] = fv[e]; sG[o] = fg[e];
+        }
+      }
+    } else {
+      for (int i = lane; i < Tn * ch; i += 64) {
+        const int j = i / ch, d = i % ch;
+        const int64_t row = base + (int64_t)j * p.tstride;
+        sQ[i] = Elt<T>::ld(p.QKV, row * p.ld + h * ch + d);
+        sK[i] = Elt<T>::ld(p.QKV, row * p.ld + p.C + h * ch + d);
+        sV[i] = Elt<T>::ld(p.QKV, row * p.ld + 2 * p.C + h * ch + d);
+        sG[i] = Elt<T>::ld(p.dO, row * p.lddo + h * ch + d);
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const int dq = lane & 3, c0 = dq * CHQ;
+  auto store_row = [&](int64_t row, int col0, const float* o) {
+    if (vec_ok && CHQ % EPV == 0) {
+#pragma unroll
+      for (int d = 0; d < CHQ; d += EPV) {
+        float f[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) f[e] = o[(d + e) < CHQ ? (d + e) : 0];
+        *(u32x4*)(p.dQKV + (row * p.ldd + col0 + c0 + d) * ES) = Elt<T>::pack(f);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < CHQ; ++d) Elt<T>::st(p.dQKV, row * p.ldd + col0 + c0 + d, o[d]);
+    }
+  };
+  // ---- phase 1: per query
+  for (int qb = 0; qb < Tn; qb += 16) {
+    const int qi = qb + (lane >> 2);
+    const bool ok = qi < Tn;
+    const int qr = ok ? qi : 0;
+    float q[CHQ], g[CHQ];
+#pragma unroll
+    for (int d = 0; d < CHQ; ++d) { q[d] = sQ[qr * ch + c0 + d] * p.scale; g[d] = sG[qr * ch + c0 + d]; }
+    float sc[32], dp[32];
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      float a = 0.f, b = 0.f;
+      if (j < Tn) {
+#pragma unroll
+        for (int d = 0; d < CHQ; ++d) { a += q[d] * sK[j * ch + c0 + d]; b += g[d] * sV[j * ch + c0 + d]; }
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        mx = fmaxf(mx, a);
+      }
+      sc[j] = a; dp[j] = b;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float e = j < Tn ? __expf(sc[j] - mx) : 0.f;
+      sc[j] = e; sum += e;
+    }
+    const float inv = 1.f / sum;
+    float Dq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { sc[j] *= inv; Dq += sc[j] * dp[j]; }
+    float o[CHQ];
+#pragma unroll
+    for (int d = 0; d < CHQ; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < Tn) {
+        const float ds = sc[j] * (dp[j] - Dq) * p.scale;
+        if (ok && dq == (j & 3)) { sP[qi * TP + j] = sc[j]; sS[qi * TP + j] = ds; }
+#pragma unroll
+        for (int d = 0; d < CHQ; ++d) o[d] += ds * sK[j * ch + c0 + d];
+      }
+    }
+    if (ok) store_row(base + (int64_t)qi * p.tstride, h * ch, o);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): P / dS visible to the whole wave
+  // ---- phase 2: per key
+  for (int kb = 0; kb < Tn; kb += 16) {
+    const int kj = kb + (lane >> 2);
+    if (kj >= Tn) continue;
+    float dk[CHQ], dv[CHQ];
+#pragma unroll
+    for (int d = 0; d < CHQ; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < Tn; ++i) {
+      const float ds = sS[i * TP + kj], pr = sP[i * TP + kj];
+#pragma unroll
+      for (int d = 0; d < CHQ; ++d) { dk[d] += ds * sQ[i * ch + c0 + d]; dv[d] += pr * sG[i * ch + c0 + d]; }
+    }
+    const int64_t row = base + (int64_t)kj * p.tstride;
+    store_row(row, p.C + h * ch, dk);
+    store_row(row, 2 * p.C + h * ch, dv);
+  }
+}
+
+template <typename T, int CHQ>
+static int launch_small_bwd(const SmallAttnBwdParams& p, hipStream_t st) {
+  const size_t lds = (size_t)4 * (4 * p.Tn * (CHQ * 4) + 2 * p.Tn * (p.Tn + 1)) * sizeof(float);
+  if (lds > 64 * 1024) {
+    static size_t attr = 0;
+    if (lds > attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_small_bwd_kernel<T, CHQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_small_bwd: set LDS attr: %s", hipGetErrorString(e));
+      attr = lds;
+    }
+  }
+  const int64_t items = (int64_t)p.S * p.heads;
+  hipLaunchKernelGGL((attn_small_bwd_kernel<T, CHQ>), dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, p);
+  return mmd_check_launch("attn_small_bwd");
+}
+
+template <typename T>
+static int dispatch_small_bwd(const SmallAttnBwdParams& p, hipStream_t st) {
+  switch (p.ch) {
+    case 16: return launch_small_bwd<T, 4>(p, st);
+    case 32: return launch_small_bwd<T, 8>(p, st);
+    case 48: return launch_small_bwd<T, 12>(p, st);
+    case 64: return launch_small_bwd<T, 16>(p, st);
+    case 96: return launch_small_bwd<T, 24>(p, st);
+    case 128: return launch_small_bwd<T, 32>(p, st);
+    default: return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_small_bwd: head width %d not in {16,32,48,64,96,128}", p.ch);
+  }
+}
+
+// Backward of mmd_attn_small_fwd: dQKV rows get [dq | dk | dv] for the same slice geometry.
+extern "C" int mmd_attn_small_bwd(int dtype, const void* QKV, int64_t ld, const void* dO, int64_t lddo, void* dQKV, int64_t ldd,
+                                  int C, int heads, int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride,
+                                  int64_t tstride, void* stream) {
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "attn_small_bwd: bad dtype %d", dtype);
+  MMD_REQUIRE(QKV && dO && dQKV && C > 0 && heads > 0 && C % heads == 0, "attn_small_bwd: bad argument");
+  MMD_REQUIRE(Tn >= 1 && Tn <= 32, "attn_small_bwd: sequence length %d not in [1,32]", Tn);
+  SmallAttnBwdParams p;
+  p.QKV = (const char*)QKV; p.ld = ld; p.dO = (const char*)dO; p.lddo = lddo; p.dQKV = (char*)dQKV; p.ldd = ldd;
+  p.C = C; p.heads = heads; p.ch = C / heads; p.S = S; p.Tn = Tn; p.inner = inner;
+  p.outer_stride = outer_stride; p.inner_stride = inner_stride; p.tstride = tstride;
+  p.scale = 1.0f / sqrtf((float)p.ch);
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == MMD_BF16 ? dispatch_small_bwd<__bf16>(p, st) : dispatch_small_bwd<float>(p, st);
+}

@@ -49,6 +49,7 @@ _PROTOS = {
     "mmd_attn_fwd_lse": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, i64, i32, i64, i32, i32, vp, vp, vp]),
     "mmd_attn_bwd_mfma": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32,
                                 i64, i32, i64, i32, i32, vp, vp]),
+    "mmd_attn_small_bwd": (i32, [i32, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "mmd_silu": (i32, [i32, vp, vp, vp, i64, vp]),
     "mmd_dropout": (i32, [i32, vp, vp, f32, vp, i64, vp]),
     "mmd_mse_grad": (i32, [vp, vp, vp, vp, i32, i64, vp]),

@@ -257,6 +257,14 @@ def attn_small(qkv, out, C, heads, geom: Geom):
     return out
 
 
+def attn_small_bwd(qkv, dout, dqkv, C, heads, geom: Geom):
+    _chk2d(qkv), _chk2d(dout), _chk2d(dqkv)
+    _dispatch("mmd_attn_small_bwd", H.dt_of(qkv), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0), dqkv.data_ptr(),
+              dqkv.stride(0), C, heads, *geom.args(),
+              meta=("attn_small_bwd", 10 * geom.S * geom.Tn * geom.Tn * C, 8 * geom.S * geom.Tn * C * qkv.element_size()))
+    return dqkv
+
+
 def resample(x, out, NF, Hh, Ww, fh, fw, mode, scale=1.0):
     """mode 0 avg-pool / 1 nearest-upsample by (1, fh, fw); Hh, Ww describe the input rows (nf, h, w)."""
     _chk2d(x), _chk2d(out)

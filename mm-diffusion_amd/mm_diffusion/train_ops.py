@@ -100,7 +100,7 @@ class SelfAttnFn(Function):
         out = torch.empty(rows, C, dtype=qkv.dtype, device=qkv.device)
         if kind == "temporal":
             ops.attn_small(qkv, out, C, heads, Geom.temporal(N, F, HW))
-            desc = dict(nb=N * HW, inner=HW, outer=F * HW, istride=1, tstride=HW, T=F)
+            desc = dict(nb=N * HW, inner=HW, outer=F * HW, istride=1, tstride=HW, T=F, geom=Geom.temporal(N, F, HW))
         else:
             T = HW if kind == "spatial" else rows // N
             nb = N * F if kind == "spatial" else N
@@ -129,6 +129,9 @@ class SelfAttnFn(Function):
         qkv, out = ctx.saved_tensors
         C = out.shape[1]
         dqkv = torch.empty_like(qkv)
+        if "geom" in d and C // heads in ops.MFMA_HEADS:       # temporal: one wave per (pixel, head)
+            ops.attn_small_bwd(qkv, dout.contiguous(), dqkv, C, heads, d["geom"])
+            return dqkv, None, None, None, None, None
         ops.attn_bwd(qkv, 0, qkv, C, 2 * C, out, dout.contiguous(), dqkv, 0, dqkv, C, 2 * C, heads, C // heads, d["nb"], 1,
                      (d["inner"], d["outer"], d["istride"], d["tstride"]), d["T"], d["T"],
                      (d["inner"], d["outer"], d["istride"], d["tstride"]), d["T"], d["T"], 1, None)
