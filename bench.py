@@ -170,6 +170,7 @@ def train_bench(args, world, rank, device):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    host_elapsed = time.perf_counter() - t0          # launch-side time (python + HIP enqueue) before the final drain
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -186,6 +187,7 @@ def train_bench(args, world, rank, device):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3]: base model training step, per-GPU batch {B}, dropout 0.1, flat-buffer gradient all-reduce",
                        "global_batch": B * world, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9},
+            "host_ms_per_step": 1000 * host_elapsed / args.steps,
             "model_tflops": 3 * MODEL_FLOPS_PER_PAIR * B * args.steps / elapsed / 1e12}))
     if world > 1:
         dist.barrier()

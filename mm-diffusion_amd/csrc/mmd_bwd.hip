@@ -114,7 +114,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* __restrict__ dy
   for (int e = 0; e < EPV; ++e) sum[e] = 0.f;
   const int m0 = blockIdx.x * rows_per_block, m1 = min(m0 + rows_per_block, M);
   if (rl < RPP) {
-    for (int m = m0 + rl; m < m1; m += RPP) {
+    int m = m0 + rl;
+    for (; m + 3 * RPP < m1; m += 4 * RPP) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(dy + ((int64_t)(m + u * RPP) * ld + col * EPV) * ES);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[EPV];
+        Elt<T>::unpack(v[u], f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) sum[e] += f[e];
+      }
+    }
+    for (; m < m1; m += RPP) {
       float f[EPV];
       Elt<T>::unpack(*(const u32x4*)(dy + ((int64_t)m * ld + col * EPV) * ES), f);
 #pragma unroll
@@ -170,11 +183,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const char* __restri
   }
   const int j0 = chunk * R, j1 = min(j0 + R, g.Tn);
   if (rl < RPP) {
-    for (int j = j0 + rl; j < j1; j += RPP) {
-      const int64_t row = base + (int64_t)j * g.tstride;
+    auto body = [&](const u32x4& vx, const u32x4& vd) {
       float fx[EPV], fd[EPV];
-      Elt<T>::unpack(*(const u32x4*)(x + (row * ldx + col * EPV) * ES), fx);
-      Elt<T>::unpack(*(const u32x4*)(dy + (row * lddy + col * EPV) * ES), fd);
+      Elt<T>::unpack(vx, fx);
+      Elt<T>::unpack(vd, fd);
 #pragma unroll
       for (int e = 0; e < EPV; ++e) {
         float dv = fd[e];
@@ -186,6 +198,20 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const char* __restri
         P[e] += dv;
         Q[e] += dv * (fx[e] - mu[e]) * rs[e];
       }
+    };
+    int j = j0 + rl;
+    for (; j + RPP < j1; j += 2 * RPP) {
+      const int64_t r0 = base + (int64_t)j * g.tstride, r1 = base + (int64_t)(j + RPP) * g.tstride;
+      const u32x4 x0 = *(const u32x4*)(x + (r0 * ldx + col * EPV) * ES);
+      const u32x4 d0 = *(const u32x4*)(dy + (r0 * lddy + col * EPV) * ES);
+      const u32x4 x1 = *(const u32x4*)(x + (r1 * ldx + col * EPV) * ES);
+      const u32x4 d1 = *(const u32x4*)(dy + (r1 * lddy + col * EPV) * ES);
+      body(x0, d0);
+      body(x1, d1);
+    }
+    if (j < j1) {
+      const int64_t r0 = base + (int64_t)j * g.tstride;
+      body(*(const u32x4*)(x + (r0 * ldx + col * EPV) * ES), *(const u32x4*)(dy + (r0 * lddy + col * EPV) * ES));
     }
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { s_p[rl * C + col * EPV + e] = P[e]; s_q[rl * C + col * EPV + e] = Q[e]; }
@@ -230,40 +256,64 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restr
   }
 }
 
-// stage 3: dx = rstd * (g_c dv - m1 - z m2)
+// stage 3: dx = rstd * (g_c dv - m1 - z m2) = k1 dv + k2 x + k3 with per-(slice, channel) coefficients held in registers;
+// block = (row chunk, slice), thread = (channel vector, row lane), two rows in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const char* __restrict__ x, int64_t ldx, const char* __restrict__ dy, int64_t lddy,
-                                                           char* __restrict__ dx, int64_t lddx, int64_t rows, int C, GnBwdGeom g,
+                                                           char* __restrict__ dx, int64_t lddx, int C, GnBwdGeom g,
                                                            const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mr,
                                                            const float* __restrict__ m12, const float* __restrict__ gamma,
-                                                           const float* __restrict__ film, int64_t film_ld, int act) {
+                                                           const float* __restrict__ film, int64_t film_ld, int act, int R) {
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
-  const int CV = C / EPV, cpg = C / 32;
-  const int64_t total = rows * CV;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t m = i / CV;
-    const int cvi = (int)(i % CV);
-    const int64_t o = m / g.outer_stride, rem = m % g.outer_stride;
-    const int s = (int)(o * g.inner + (rem / g.inner_stride) % g.inner);
+  const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int CV = C / EPV, RPP = 256 / CV, cpg = C / 32;
+  const int col = tid % CV, rl = tid / CV;
+  if (rl >= RPP) return;
+  const int64_t base = gnb_base(g, s);
+  float av[EPV], bv[EPV], k1[EPV], k2[EPV], k3[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    const int c = col * EPV + e, gi = c / cpg;
+    av[e] = a[(int64_t)s * C + c];
+    bv[e] = b[(int64_t)s * C + c];
+    const float mu = mr[((int64_t)s * 32 + gi) * 2], rs = mr[((int64_t)s * 32 + gi) * 2 + 1];
+    const float m1 = m12[((int64_t)s * 32 + gi) * 2], m2 = m12[((int64_t)s * 32 + gi) * 2 + 1];
+    const float gc = (film ? 1.f + film[(int64_t)s * film_ld + c] : 1.f) * gamma[c];
+    k1[e] = rs * gc;
+    k2[e] = -rs * rs * m2;
+    k3[e] = rs * (mu * rs * m2 - m1);
+  }
+  const int j0 = chunk * R, j1 = min(j0 + R, g.Tn);
+  auto body = [&](const u32x4& vx, const u32x4& vd, int64_t row) {
     float fx[EPV], fd[EPV], out[EPV];
-    Elt<T>::unpack(*(const u32x4*)(x + (m * ldx + (int64_t)cvi * EPV) * ES), fx);
-    Elt<T>::unpack(*(const u32x4*)(dy + (m * lddy + (int64_t)cvi * EPV) * ES), fd);
+    Elt<T>::unpack(vx, fx);
+    Elt<T>::unpack(vd, fd);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      const int c = cvi * EPV + e, gi = c / cpg;
       float dv = fd[e];
       if (act) {
-        const float v = fx[e] * a[(int64_t)s * C + c] + b[(int64_t)s * C + c];
+        const float v = fx[e] * av[e] + bv[e];
         const float sg = 1.f / (1.f + __expf(-v));
         dv *= sg * (1.f + v * (1.f - sg));
       }
-      const float mu = mr[((int64_t)s * 32 + gi) * 2], rs = mr[((int64_t)s * 32 + gi) * 2 + 1];
-      const float gc = (film ? 1.f + film[(int64_t)s * film_ld + c] : 1.f) * gamma[c];
-      const float z = (fx[e] - mu) * rs;
-      out[e] = rs * (gc * dv - m12[((int64_t)s * 32 + gi) * 2] - z * m12[((int64_t)s * 32 + gi) * 2 + 1]);
+      out[e] = k1[e] * dv + k2[e] * fx[e] + k3[e];
     }
-    *(u32x4*)(dx + (m * lddx + (int64_t)cvi * EPV) * ES) = Elt<T>::pack(out);
+    *(u32x4*)(dx + (row * lddx + col * EPV) * ES) = Elt<T>::pack(out);
+  };
+  int j = j0 + rl;
+  for (; j + RPP < j1; j += 2 * RPP) {
+    const int64_t r0 = base + (int64_t)j * g.tstride, r1 = base + (int64_t)(j + RPP) * g.tstride;
+    const u32x4 x0 = *(const u32x4*)(x + (r0 * ldx + col * EPV) * ES);
+    const u32x4 d0 = *(const u32x4*)(dy + (r0 * lddy + col * EPV) * ES);
+    const u32x4 x1 = *(const u32x4*)(x + (r1 * ldx + col * EPV) * ES);
+    const u32x4 d1 = *(const u32x4*)(dy + (r1 * lddy + col * EPV) * ES);
+    body(x0, d0, r0);
+    body(x1, d1, r1);
+  }
+  if (j < j1) {
+    const int64_t r0 = base + (int64_t)j * g.tstride;
+    body(*(const u32x4*)(x + (r0 * ldx + col * EPV) * ES), *(const u32x4*)(dy + (r0 * lddy + col * EPV) * ES), r0);
   }
 }
 
@@ -348,7 +398,7 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
   int rc = mmd_check_launch("conv_wgrad");
   if (rc || !db) return rc;
   MMD_REQUIRE(Cout / epv <= 256, "conv_wgrad: Cout too wide for colsum");
-  const int rpb = 512;
+  const int rpb = M >= 65536 ? 256 : 128;
   if (dtype == MMD_BF16) hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
   else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
   return mmd_check_launch("colsum");
@@ -384,13 +434,16 @@ extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy,
                      dfilm_ld, m12);
   rc = mmd_check_launch("gn_bwd_params");
   if (rc) return rc;
-  const int grid3 = ew_grid_b(rows * (C / epv));
+  int R3 = 4 * rpp;
+  while ((int64_t)S * cdiv(Tn, R3) > 4096 && R3 < 1024) R3 *= 2;
+  dim3 grid3(cdiv(Tn, R3), S);
+  (void)rows;
   if (dtype == MMD_BF16)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, dim3(grid3), dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, (char*)dx, lddx, rows, C, g,
-                       a, b, mr, (const float*)m12, gamma, film, film_ld, act);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, grid3, dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, (char*)dx, lddx, C, g,
+                       a, b, mr, (const float*)m12, gamma, film, film_ld, act, R3);
   else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid3), dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, (char*)dx, lddx, rows, C, g,
-                       a, b, mr, (const float*)m12, gamma, film, film_ld, act);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid3, dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, (char*)dx, lddx, C, g,
+                       a, b, mr, (const float*)m12, gamma, film, film_ld, act, R3);
   return mmd_check_launch("gn_bwd_apply");
 }
 
