@@ -166,6 +166,18 @@ int mmd_attn_bwd_mfma(const void* Q, int64_t ldq, int q_off, const void* KV, int
                       int dk_off, int dv_off, const float* lse2, float* dsum_ws, int heads, int ch, int nb, int G,
                       int64_t q_rows_per_batch, int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win,
                       const int* shift_dev, void* stream);
+/* DDIM step for one stream (ddim_sample gd:821-901; flag 8 = ddim_reverse_sample gd:903-953).  tables as mmd_ddpm_update,
+ * tab3 [3,T] fp32 = alphas_cumprod, alphas_cumprod_prev, alphas_cumprod_next; flags 1 clip, 2 model predicts x0, 4 learned sigma. */
+int mmd_ddim_update(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, const float* tables,
+                    const float* tab3, const int64_t* t, int T, int N, int F, int C, int HW, int flags, float eta, void* stream);
+/* out[n,:] = (ca[t_n] a + cb[t_n] b) cs[t_n]: the _predict_* / q_posterior helpers (gd:170-229,345-366); NULL table = 1, b nullable. */
+int mmd_lincomb_t(const float* a, const float* b, float* out, const float* ca, const float* cb, const float* cs, const int64_t* t,
+                  int N, int64_t per_sample, void* stream);
+/* out = ca a + cb b + cc c (b, c nullable): solver update combinations (multimodal_dpm_solver_plus.py:520-1100). */
+int mmd_lincomb(const float* a, float ca, const float* b, float cb, const float* c, float cc, float* out, int64_t n, void* stream);
+/* backward of mmd_ddpm_update's sample w.r.t. x and the model output (gradient-guided sampling gd:722-817; fixed variance). */
+int mmd_ddpm_update_bwd(const float* x, const float* model_out, const float* dsample, float* dx, float* dmodel_out, const float* tables,
+                        const int64_t* t, int T, int N, int64_t per_sample, int flags, void* stream);
 /* backward of mmd_attn_small_fwd (temporal attention): dQKV rows [dq | dk | dv], same slice geometry. */
 int mmd_attn_small_bwd(int dtype, const void* QKV, int64_t ld, const void* dO, int64_t lddo, void* dQKV, int64_t ldd, int C, int heads,
                        int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, void* stream);

@@ -617,3 +617,124 @@ extern "C" int mmd_timestep_embedding(const void* t, int t_kind, int N, int dim,
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, t, t_kind, dim, out);
   return mmd_check_launch("timestep_embedding");
 }
+
+// ----------------------------------------------------------------------------- DDIM step / helper combinations
+// ddim_sample (gd:821-901) and ddim_reverse_sample (gd:903-953) for one stream, API layout [N, F, Cm, HW]:
+//   x0 = eps-or-x0 prediction (clamped with flag 1), eps = (sqrt_recip_ac x - x0) / sqrt_recipm1_ac,
+//   sigma = eta sqrt((1-ac_prev)/(1-ac)) sqrt(1 - ac/ac_prev),
+//   out = x0 sqrt(ac_prev) + sqrt(1 - ac_prev - sigma^2) eps + [t != 0] sigma noise          (flag 8: reverse ODE with ac_next, no noise)
+// tab3 = [3][T] fp32: alphas_cumprod, alphas_cumprod_prev, alphas_cumprod_next.
+struct DdimParams {
+  const float* x; const float* mo; const float* noise;
+  float* out; float* x0_out;
+  const float* tables; const float* tab3; const int64_t* t;
+  int T, N, F, C, HW, flags;
+  float eta;
+};
+__global__ __launch_bounds__(256) void ddim_update_kernel(const DdimParams p) {
+  const int64_t per = (int64_t)p.F * p.C * p.HW;
+  const int64_t total = per * p.N;
+  const int Cm = (p.flags & 4) ? 2 * p.C : p.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / per, r = i % per;
+    const int hw = (int)(r % p.HW), c = (int)((r / p.HW) % p.C);
+    const int64_t f = r / ((int64_t)p.HW * p.C);
+    const int ti = (int)p.t[n];
+    const float cr = p.tables[ti], crm1 = p.tables[p.T + ti];
+    const float o = p.mo[((n * p.F + f) * Cm + c) * (int64_t)p.HW + hw];
+    const float xv = p.x[i];
+    float x0 = (p.flags & 2) ? o : cr * xv - crm1 * o;
+    if (p.flags & 1) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    const float eps = (cr * xv - x0) / crm1;
+    float res;
+    if (p.flags & 8) {
+      const float an = p.tab3[2 * p.T + ti];
+      res = x0 * sqrtf(an) + sqrtf(1.f - an) * eps;
+    } else {
+      const float ab = p.tab3[ti], ap = p.tab3[p.T + ti];
+      const float sigma = p.eta * sqrtf((1.f - ap) / (1.f - ab)) * sqrtf(1.f - ab / ap);
+      const float mean = x0 * sqrtf(ap) + sqrtf(1.f - ap - sigma * sigma) * eps;
+      const float nz = ti != 0 ? 1.f : 0.f;
+      res = mean + nz * sigma * (p.noise ? p.noise[i] : 0.f);
+    }
+    if (p.out) p.out[i] = res;
+    if (p.x0_out) p.x0_out[i] = x0;
+  }
+}
+extern "C" int mmd_ddim_update(const float* x, const float* model_out, const float* noise, float* out, float* x0_out,
+                               const float* tables, const float* tab3, const int64_t* t, int T, int N, int F, int C, int HW,
+                               int flags, float eta, void* stream) {
+  MMD_REQUIRE(x && model_out && tables && tab3 && t && T > 0 && N > 0 && F > 0 && C > 0 && HW > 0, "ddim_update: bad argument");
+  MMD_REQUIRE((flags & 8) || eta == 0.f || noise, "ddim_update: eta > 0 needs noise");
+  DdimParams p;
+  p.x = x; p.mo = model_out; p.noise = noise; p.out = out; p.x0_out = x0_out; p.tables = tables; p.tab3 = tab3; p.t = t;
+  p.T = T; p.N = N; p.F = F; p.C = C; p.HW = HW; p.flags = flags; p.eta = eta;
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(ew_grid((int64_t)N * F * C * HW)), dim3(256), 0, (hipStream_t)stream, p);
+  return mmd_check_launch("ddim_update");
+}
+
+// out[n, i] = (ca[t_n] a + cb[t_n] b) * cs[t_n]    per-sample coefficients looked up from fp32 tables of length T
+// (ca / cb / cs may be NULL = 1; b may be NULL).  Covers _predict_xstart_from_eps, _predict_eps_from_xstart,
+// _predict_xstart_from_xprev, q_posterior mean, q_mean (gd:170-229,345-366).
+__global__ __launch_bounds__(256) void lincomb_t_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                        const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ cs,
+                                                        const int64_t* __restrict__ t, int64_t per, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ti = (int)t[i / per];
+    float v = (ca ? ca[ti] : 1.f) * a[i];
+    if (b) v += (cb ? cb[ti] : 1.f) * b[i];
+    out[i] = cs ? v * cs[ti] : v;
+  }
+}
+extern "C" int mmd_lincomb_t(const float* a, const float* b, float* out, const float* ca, const float* cb, const float* cs,
+                             const int64_t* t, int N, int64_t per_sample, void* stream) {
+  MMD_REQUIRE(a && out && t && N > 0 && per_sample > 0, "lincomb_t: bad argument");
+  const int64_t total = per_sample * N;
+  hipLaunchKernelGGL(lincomb_t_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a, b, out, ca, cb, cs, t, per_sample, total);
+  return mmd_check_launch("lincomb_t");
+}
+
+// out = ca a + cb b + cc c with host scalars (b, c nullable): the DPM-Solver update combinations (dpm:520-1100).
+__global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                      float* __restrict__ out, float ca, float cb, float cc, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float v = ca * a[i];
+    if (b) v += cb * b[i];
+    if (c) v += cc * c[i];
+    out[i] = v;
+  }
+}
+extern "C" int mmd_lincomb(const float* a, float ca, const float* b, float cb, const float* c, float cc, float* out, int64_t n,
+                           void* stream) {
+  MMD_REQUIRE(a && out && n > 0, "lincomb: bad argument");
+  hipLaunchKernelGGL(lincomb_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, ca, cb, cc, n);
+  return mmd_check_launch("lincomb");
+}
+
+// Backward of the sampling update through the posterior mean (gradient-guided conditional sampling, gd:722-817):
+//   sample = c1 clamp(x0) + c2 x + noise term,  x0 = cr x - crm1 eps  (or x0 = model output with flag 2)
+//   dx = dsample (c1 cr [|x0| <= 1] + c2),  dmo = dsample (-c1 crm1 [|x0| <= 1])   (fixed variance only)
+__global__ __launch_bounds__(256) void ddpm_update_bwd_kernel(const DdpmParams p, const float* __restrict__ ds, float* __restrict__ dx,
+                                                              float* __restrict__ dmo) {
+  const int64_t per = (int64_t)p.F * p.C * p.HW;
+  const int64_t total = per * p.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ti = (int)p.t[i / per];
+    const float cr = p.tables[ti], crm1 = p.tables[p.T + ti], c1 = p.tables[2 * p.T + ti], c2 = p.tables[3 * p.T + ti];
+    const float o = p.mo[i], xv = p.x[i], g = ds[i];
+    const float x0 = (p.flags & 2) ? o : cr * xv - crm1 * o;
+    const float pass = (!(p.flags & 1) || (x0 >= -1.f && x0 <= 1.f)) ? 1.f : 0.f;
+    if (dx) dx[i] = g * (((p.flags & 2) ? 0.f : c1 * cr * pass) + c2);
+    if (dmo) dmo[i] = g * ((p.flags & 2) ? c1 * pass : -c1 * crm1 * pass);
+  }
+}
+extern "C" int mmd_ddpm_update_bwd(const float* x, const float* model_out, const float* dsample, float* dx, float* dmodel_out,
+                                   const float* tables, const int64_t* t, int T, int N, int64_t per_sample, int flags, void* stream) {
+  MMD_REQUIRE(x && model_out && dsample && tables && t && T > 0 && N > 0 && per_sample > 0, "ddpm_update_bwd: bad argument");
+  MMD_REQUIRE(!(flags & 4), "ddpm_update_bwd: learned variance is not differentiable here");
+  DdpmParams p;
+  p.x = x; p.mo = model_out; p.noise = nullptr; p.out = nullptr; p.x0_out = nullptr; p.mean_out = nullptr; p.logvar_out = nullptr;
+  p.tables = tables; p.t = t; p.T = T; p.N = N; p.F = 1; p.C = 1; p.HW = (int)per_sample; p.flags = flags;
+  hipLaunchKernelGGL(ddpm_update_bwd_kernel, dim3(ew_grid((int64_t)N * per_sample)), dim3(256), 0, (hipStream_t)stream, p, dsample, dx, dmodel_out);
+  return mmd_check_launch("ddpm_update_bwd");
+}

@@ -50,6 +50,10 @@ _PROTOS = {
     "mmd_attn_bwd_mfma": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32,
                                 i64, i32, i64, i32, i32, vp, vp]),
     "mmd_attn_small_bwd": (i32, [i32, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
+    "mmd_ddim_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "mmd_lincomb_t": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    "mmd_lincomb": (i32, [vp, f32, vp, f32, vp, f32, vp, i64, vp]),
+    "mmd_ddpm_update_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "mmd_silu": (i32, [i32, vp, vp, vp, i64, vp]),
     "mmd_dropout": (i32, [i32, vp, vp, f32, vp, i64, vp]),
     "mmd_mse_grad": (i32, [vp, vp, vp, vp, i32, i64, vp]),

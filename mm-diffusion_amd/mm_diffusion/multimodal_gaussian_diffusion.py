@@ -12,7 +12,11 @@ MI355X-first differences:
     fused elementwise kernel per stream (mmd_ddpm_update)
   * `p_sample_loop` captures [U-Net launch plan + both updates] into one hipGraph and replays it per step,
     refreshing only the timestep, the window shifts and the noise
-Not built (out of the hot path): DDIM loops, zero-shot conditional sampling, bpd loops.
+  * DDIM (`ddim_sample(_loop)`) rides the same graph with mmd_ddim_update; zero-shot conditional sampling
+    (`conditional_p_sample_loop`, gd:584-819) is built for both the replacement and the gradient-guided method
+    (the latter differentiates the HIP training path w.r.t. the target stream's input)
+Not built: cond_fn (the reference's condition_mean / condition_score call `.float()` / `.shape` on the stream
+dict, gd:385,403, and raise for every multimodal call), calc_bpd_loop.
 """
 import enum
 import math
@@ -129,6 +133,68 @@ class GaussianDiffusion:
                                      th.from_numpy(q).float().to(device).contiguous())
         return self._dev_tables[key]
 
+    def ddim_tables(self, device):
+        """[3, T] fp32 alphas_cumprod, alphas_cumprod_prev, alphas_cumprod_next for mmd_ddim_update."""
+        key = ("ddim", str(device))
+        if key not in self._dev_tables:
+            tab = np.stack([self.alphas_cumprod, self.alphas_cumprod_prev, self.alphas_cumprod_next])
+            self._dev_tables[key] = th.from_numpy(tab).float().to(device).contiguous()
+        return self._dev_tables[key]
+
+    def _tab(self, arr, name, device):
+        """fp32 device copy of one fp64 coefficient table (cached by name) for mmd_lincomb_t."""
+        key = (name, str(device))
+        if key not in self._dev_tables:
+            self._dev_tables[key] = th.from_numpy(np.asarray(arr, dtype=np.float64)).float().to(device).contiguous()
+        return self._dev_tables[key]
+
+    def _lin(self, a, b, t, ca=None, cb=None, cs=None):
+        """(ca[t] a + cb[t] b) cs[t] with per-sample table lookups, one kernel; ca/cb/cs = (name, fp64 table) or None."""
+        H.require_cuda(a)
+        dev = a.device
+        tabs = [None if c is None else self._tab(c[1], c[0], dev) for c in (ca, cb, cs)]
+        a32 = a.float().contiguous()
+        b32 = None if b is None else b.float().contiguous()
+        return ops.lincomb_t(a32, b32, th.empty_like(a32), tabs[0], tabs[1], tabs[2], t.to(th.int64).contiguous())
+
+    def _extract(self, arr, name, t, shape):
+        """`_extract_into_tensor` (gd:1289-1303): fp32 table values at t broadcast to `shape`."""
+        v = self._tab(arr, name, t.device)[t.long()]
+        return v.view(-1, *([1] * (len(shape) - 1))).expand(shape)
+
+    def q_mean_variance(self, x_start, t):
+        """gd:170-185."""
+        mean = self._lin(x_start, None, t, ca=("sqrt_ac", self.sqrt_alphas_cumprod))
+        variance = self._extract(1.0 - self.alphas_cumprod, "one_minus_ac", t, x_start.shape)
+        log_variance = self._extract(self.log_one_minus_alphas_cumprod, "log_one_minus_ac", t, x_start.shape)
+        return mean, variance, log_variance
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """gd:207-229: mean = coef1 x_0 + coef2 x_t, posterior variance and its clipped log."""
+        assert x_start.shape == x_t.shape
+        mean = self._lin(x_start, x_t, t, ca=("post_c1", self.posterior_mean_coef1), cb=("post_c2", self.posterior_mean_coef2))
+        variance = self._extract(self.posterior_variance, "post_var", t, x_t.shape)
+        logvar = self._extract(self.posterior_log_variance_clipped, "post_logvar", t, x_t.shape)
+        return mean, variance, logvar
+
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        """gd:345-350."""
+        assert x_t.shape == eps.shape
+        return self._lin(x_t, eps, t, ca=("sqrt_recip_ac", self.sqrt_recip_alphas_cumprod),
+                         cb=("neg_sqrt_recipm1_ac", -self.sqrt_recipm1_alphas_cumprod))
+
+    def _predict_xstart_from_xprev(self, x_t, t, xprev):
+        """gd:352-360: (xprev - coef2 x_t) / coef1."""
+        assert x_t.shape == xprev.shape
+        return self._lin(xprev, x_t, t, ca=("inv_post_c1", 1.0 / self.posterior_mean_coef1),
+                         cb=("neg_c2_over_c1", -self.posterior_mean_coef2 / self.posterior_mean_coef1))
+
+    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
+        """gd:362-366: (sqrt_recip_ac x_t - x_0) / sqrt_recipm1_ac."""
+        neg1 = ("neg_one", -np.ones_like(self.betas))
+        return self._lin(x_t, pred_xstart, t, ca=("sqrt_recip_ac", self.sqrt_recip_alphas_cumprod), cb=neg1,
+                         cs=("inv_sqrt_recipm1_ac", 1.0 / self.sqrt_recipm1_alphas_cumprod))
+
     def _flags(self, clip_denoised):
         return ((1 if clip_denoised else 0) | (2 if self.model_mean_type == ModelMeanType.START_X else 0) |
                 (4 if self.model_var_type == ModelVarType.LEARNED_RANGE else 0))
@@ -187,16 +253,198 @@ class GaussianDiffusion:
         """One ancestral step (gd:415-474).  Like the reference, the `noise` argument is ignored and fresh N(0,1)
         noise is drawn for both streams (video first), also at t == 0."""
         if cond_fn is not None or denoised_fn is not None:
-            raise NotImplementedError("cond_fn / denoised_fn (zero-shot conditional sampling) are not built (SURVEY 8f4)")
+            raise NotImplementedError("cond_fn / denoised_fn: the reference's condition_mean raises for the multimodal dict "
+                                      "(gd:385 calls dict.float()); not built")
         model_kwargs = model_kwargs or {}
         video_output, audio_output = model(x["video"], x["audio"], self._scale_timesteps(t), **model_kwargs)
         noise = {"video": self._randn_like(x["video"]), "audio": self._randn_like(x["audio"])}
         res = {"sample": {}, "pred_start": {}, "pred_noise": {"video": video_output, "audio": audio_output}}
+        differentiable = th.is_grad_enabled() and any(v.requires_grad for v in (video_output, audio_output, x["video"], x["audio"]))
         for key, mo in (("video", video_output), ("audio", audio_output)):
+            if differentiable:          # gradient-guided conditional sampling differentiates the step (gd:795-817)
+                from .train_ops import DdpmUpdateFn
+                tab, _ = self.device_tables(x[key].device)
+                s_, x0_ = DdpmUpdateFn.apply(x[key].float(), mo.float(), noise[key].float().contiguous(), tab,
+                                             t.to(th.int64).contiguous(), self._flags(clip_denoised), _geom(x[key]))
+                res["sample"][key], res["pred_start"][key] = s_, x0_
+                continue
             r = self._update(key, mo, x[key], t, clip_denoised, noise=noise[key].float().contiguous(),
                              want=("sample", "pred_xstart"))
             res["sample"][key], res["pred_start"][key] = r["sample"], r["pred_xstart"]
         return res
+
+    # ------------------------------------------------------------------ DDIM
+    def _ddim(self, model, x, t, clip_denoised, model_kwargs, eta, reverse):
+        video_output, audio_output = model(x["video"], x["audio"], self._scale_timesteps(t), **(model_kwargs or {}))
+        res = {"sample": {}, "pred_xstart": {}}
+        flags = self._flags(clip_denoised) | (8 if reverse else 0)
+        for key, mo in (("video", video_output), ("audio", audio_output)):
+            tab, _ = self.device_tables(x[key].device)
+            F, C, HW = _geom(x[key])
+            xs = x[key].float().contiguous()
+            noise = None if reverse else self._randn_like(xs).float().contiguous()      # drawn even when eta == 0 (gd:876-877)
+            out, x0 = th.empty_like(xs), th.empty_like(xs)
+            ops.ddim_update(xs, mo.float().contiguous(), noise, out, tab, self.ddim_tables(xs.device), t.to(th.int64).contiguous(),
+                            F, C, HW, flags, eta, x0_out=x0)
+            res["sample"][key], res["pred_xstart"][key] = out, x0
+        return res
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        """One DDIM step (gd:821-901): eps re-derived from the (clipped) x_0 prediction; noise drawn video first."""
+        if cond_fn is not None or denoised_fn is not None:
+            raise NotImplementedError("cond_fn / denoised_fn: the reference's condition_score raises for the multimodal dict (gd:403)")
+        return self._ddim(model, x, t, clip_denoised, model_kwargs, eta, False)
+
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        """DDIM reverse ODE step x_t -> x_{t+1} (gd:903-953).  The reference indexes its own result dict the wrong way
+        round (`out["video"]["pred_xstart"]`, gd:925) and raises KeyError; this computes the intended update."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        if denoised_fn is not None:
+            raise NotImplementedError("denoised_fn is not supported by the fused update kernel")
+        return self._ddim(model, x, t, clip_denoised, model_kwargs, 0.0, True)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                         device=None, progress=True, eta=0.0):
+        final = None
+        for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                                        cond_fn=cond_fn, model_kwargs=model_kwargs, device=device, progress=progress,
+                                                        eta=eta):
+            final = sample
+        return final
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0, use_graph=True):
+        """gd:989-1046 (the `noise` argument is ignored there too: x_T is always drawn on the CPU, video then audio)."""
+        if cond_fn is not None or denoised_fn is not None:
+            raise NotImplementedError("cond_fn / denoised_fn: see ddim_sample")
+        device = self._sampling_device(device)
+        x = {"video": th.randn(*shape["video"], device="cpu").to(device), "audio": th.randn(*shape["audio"], device="cpu").to(device)}
+        indices = self._indices(progress)
+        from .sampler import GraphStepper, unwrap_unet
+        unet = unwrap_unet(model)
+        if use_graph and unet is not None and not (model_kwargs or {}):
+            stepper = GraphStepper(self, unet, shape["video"][0], device, clip_denoised, update="ddim", eta=eta)
+            stepper.load(x["video"], x["audio"])
+            for i in indices:
+                stepper.step(i)
+                yield stepper.current()
+            return
+        for i in indices:
+            t = th.tensor([i] * shape["video"][0], device=device)
+            with th.no_grad():
+                out = self.ddim_sample(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta)
+            yield out["sample"]
+            x = out["sample"]
+
+    # ------------------------------------------------------------------ zero-shot conditional sampling (gd:584-819)
+    def _sampling_device(self, device):
+        if device is None:
+            from . import dist_util
+            device = dist_util.dev()
+        if th.device(device).type != "cuda":
+            raise H.MMDError("sampling runs on the MI355X HIP path only (device must be a GPU); no CPU fallback")
+        return device
+
+    def _indices(self, progress):
+        indices = list(range(self.num_timesteps))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        return indices
+
+    def conditional_p_sample_loop(self, model, shape, use_fp16, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=True, class_scale=0.):
+        """class_scale == 0: replacement method; otherwise the gradient-guided method (gd:584-640)."""
+        fn = self.conditional_p_sample_loop_progressive_unscale if class_scale == 0 else self.conditional_p_sample_loop_progressive_scale
+        final = None
+        for sample in fn(model, shape, use_fp16, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                         model_kwargs=model_kwargs, device=device, progress=progress, class_scale=class_scale):
+            final = sample
+        return final
+
+    def _cond_setup(self, shape, noise, model_kwargs, device):
+        device = self._sampling_device(device)
+        if noise is None:
+            noise = {"video": th.randn(*shape["video"], device="cpu").to(device), "audio": th.randn(*shape["audio"], device="cpu").to(device)}
+        model_kwargs = model_kwargs if model_kwargs is not None else {}
+        cond = {k: model_kwargs.pop(k) for k in ("video", "audio") if k in model_kwargs}     # popped like gd:687-691
+        return device, noise, model_kwargs, cond
+
+    def conditional_p_sample_loop_progressive_unscale(self, model, shape, use_fp16, noise=None, clip_denoised=True, denoised_fn=None,
+                                                      cond_fn=None, model_kwargs=None, device=None, progress=False, class_scale=0.0,
+                                                      use_graph=True):
+        """Replacement method (gd:642-720): before every step the conditioning stream is overwritten with
+        q_sample(condition, t, noise=<the fixed initial noise of that stream>); then one ordinary p_sample."""
+        if cond_fn is not None or denoised_fn is not None:
+            raise NotImplementedError("cond_fn / denoised_fn: see p_sample")
+        device, noise, model_kwargs, cond = self._cond_setup(shape, noise, model_kwargs, device)
+        x = dict(noise)
+        B = shape["video"][0]
+        from .sampler import GraphStepper, unwrap_unet
+        unet = unwrap_unet(model)
+        stepper = None
+        if use_graph and unet is not None and not model_kwargs:
+            stepper = GraphStepper(self, unet, B, device, clip_denoised)
+            stepper.load(x["video"], x["audio"])
+        for i in self._indices(progress):
+            t = th.tensor([i] * B, device=device)
+            for k in ("video", "audio"):
+                if k in cond:
+                    x[k] = self.q_sample(cond[k], t, noise=noise[k])
+                    if stepper is not None:
+                        (stepper.eng.x_video if k == "video" else stepper.eng.x_audio).copy_(x[k])
+            if stepper is not None:
+                stepper.step(i)
+                x = stepper.current()
+            else:
+                with th.no_grad():
+                    x = self.p_sample(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)["sample"]
+            yield x
+
+    def conditional_p_sample_loop_progressive_scale(self, model, shape, use_fp16, noise=None, clip_denoised=True, denoised_fn=None,
+                                                    cond_fn=None, model_kwargs=None, device=None, progress=False, class_scale=3.0):
+        """Gradient-guided method (gd:722-817).  Per step: replace the conditioning stream at t, take one differentiable
+        p_sample, loss = mean_flat((sample[cond] - q_sample(cond, t-1))^2).mean() (x 2^20 when use_fp16, never unscaled -
+        as in the reference), and move the target stream against d loss / d x_t[target] scaled by
+        class_scale * sqrt_alphas_cumprod[i].  The U-Net backward w.r.t. its input runs on the HIP training kernels."""
+        if cond_fn is not None or denoised_fn is not None:
+            raise NotImplementedError("cond_fn / denoised_fn: see p_sample")
+        device, noise, model_kwargs, cond = self._cond_setup(shape, noise, model_kwargs, device)
+        if not cond:
+            raise UnboundLocalError("conditional sampling needs model_kwargs['video'] or model_kwargs['audio'] (gd:776-786)")
+        x = dict(noise)
+        B = shape["video"][0]
+        from .sampler import unwrap_unet
+        unet = unwrap_unet(model)
+        frozen = [p for p in unet.parameters() if p.requires_grad] if unet is not None else []
+        for p in frozen:                 # only d/dx is needed: skip every weight-gradient kernel
+            p.requires_grad_(False)
+        try:
+            yield from self._guided_steps(model, x, noise, cond, B, device, use_fp16, clip_denoised, model_kwargs, progress, class_scale)
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+
+    def _guided_steps(self, model, x, noise, cond, B, device, use_fp16, clip_denoised, model_kwargs, progress, class_scale):
+        for i in self._indices(progress):
+            t = th.tensor([i] * B, device=device)
+            for k, other in (("video", "audio"), ("audio", "video")):
+                if k in cond:
+                    condition, target = k, other
+                    x[condition] = self.q_sample(cond[k], t, noise=noise[condition])
+                    # at i == 0 the reference indexes its tables with t - 1 == -1, i.e. the LAST entry (gd:779,785)
+                    previous_step_condition = self.q_sample(cond[k], (t - 1) % self.num_timesteps, noise=noise[condition])
+            with th.enable_grad():
+                none_zero_mask = (t != 0).float().view(-1, *([1] * (len(x[target].shape) - 1)))
+                x[target] = x[target].detach().requires_grad_()
+                out = self.p_sample(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+                pred = out["sample"]
+                loss = mean_flat((pred[condition] - previous_step_condition) ** 2)
+                loss_scale = 2 ** 20 if use_fp16 == True else 1.       # noqa: E712 (reference compares with ==)
+                grad = th.autograd.grad(loss.mean() * loss_scale, x[target])[0]
+                x = {condition: x[condition], target: (pred[target] - none_zero_mask * grad * class_scale *
+                                                       float(self.sqrt_alphas_cumprod[i])).detach()}
+            yield x
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=True):
@@ -212,12 +460,8 @@ class GaussianDiffusion:
         """gd:523-582.  x_T is drawn on the CPU (video, then audio) and moved to the device like the reference;
         every step then replays one captured hipGraph (U-Net plan + both fused updates)."""
         if cond_fn is not None or denoised_fn is not None:
-            raise NotImplementedError("cond_fn / denoised_fn are not built (SURVEY 8f4)")
-        if device is None:
-            from . import dist_util
-            device = dist_util.dev()
-        if th.device(device).type != "cuda":
-            raise H.MMDError("sampling runs on the MI355X HIP path only (device must be a GPU); no CPU fallback")
+            raise NotImplementedError("cond_fn / denoised_fn: see p_sample")
+        device = self._sampling_device(device)
         video = th.randn(*shape["video"], device="cpu").to(device)
         audio = th.randn(*shape["audio"], device="cpu").to(device)
         x = {"video": video, "audio": audio}

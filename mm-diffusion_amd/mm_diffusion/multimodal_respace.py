@@ -55,6 +55,9 @@ class SpacedDiffusion(GaussianDiffusion):
     def p_sample(self, model, *args, **kwargs):
         return super().p_sample(self._wrap_model(model), *args, **kwargs)
 
+    def _ddim(self, model, *args, **kwargs):          # ddim_sample / ddim_reverse_sample reach the model through here
+        return super()._ddim(self._wrap_model(model), *args, **kwargs)
+
     def multimodal_training_losses(self, model, *args, **kwargs):
         return super().multimodal_training_losses(self._wrap_model(model), *args, **kwargs)
 

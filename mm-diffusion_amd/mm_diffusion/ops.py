@@ -323,6 +323,37 @@ def ddpm_update(x, model_out, noise, out, tables, t, F, C, HW, flags, x0_out=Non
     return out
 
 
+def ddim_update(x, model_out, noise, out, tables, tab3, t, F, C, HW, flags, eta, x0_out=None):
+    H.require_cuda(x, model_out, tables, tab3, t)
+    _dispatch("mmd_ddim_update", x.data_ptr(), model_out.data_ptr(), H.ptr(noise), H.ptr(out), H.ptr(x0_out), tables.data_ptr(),
+              tab3.data_ptr(), t.data_ptr(), tables.shape[1], x.shape[0], F, C, HW, flags, float(eta),
+              meta=("ddim_update", 0, 16 * x.numel()))
+    return out
+
+
+def lincomb_t(a, b, out, ca, cb, cs, t):
+    """out[n] = (ca[t_n] a[n] + cb[t_n] b[n]) cs[t_n] (None table = 1, b may be None); fp32 contiguous tensors."""
+    H.require_cuda(a, out, t)
+    _dispatch("mmd_lincomb_t", a.data_ptr(), H.ptr(b), out.data_ptr(), H.ptr(ca), H.ptr(cb), H.ptr(cs), t.data_ptr(), a.shape[0],
+              a[0].numel(), meta=("lincomb_t", 0, 12 * a.numel()))
+    return out
+
+
+def lincomb(a, ca, b=None, cb=0.0, c=None, cc=0.0, out=None):
+    """out = ca a + cb b + cc c with host scalars; fp32 contiguous tensors of one size."""
+    H.require_cuda(a)
+    out = torch.empty_like(a) if out is None else out
+    _dispatch("mmd_lincomb", a.data_ptr(), float(ca), H.ptr(b), float(cb), H.ptr(c), float(cc), out.data_ptr(), a.numel(),
+              meta=("lincomb", 0, 16 * a.numel()))
+    return out
+
+
+def ddpm_update_bwd(x, model_out, dsample, dx, dmo, tables, t, flags):
+    H.require_cuda(x, model_out, dsample, tables, t)
+    _dispatch("mmd_ddpm_update_bwd", x.data_ptr(), model_out.data_ptr(), dsample.data_ptr(), H.ptr(dx), H.ptr(dmo), tables.data_ptr(),
+              t.data_ptr(), tables.shape[1], x.shape[0], x[0].numel(), flags, meta=("ddpm_update_bwd", 0, 20 * x.numel()))
+
+
 def q_sample(x0, eps, out, tab2, t):
     H.require_cuda(x0, eps, out, tab2, t)
     _dispatch("mmd_q_sample", x0.data_ptr(), eps.data_ptr(), out.data_ptr(), tab2.data_ptr(), t.data_ptr(), tab2.shape[1],

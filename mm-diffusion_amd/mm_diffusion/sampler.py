@@ -23,7 +23,7 @@ def unwrap_unet(model):
 
 
 class GraphStepper:
-    def __init__(self, diffusion, unet, batch, device, clip_denoised=True, use_graph=True):
+    def __init__(self, diffusion, unet, batch, device, clip_denoised=True, use_graph=True, update="ddpm", eta=0.0):
         self.diff, self.unet, self.N = diffusion, unet, int(batch)
         self.device = th.device(device)
         self.eng = unet.engine(self.N, self.device)
@@ -44,9 +44,15 @@ class GraphStepper:
         with ops.recording(self.update_plan):
             # in place: x_{t-1} overwrites x_t (purely elementwise); each update rides its own stream, then join
             ops.cur_sid = 0
-            ops.ddpm_update(e.x_video, e.out_video, self.noise_v, e.x_video, self.tab, self.t_idx, F, C, HW, self.flags)
-            ops.cur_sid = 1
-            ops.ddpm_update(e.x_audio, e.out_audio, self.noise_a, e.x_audio, self.tab, self.t_idx, 1, e.Ca_in, e.L0, self.flags)
+            if update == "ddim":       # ddim_sample (gd:821-901): same graph, different fused update
+                tab3 = diffusion.ddim_tables(self.device)
+                ops.ddim_update(e.x_video, e.out_video, self.noise_v, e.x_video, self.tab, tab3, self.t_idx, F, C, HW, self.flags, eta)
+                ops.cur_sid = 1
+                ops.ddim_update(e.x_audio, e.out_audio, self.noise_a, e.x_audio, self.tab, tab3, self.t_idx, 1, e.Ca_in, e.L0, self.flags, eta)
+            else:
+                ops.ddpm_update(e.x_video, e.out_video, self.noise_v, e.x_video, self.tab, self.t_idx, F, C, HW, self.flags)
+                ops.cur_sid = 1
+                ops.ddpm_update(e.x_audio, e.out_audio, self.noise_a, e.x_audio, self.tab, self.t_idx, 1, e.Ca_in, e.L0, self.flags)
             ops.cur_sid = 0
             ops.record_sync(1, 0)
         self.graph = None

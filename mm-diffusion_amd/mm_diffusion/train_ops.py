@@ -42,6 +42,8 @@ class ConvFn(Function):
         if ctx.needs_input_grad[0]:
             wt = weight.detach().float().reshape(Cout, Cin, nt).permute(1, 2, 0).reshape(Cin, nt * Cout).to(x.dtype).contiguous()
             dx = ops.conv_gemm(dy, wt, None, taps=_neg(taps), dims=dims)
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):      # frozen weights (gradient-guided sampling)
+            return dx, None, None, (dy if ctx.has_res else None), None, None
         dW32 = torch.zeros(Cout, nt * Cin, dtype=torch.float32, device=x.device)
         db32 = torch.zeros(Cout, dtype=torch.float32, device=x.device)
         ops.conv_wgrad(dy, x, dW32, db32, taps, dims)
@@ -279,6 +281,32 @@ class MseLossFn(Function):
         return g, None
 
 
+class DdpmUpdateFn(Function):
+    """Differentiable p_sample update of one stream (gd:231-343,415-474; fixed variance): returns (sample, pred_xstart);
+    gradients flow through the posterior mean to x_t and to the model output (mmd_ddpm_update_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, mo, noise, tab, t, flags, geom):
+        if flags & 4:
+            raise NotImplementedError("gradient-guided sampling with learned variance is not built")
+        x, mo = x.contiguous(), mo.contiguous()
+        F, C, HW = geom
+        sample, x0 = torch.empty_like(x), torch.empty_like(x)
+        ops.ddpm_update(x, mo, noise, sample, tab, t, F, C, HW, flags, x0_out=x0)
+        ctx.save_for_backward(x, mo, tab, t)
+        ctx.flags = flags
+        ctx.mark_non_differentiable(x0)
+        return sample, x0
+
+    @staticmethod
+    def backward(ctx, dsample, _dx0):
+        x, mo, tab, t = ctx.saved_tensors
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dmo = torch.empty_like(mo) if ctx.needs_input_grad[1] else None
+        ops.ddpm_update_bwd(x, mo, dsample.float().contiguous(), dx, dmo, tab, t, ctx.flags)
+        return dx, dmo, None, None, None, None, None
+
+
 class DropoutFn(Function):
     """nn.Dropout(p) (reference unet:376,384): the Bernoulli mask is drawn by torch's generator (noise input), the scaling
     runs in libmmd; backward re-applies the same mask."""
@@ -316,8 +344,15 @@ class RecomputeFn(Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        ins = [x.detach().requires_grad_(True) for x in ctx.inputs]
+        need = ctx.needs_input_grad[2:]
+        n_in = len(ctx.inputs)
+        ins = [x.detach().requires_grad_(bool(need[i])) for i, x in enumerate(ctx.inputs)]
         with torch.enable_grad():
             outs = ctx.run(*ins)
-        grads = torch.autograd.grad(outs, ins + ctx.params, gouts, allow_unused=True)
+        cand = ins + ctx.params
+        wrt = [t for i, t in enumerate(cand) if need[i]]          # frozen parameters / constant inputs are skipped
+        pairs = [(o, g) for o, g in zip(outs, gouts) if o.requires_grad and g is not None]
+        got = iter(torch.autograd.grad([o for o, _ in pairs], wrt, [g for _, g in pairs], allow_unused=True))
+        grads = tuple(next(got) if need[i] else None for i in range(len(cand)))
+        assert len(grads) == n_in + len(ctx.params)
         return (None, None) + grads

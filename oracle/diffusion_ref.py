@@ -5,7 +5,8 @@ timestep respacing, the DDPM ancestral step (p_mean_variance + p_sample), the sa
 q_sample and the training loss.  fp64 numpy tables, fp32 torch arithmetic - like the reference.
 
 Parity status: PINNED against fixtures captured from the imported reference
-(tests/golden/tables.npz, space_timesteps.json, *_psample*.npz, *_train_loss.npz).
+(tests/golden/tables.npz, space_timesteps.json, *_psample*.npz, *_train_loss.npz, *_ddim*.npz,
+*_cond_*_replace*.npz, helpers.npz).
 
 Follows (relative to /root/reference/mm_diffusion):
   multimodal_gaussian_diffusion.py:17-61     get_named_beta_schedule / betas_for_alpha_bar
@@ -15,6 +16,10 @@ Follows (relative to /root/reference/mm_diffusion):
   multimodal_gaussian_diffusion.py:415-474   p_sample
   multimodal_gaussian_diffusion.py:523-582   p_sample_loop_progressive
   multimodal_gaussian_diffusion.py:1048-1092 _vb_terms_bpd ; 1114-1203 multimodal_training_losses
+  multimodal_gaussian_diffusion.py:170-229,345-366  q_mean_variance / q_posterior_mean_variance / _predict_* helpers
+  multimodal_gaussian_diffusion.py:821-901,955-1046 ddim_sample / ddim_sample_loop
+  multimodal_gaussian_diffusion.py:642-720   conditional_p_sample_loop (replacement method; the gradient-guided method
+                                             gd:722-817 is pinned by reference-generated goldens only, not restated here)
   multimodal_respace.py:6-59, 71-86, 127-139 space_timesteps / SpacedDiffusion / _WrappedModel
   losses.py:12-77                             normal_kl / discretized_gaussian_log_likelihood
 """
@@ -144,6 +149,68 @@ def p_sample_loop(S: Schedule, model, shape, clip=True):
     for i in reversed(range(S.T)):
         x = p_sample(S, model, x, torch.tensor([i] * B), clip)
     return x
+
+
+@torch.no_grad()
+def ddim_sample(S: Schedule, model, x, t, eta=0.0, clip=True):
+    """gd:821-901: eps is re-derived from the clipped x0; per-stream noise is drawn (video first) even when eta == 0."""
+    vo, ao = model(x["video"], x["audio"], S.model_t(t))
+    pre = {}
+    for key, o, cdim in (("video", vo, 2), ("audio", ao, 1)):
+        pre[key] = p_mean_variance(S, o.float(), x[key], t, cdim, clip)[2]
+    noise = {"video": torch.randn_like(x["video"]), "audio": torch.randn_like(x["audio"])}
+    res = {}
+    for key in ("video", "audio"):
+        nd = x[key].dim()
+        x0 = pre[key]
+        eps = (_ext(S.sqrt_recip_ac, t, nd) * x[key] - x0) / _ext(S.sqrt_recipm1_ac, t, nd)
+        ab, ap = _ext(S.alphas_cumprod, t, nd), _ext(S.alphas_cumprod_prev, t, nd)
+        sigma = eta * torch.sqrt((1 - ap) / (1 - ab)) * torch.sqrt(1 - ab / ap)
+        mean = x0 * torch.sqrt(ap) + torch.sqrt(1 - ap - sigma ** 2) * eps
+        nz = (t != 0).float().reshape(-1, *([1] * (nd - 1)))
+        res[key] = mean + nz * sigma * noise[key]
+    return res
+
+
+@torch.no_grad()
+def ddim_sample_loop(S: Schedule, model, shape, eta=0.0, clip=True):
+    x = {"video": torch.randn(*shape["video"]), "audio": torch.randn(*shape["audio"])}
+    B = shape["video"][0]
+    for i in reversed(range(S.T)):
+        x = ddim_sample(S, model, x, torch.tensor([i] * B), eta, clip)
+    return x
+
+
+@torch.no_grad()
+def cond_replace_loop(S: Schedule, model, shape, cond, clip=True):
+    """Replacement-method zero-shot conditional sampling (gd:642-720): cond = {"video": x0} or {"audio": x0}."""
+    noise = {"video": torch.randn(*shape["video"]), "audio": torch.randn(*shape["audio"])}
+    x = dict(noise)
+    B = shape["video"][0]
+    for i in reversed(range(S.T)):
+        t = torch.tensor([i] * B)
+        for k in cond:
+            x[k] = q_sample(S, cond[k], t, noise[k])
+        x = p_sample(S, model, x, t, clip)
+    return x
+
+
+def q_posterior(S: Schedule, x0, xt, t):
+    nd = x0.dim()
+    return (_ext(S.post_c1, t, nd) * x0 + _ext(S.post_c2, t, nd) * xt, _ext(S.post_var, t, nd).expand(x0.shape),
+            _ext(S.post_logvar_clipped, t, nd).expand(x0.shape))
+
+
+def predict_xstart_from_eps(S: Schedule, xt, t, eps):
+    return _ext(S.sqrt_recip_ac, t, xt.dim()) * xt - _ext(S.sqrt_recipm1_ac, t, xt.dim()) * eps
+
+
+def predict_xstart_from_xprev(S: Schedule, xt, t, xprev):
+    return _ext(1.0 / S.post_c1, t, xt.dim()) * xprev - _ext(S.post_c2 / S.post_c1, t, xt.dim()) * xt
+
+
+def predict_eps_from_xstart(S: Schedule, xt, t, x0):
+    return (_ext(S.sqrt_recip_ac, t, xt.dim()) * xt - x0) / _ext(S.sqrt_recipm1_ac, t, xt.dim())
 
 
 def q_sample(S: Schedule, x0, t, noise):

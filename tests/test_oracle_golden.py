@@ -169,6 +169,42 @@ def test_psample_loop(tag, cfgname, keyset, resp, over):
     assert rel_l2(x["video"], g["video"]) < 1e-4 and rel_l2(x["audio"], g["audio"]) < 1e-4
 
 
+@pytest.mark.parametrize("tag,resp,eta", [("tiny_ddim4_eta00", "4", 0.0), ("tiny_ddim4_eta05", "4", 0.5)])
+def test_ddim_loop(tag, resp, eta):
+    g = gold(tag)
+    fl = flags("tiny")
+    B = int(g["B"])
+    S = dref.Schedule(respacing=resp)
+    model = uref.OracleModel(synth_sd("tiny"), fl, shifts=list(g["shifts"]))
+    torch.manual_seed(int(g["seed"]))
+    x = dref.ddim_sample_loop(S, model, {"video": (B, *fl["video_size"]), "audio": (B, *fl["audio_size"])}, eta=eta)
+    assert rel_l2(x["video"], g["video"]) < 2e-4 and rel_l2(x["audio"], g["audio"]) < 2e-4
+
+
+def test_conditional_replacement_loop():
+    g = gold("tiny_cond_video_replace4")
+    fl = flags("tiny")
+    B = int(g["B"])
+    S = dref.Schedule(respacing="4")
+    model = uref.OracleModel(synth_sd("tiny"), fl, shifts=list(g["shifts"]))
+    torch.manual_seed(int(g["seed"]))
+    x = dref.cond_replace_loop(S, model, {"video": (B, *fl["video_size"]), "audio": (B, *fl["audio_size"])},
+                               {"video": torch.from_numpy(g["cond"])})
+    assert rel_l2(x["video"], g["video"]) < 2e-4 and rel_l2(x["audio"], g["audio"]) < 2e-4
+
+
+def test_posterior_and_predict_helpers():
+    g = gold("helpers")
+    S = dref.Schedule()
+    a, b, t = torch.from_numpy(g["a"]), torch.from_numpy(g["b"]), torch.from_numpy(g["t"])
+    pm, pv, plv = dref.q_posterior(S, a, b, t)
+    for got, key in ((pm, "post_mean"), (pv, "post_var"), (plv, "post_logvar"),
+                     (dref.predict_xstart_from_eps(S, a, t, b), "xstart_from_eps"),
+                     (dref.predict_xstart_from_xprev(S, a, t, b), "xstart_from_xprev"),
+                     (dref.predict_eps_from_xstart(S, a, t, b), "eps_from_xstart")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=1e-6)
+
+
 def test_full_config1_two_step():
     """BASELINE config[0]: Landscape base model, batch 1, 2-step DDPM on the CPU path."""
     g = gold("full_psample2")

@@ -271,6 +271,51 @@ def gen_train_loss(name, B, seed, **over):
          **{k: v for k, v in losses.items()}, **grads)
 
 
+def gen_ddim(name, B, seed, respacing, eta):
+    """ddim_sample_loop (gd:955-1046) final sample; the loop draws x_T and per-step noise even with eta = 0."""
+    f = flags(name, timestep_respacing=respacing)
+    model, diff = msu.create_model_and_diffusion(**f)
+    synth_init(model).eval()
+    shape = {"video": (B, *f["video_size"]), "audio": (B, *f["audio_size"])}
+    th.manual_seed(seed)
+    random.seed(seed)
+    with ShiftRecorder() as rec:
+        sample = diff.ddim_sample_loop(model, shape=shape, device=th.device("cpu"), progress=False, clip_denoised=True, eta=eta)
+    save(f"{name}_ddim{respacing}_eta{int(eta * 10):02d}", seed=seed, B=B, eta=eta, shifts=np.asarray(rec.draws),
+         video=sample["video"], audio=sample["audio"])
+
+
+def gen_cond(name, B, seed, respacing, which, class_scale):
+    """conditional_p_sample_loop (gd:584-819): replacement (class_scale 0) or gradient-guided sampling given one stream."""
+    f = flags(name, timestep_respacing=respacing)
+    model, diff = msu.create_model_and_diffusion(**f)
+    synth_init(model).eval()
+    shape = {"video": (B, *f["video_size"]), "audio": (B, *f["audio_size"])}
+    g = th.Generator().manual_seed(seed + 1000)
+    cond = th.rand(*shape[which], generator=g) * 2 - 1
+    th.manual_seed(seed)
+    random.seed(seed)
+    with ShiftRecorder() as rec:
+        sample = diff.conditional_p_sample_loop(model, shape=shape, use_fp16=False, model_kwargs={which: cond.clone()},
+                                                device=th.device("cpu"), progress=False, clip_denoised=True, class_scale=class_scale)
+    save(f"{name}_cond_{which}_{'guided' if class_scale else 'replace'}{respacing}", seed=seed, B=B, class_scale=class_scale,
+         shifts=np.asarray(rec.draws), cond=cond, video=sample["video"].detach(), audio=sample["audio"].detach())
+
+
+def gen_helpers():
+    """q_mean_variance / q_posterior_mean_variance / _predict_* (gd:170-229,345-366) on random inputs."""
+    f = flags("tiny", timestep_respacing="")
+    _, diff = msu.create_model_and_diffusion(**f)
+    g = th.Generator().manual_seed(77)
+    a, b = th.randn(3, 4, 5, generator=g), th.randn(3, 4, 5, generator=g)
+    t = th.tensor([0, 500, 999])
+    qm, qv, qlv = diff.q_mean_variance(a, t)
+    pm, pv, plv = diff.q_posterior_mean_variance(a, b, t)
+    save("helpers", a=a, b=b, t=t, q_mean=qm, q_var=qv, q_logvar=qlv, post_mean=pm, post_var=pv, post_logvar=plv,
+         xstart_from_eps=diff._predict_xstart_from_eps(a, t, b), xstart_from_xprev=diff._predict_xstart_from_xprev(a, t, b),
+         eps_from_xstart=diff._predict_eps_from_xstart(a, t, b))
+
+
 ALL = {
     "tables": gen_tables,
     "keys": gen_keys,
@@ -282,6 +327,12 @@ ALL = {
     "tiny_psample4": lambda: gen_psample("tiny", 1, 22, "4"),
     "tiny_ls_psample": lambda: gen_psample("tiny", 2, 23, "2", learn_sigma=True),
     "full_psample": lambda: gen_psample("full", 1, 0, "2"),
+    "tiny_ddim_eta0": lambda: gen_ddim("tiny", 2, 41, "4", 0.0),
+    "tiny_ddim_eta5": lambda: gen_ddim("tiny", 1, 42, "4", 0.5),
+    "tiny_cond_replace": lambda: gen_cond("tiny", 2, 51, "4", "video", 0.0),
+    "tiny_cond_guided_v": lambda: gen_cond("tiny", 1, 52, "4", "video", 3.0),
+    "tiny_cond_guided_a": lambda: gen_cond("tiny", 1, 53, "2", "audio", 3.0),
+    "helpers": gen_helpers,
     "tiny_train_loss": lambda: gen_train_loss("tiny", 2, 31),
     "tiny_ls_train_loss": lambda: gen_train_loss("tiny", 2, 32, learn_sigma=True),
 }
