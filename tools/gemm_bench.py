@@ -23,7 +23,14 @@ SHAPES = [  # name, M, Cin, taps, dims, Cout, residual
     ("qkv ds4 384->1152", 16384, 384, ops.TAPS_1, (1, 1, 1), 1152, False),
     ("1x1 ds8 512->512", 4096, 512, ops.TAPS_1, (1, 1, 1), 512, True),
     ("audio k3 d4 128->128", 102400, 128, ops.taps_audio(4), (25600, 1, 1), 128, False),
+    ("proj ds2 256->256", 65536, 256, ops.TAPS_1, (1, 1, 1), 256, False),
+    ("proj ds4 384->384 +res", 16384, 384, ops.TAPS_1, (1, 1, 1), 384, True),
+    ("skip ds1 384->128", 262144, 384, ops.TAPS_1, (1, 1, 1), 128, False),
+    ("skip ds2 768->256", 65536, 768, ops.TAPS_1, (1, 1, 1), 256, False),
+    ("qkv ds8 512->1536", 4096, 512, ops.TAPS_1, (1, 1, 1), 1536, False),
+    ("audio qkv 256->768", 25600, 256, ops.TAPS_1, (1, 1, 1), 768, False),
 ]
+TILES = (128, 129, 130, 131)
 
 
 def main():
@@ -42,7 +49,7 @@ def main():
         nbytes = 2 * (M * Cin + M * Cout * (2 if res else 1) + Cout * Cin * len(taps))
         ref = None
         line = f"{name:26s} M={M:6d} K={Cin*len(taps):5d} N={Cout:4d}"
-        for tile in (64, 128, 129):
+        for tile in TILES:
             y = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile)
             if ref is None:
                 ref = y.clone()
