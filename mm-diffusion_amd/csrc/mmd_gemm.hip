@@ -15,8 +15,6 @@
 // The weights are the MFMA A operand (D rows = co) so each lane owns 4 consecutive output channels;
 // the accumulators are staged through LDS in fp32 and written with 16-byte coalesced row stores with
 // bias and residual folded in.
-#include <type_traits>
-
 #include "mmd_common.h"
 
 struct ConvGemmParams {
@@ -474,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
   __syncthreads();
   int cur = 0;
   for (int it = 0; it + 1 < nit; ++it) {
-#ifndef GEMM_ABLATE_NODMA
+#ifndef GEMM_ABLATE_NODMA                                   // ablation builds (tools/gemm_bench.py): compute-only / DMA-only loops
     advance();
     issue(cur ^ 1);                                      // DMA of the next K step runs under this step's MFMAs
 #endif
@@ -539,489 +537,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 256(m) x 128(co) direct-to-LDS variant: 512 threads = 8 waves in a 4(m) x 2(co) grid, each wave the same 64x64 block as
-// above.  One K step moves 48 KB for twice the MFMA work of the 128x128 tile (0.75x the L2->LDS bytes per flop), which is
-// what bounds the wide layers (M >= 65536) - their 128x128 tiles already sit at ~11 TB/s of L2->LDS fill.
-template <typename T>
-__global__ __launch_bounds__(512, 1) void conv_gemm_glds256_kernel(const ConvGemmParams p) {
-  constexpr int BM = 256, BN = 128;
-  constexpr int EPV = Elt<T>::EPV;
-  constexpr int ES = 16 / EPV;
-  constexpr int LDC = BN + 4;
-  constexpr int TA_B = BM * 128, TW_B = BN * 128, STAGE_B = TA_B + TW_B;
-  constexpr int MAIN_B = (2 * STAGE_B > BM * LDC * 4) ? 2 * STAGE_B : BM * LDC * 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sC = (float*)smem;
-  int* s_taps = (int*)(smem + MAIN_B);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wr = wave >> 1;
-  const int half = lane >> 5, l31 = lane & 31;
-  if (tid < p.ntaps * 3) s_taps[tid] = p.taps[tid];
-
-  const int Nt = (p.Cout + BN - 1) / BN;
-  int wgid;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nt = wgid % Nt, mt = wgid / Nt;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int CinV = p.Cin / EPV;
-  const int KV = CinV * p.ntaps;
-  const int64_t K = (int64_t)p.Cin * p.ntaps;
-  const int nit = (KV + 7) >> 3;
-  const int D12 = p.D1 * p.D2;
-
-  const int lrow = lane >> 3, pc = lane & 7;
-  const int c_par[2] = {pc ^ (lane >> 4), pc ^ (lane >> 4) ^ 4};
-  int tapP[2], civP[2], kvP[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) { tapP[q] = c_par[q] / CinV; civP[q] = c_par[q] % CinV; kvP[q] = c_par[q]; }
-  int pp0[4], pp1[4], pp2[4];
-  int64_t arow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wave * 32 + 8 * i + lrow;
-    arow[i] = (int64_t)m;
-    if (m < p.M) {
-      pp2[i] = m % p.D2;
-      pp1[i] = (m / p.D2) % p.D1;
-      pp0[i] = (m / D12) % p.D0;
-    } else {
-      pp0[i] = pp1[i] = pp2[i] = -(1 << 28);
-    }
-  }
-  // FAST path state: lane-constant pointers, uniform (tap, channel-chunk) cursor
-  const char* a_ptr[4];
-  const char* w_ptr[4];
-  bool w_ok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a_ptr[i] = p.A + (arow[i] * p.lda + (int64_t)c_par[i & 1] * EPV) * ES;
-    const int co = n0 + wave * 32 + 8 * i + lrow;
-    w_ok[i] = co < p.Cout;
-    w_ptr[i] = p.W + ((int64_t)(w_ok[i] ? co : 0) * K + (int64_t)c_par[i & 1] * EPV) * ES;
-  }
-  int u_tap = 0, u_civ = 0;                  // uniform: tap index and first 16-byte chunk of this K step inside the tap
-  __syncthreads();   // s_taps visible
-
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  auto issue = [&](int buf) {
-    int o0[2], o1[2], o2[2];
-    bool tapok[2];
-    int64_t roff[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      tapok[q] = tapP[q] < p.ntaps;
-      const int t3 = tapok[q] ? tapP[q] * 3 : 0;
-      o0[q] = s_taps[t3]; o1[q] = s_taps[t3 + 1]; o2[q] = s_taps[t3 + 2];
-      roff[q] = (int64_t)o0[q] * D12 + o1[q] * p.D2 + o2[q];
-    }
-    char* bA = smem + buf * STAGE_B;
-    char* bW = bA + TA_B;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {          // A: 32 rows per wave
-      const int q = i & 1;
-      const bool ok = tapok[q] && (unsigned)(pp0[i] + o0[q]) < (unsigned)p.D0 &&
-                      (unsigned)(pp1[i] + o1[q]) < (unsigned)p.D1 && (unsigned)(pp2[i] + o2[q]) < (unsigned)p.D2;
-      const char* src = ok ? p.A + ((arow[i] + roff[q]) * p.lda + (int64_t)civP[q] * EPV) * ES : (const char*)g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bA + (wave * 32 + 8 * i) * 128), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {          // W: 16 rows per wave (row groups 2*wave, 2*wave+1: parities 0, 1)
-      const int co = n0 + wave * 16 + 8 * i + lrow;
-      const char* src = (co < p.Cout && kvP[i] < KV) ? p.W + ((int64_t)co * K + (int64_t)kvP[i] * EPV) * ES : (const char*)g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bW + (wave * 16 + 8 * i) * 128), 16, 0, 0);
-    }
-  };
-  auto advance = [&]() {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      kvP[q] += 8;
-      civP[q] += 8;
-      while (civP[q] >= CinV) { civP[q] -= CinV; ++tapP[q]; }
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int xsw = (l31 >> 1) & 7;
-  auto compute = [&](int buf) {
-    const char* bA = smem + buf * STAGE_B + (wr * 64 + l31) * 128;
-    const char* bW = smem + buf * STAGE_B + TA_B + (wc * 64 + l31) * 128;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int phys = ((2 * c + half) ^ xsw) * 16;
-      u32x4 fw[2], fa[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) fw[a] = *(const u32x4*)(bW + a * 32 * 128 + phys);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) fa[b] = *(const u32x4*)(bA + b * 32 * 128 + phys);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
-    }
-  };
-
-  issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int it = 0; it < nit; ++it) {
-    if (it + 1 < nit) { advance(); issue(cur ^ 1); }
-    compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-  // epilogue: as gemm_epilogue, 512 threads
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int ml = wr * 64 + b * 32 + l31;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = wc * 64 + a * 32 + 8 * q + 4 * half;
-        f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-        *(f32x4*)(sC + ml * LDC + col) = v;
-      }
-    }
-  __syncthreads();
-  const int cg = tid % 16, rr = tid / 16;      // 16 channel groups of 8 per row, 32 rows per pass
-  const int co = n0 + cg * 8;
-  if (co < p.Cout) {
-    float bs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
-#pragma unroll 2
-    for (int ml = rr; ml < BM; ml += 32) {
-      const int m = m0 + ml;
-      if (m >= p.M) break;
-      float v[8];
-      const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + cg * 8);
-      const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + cg * 8 + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
-      if (p.R) {
-#pragma unroll
-        for (int h = 0; h < 8 / EPV; ++h) {
-          float rf[EPV];
-          Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
-#pragma unroll
-          for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 8 / EPV; ++h)
-        *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
-    }
-  }
-}
-
-template <typename T>
-static int launch_conv_gemm_glds256(const ConvGemmParams& p, hipStream_t st) {
-  const size_t lds = 256 * 132 * sizeof(float) + 336;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_glds256: set LDS attr: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  const int grid = cdiv(p.M, 256) * cdiv(p.Cout, 128);
-  hipLaunchKernelGGL((conv_gemm_glds256_kernel<T>), dim3(grid), dim3(512), lds, st, p);
-  return mmd_check_launch("conv_gemm_glds256");
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent "stream" variant of the direct-to-LDS kernel: one block per CU walks a contiguous run of output tiles and
-// treats (tile, K step) as ONE flat stage stream through a 3-deep LDS ring.  The DMA of the next tile's first stages is
-// issued under the current tile's last MFMAs and stays in flight across the epilogue, so the per-tile memory round
-// trips (first-stage latency, output stores) that bound the short-K pointwise convs (K = Cin <= 768: 4-12 stages) are
-// overlapped instead of serialised.  Waits are counted (s_waitcnt vmcnt(N), stores included - they share the counter on
-// gfx950) and the barrier is a raw s_barrier: a __syncthreads() fence would drain the DMAs in flight.
-// Epilogue: each wave stages its own 64x64 accumulator block through a private fp32 LDS slab (no block barrier) and
-// writes 64-byte row segments with bias / residual folded in.
-template <typename T, bool HAS_R>
-__global__ __launch_bounds__(256, 2) void conv_gemm_stream_kernel(const ConvGemmParams p, int tiles_per_block) {
-  constexpr int BM = 128, BN = 128, NS = 3;
-  constexpr int EPV = Elt<T>::EPV;
-  constexpr int ES = 16 / EPV;
-  constexpr int TILE_B = 128 * 128;
-  constexpr int STAGE_B = 2 * TILE_B;          // A tile | W tile
-  constexpr int LDE = 36;                      // floats per staged epilogue row (32 + pad)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sE = (float*)(smem + NS * STAGE_B);   // [4 waves][64][LDE]
-  int* s_taps = (int*)(smem + NS * STAGE_B + 4 * 64 * LDE * 4);
-  float* s_bias = (float*)(s_taps + 84);       // [Nt * 128] bias (zero padded): no vector-memory load in the epilogue
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wr = wave >> 1;
-  const int half = lane >> 5, l31 = lane & 31;
-  if (tid < p.ntaps * 3) s_taps[tid] = p.taps[tid];
-
-  const int Nt = (p.Cout + BN - 1) / BN, Mt = (p.M + BM - 1) / BM;
-  for (int c = tid; c < Nt * BN; c += 256) s_bias[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
-  const int ntiles = Nt * Mt;
-  int lid;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int t_begin = lid * tiles_per_block;
-  const int t_end = min(ntiles, t_begin + tiles_per_block);
-  if (t_begin >= t_end) return;
-
-  const int CinV = p.Cin / EPV;
-  const int KV = CinV * p.ntaps;
-  const int64_t K = (int64_t)p.Cin * p.ntaps;
-  const int nit = (KV + 7) >> 3;
-  const int D12 = p.D1 * p.D2;
-  const int G = (t_end - t_begin) * nit;
-
-  // ---- issue-side state (runs NS-1 stages ahead of the MFMAs)
-  const int lrow = lane >> 3, pc = lane & 7;
-  const int c_par[2] = {pc ^ (lane >> 4), pc ^ (lane >> 4) ^ 4};
-  int tapP[2], civP[2], kvP[2];
-  int pp0[4], pp1[4], pp2[4];
-  int64_t arow[4];
-  int i_tile = t_begin, i_k = 0, i_n0 = 0;
-  auto issue_tile = [&]() {
-    const int nt = i_tile % Nt, mt = i_tile / Nt;
-    i_n0 = nt * BN;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { tapP[q] = c_par[q] / CinV; civP[q] = c_par[q] % CinV; kvP[q] = c_par[q]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mt * BM + wave * 32 + 8 * i + lrow;
-      arow[i] = (int64_t)m;
-      if (m < p.M) {
-        pp2[i] = m % p.D2;
-        pp1[i] = (m / p.D2) % p.D1;
-        pp0[i] = (m / D12) % p.D0;
-      } else {
-        pp0[i] = pp1[i] = pp2[i] = -(1 << 28);
-      }
-    }
-  };
-  issue_tile();
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // s_taps visible
-
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  auto issue = [&](int buf) {
-    int o0[2], o1[2], o2[2];
-    bool tapok[2];
-    int64_t roff[2];
-    const bool live = i_tile < t_end;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      tapok[q] = live && tapP[q] < p.ntaps;
-      const int t3 = tapok[q] ? tapP[q] * 3 : 0;
-      o0[q] = s_taps[t3]; o1[q] = s_taps[t3 + 1]; o2[q] = s_taps[t3 + 2];
-      roff[q] = (int64_t)o0[q] * D12 + o1[q] * p.D2 + o2[q];
-    }
-    char* bA = smem + buf * STAGE_B;
-    char* bW = bA + TILE_B;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = i & 1;
-      const bool ok = tapok[q] && (unsigned)(pp0[i] + o0[q]) < (unsigned)p.D0 &&
-                      (unsigned)(pp1[i] + o1[q]) < (unsigned)p.D1 && (unsigned)(pp2[i] + o2[q]) < (unsigned)p.D2;
-      const char* src = ok ? p.A + ((arow[i] + roff[q]) * p.lda + (int64_t)civP[q] * EPV) * ES : (const char*)g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bA + (wave * 32 + 8 * i) * 128), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = i & 1;
-      const int co = i_n0 + wave * 32 + 8 * i + lrow;
-      const char* src = (live && co < p.Cout && kvP[q] < KV) ? p.W + ((int64_t)co * K + (int64_t)kvP[q] * EPV) * ES : (const char*)g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bW + (wave * 32 + 8 * i) * 128), 16, 0, 0);
-    }
-    // advance the issue cursor: next K step, or the first K step of the next tile
-    if (++i_k == nit) {
-      i_k = 0;
-      ++i_tile;
-      issue_tile();
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        kvP[q] += 8;
-        civP[q] += 8;
-        while (civP[q] >= CinV) { civP[q] -= CinV; ++tapP[q]; }
-      }
-    }
-  };
-
-  f32x16 acc[2][2];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  };
-  zero_acc();
-
-  const int xsw = (l31 >> 1) & 7;
-  auto compute = [&](int buf) {
-    const char* bA = smem + buf * STAGE_B + (wr * 64 + l31) * 128;
-    const char* bW = smem + buf * STAGE_B + TILE_B + (wc * 64 + l31) * 128;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int phys = ((2 * c + half) ^ xsw) * 16;
-      u32x4 fw[2], fa[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) fw[a] = *(const u32x4*)(bW + a * 32 * 128 + phys);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) fa[b] = *(const u32x4*)(bA + b * 32 * 128 + phys);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
-    }
-  };
-
-  float* myE = sE + wave * 64 * LDE;
-  // Residual rows of the tile are fetched into registers one K step ahead (BEFORE that step's DMAs are issued: loads
-  // return in order, so waiting for them later leaves the newer DMAs in flight).
-  u32x4 rres[2][4][8 / EPV];
-  auto prefetch_residual = [&](int tile) {
-    const int nt = tile % Nt, mt = tile / Nt;
-    const int mw = mt * BM + wr * 64, cw = nt * BN + wc * 64;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int m = mw + pass * 16 + (lane >> 2), co = cw + a * 32 + (lane & 3) * 8;
-        const bool ok = m < p.M && co < p.Cout;
-#pragma unroll
-        for (int h = 0; h < 8 / EPV; ++h)
-          rres[a][pass][h] = *(const u32x4*)(ok ? p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES : (const char*)g_zero_page);
-      }
-  };
-  // INTERIOR tiles issue exactly 8 stores per wave (counted by the stream waits); edge tiles are predicated.
-  auto epilogue = [&](int tile, auto interior_tag) {
-    constexpr bool INTERIOR = decltype(interior_tag)::value;
-    const int nt = tile % Nt, mt = tile / Nt;
-    const int mw = mt * BM + wr * 64, cw = nt * BN + wc * 64;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-          *(f32x4*)(myE + (b * 32 + l31) * LDE + 8 * q + 4 * half) = v;
-        }
-      const int cg = lane & 3;
-      const int co = cw + a * 32 + cg * 8;
-      const f32x4 b0 = *(const f32x4*)(s_bias + (co - 0)), b1 = *(const f32x4*)(s_bias + co + 4);
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int ml = pass * 16 + (lane >> 2);
-        const int m = mw + ml;
-        const f32x4 c0 = *(const f32x4*)(myE + ml * LDE + cg * 8);
-        const f32x4 c1 = *(const f32x4*)(myE + ml * LDE + cg * 8 + 4);
-        if (INTERIOR || (m < p.M && co < p.Cout)) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] = c0[j] + b0[j]; v[4 + j] = c1[j] + b1[j]; }
-          if (HAS_R) {
-#pragma unroll
-            for (int h = 0; h < 8 / EPV; ++h) {
-              float rf[EPV];
-              Elt<T>::unpack(rres[a][pass][h], rf);
-#pragma unroll
-              for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
-            }
-          }
-#pragma unroll
-          for (int h = 0; h < 8 / EPV; ++h)
-            *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
-        }
-      }
-    }
-  };
-  constexpr int NST = 8 * (8 / EPV);            // stores per wave of an interior epilogue
-
-  // Every step issues exactly 8 DMAs per wave (dead stages past the end of this block's run read the zero page), so the
-  // counted waits and the compiler's own scoreboard for the residual registers see a fixed instruction count.
-  auto stage_wait = [&](int stores) {           // stage g landed: at most (next stage's 8 DMAs + counted stores) outstanding
-    if (stores >= 2 * NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * NST) : "memory");
-    else if (stores >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  issue(0);
-  issue(1);
-  int g = 0;
-  int st1 = 0, st2 = 0;                         // counted stores issued after I(g-1) / after I(g-2)
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    for (int k = 0; k < nit - 1; ++k, ++g) {
-      stage_wait(st1 + st2);
-      issue((g + 2) % NS);
-      st2 = st1;
-      st1 = 0;
-      compute(g % NS);
-    }
-    stage_wait(st1 + st2);                      // last K step of the tile
-    if (HAS_R) prefetch_residual(tile);
-    issue((g + 2) % NS);
-    st2 = st1;
-    st1 = 0;
-    compute(g % NS);
-    ++g;
-    const int nt = tile % Nt, mt = tile / Nt;
-    const bool interior = (mt + 1) * BM <= p.M && (nt + 1) * BN <= p.Cout;
-    if (interior) { epilogue(tile, std::true_type{}); st1 = NST; }
-    else epilogue(tile, std::false_type{});
-    zero_acc();
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dead-stage DMAs must not outlive the block's LDS allocation
-}
-
-template <typename T>
-static int launch_conv_gemm_stream(const ConvGemmParams& p, hipStream_t st) {
-  const size_t lds = 3 * 2 * 128 * 128 + 4 * 64 * 36 * 4 + 336 + (size_t)cdiv(p.Cout, 128) * 128 * 4;
-  static bool attr_set = false;
-  static int ncu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_stream_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_stream_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_stream: set LDS attr: %s", hipGetErrorString(e));
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_stream: cannot query the device");
-    ncu = prop.multiProcessorCount;
-    attr_set = true;
-  }
-  if (p.Cout > 4096) return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm_stream: Cout %d > 4096", p.Cout);
-  const int ntiles = cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  const int tpb = cdiv(ntiles, ncu);
-  const int grid = cdiv(ntiles, tpb);
-  if (p.R) hipLaunchKernelGGL((conv_gemm_stream_kernel<T, true>), dim3(grid), dim3(256), lds, st, p, tpb);
-  else hipLaunchKernelGGL((conv_gemm_stream_kernel<T, false>), dim3(grid), dim3(256), lds, st, p, tpb);
-  return mmd_check_launch("conv_gemm_stream");
-}
-
 template <typename T>
 static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds = 128 * 132 * sizeof(float) + 336;
@@ -1062,8 +577,6 @@ static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st)
     return launch_conv_gemm<T, 64, 64, true>(p, st);
   }
   if (tile == 129) return launch_conv_gemm_glds<T>(p, st);
-  if (tile == 130) return launch_conv_gemm_stream<T>(p, st);
-  if (tile == 131) return launch_conv_gemm_glds256<T>(p, st);
   if (tile == 128) return launch_conv_gemm<T, 128, 128, false>(p, st);
   return launch_conv_gemm<T, 64, 64, false>(p, st);
 }
@@ -1091,8 +604,7 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
-  MMD_REQUIRE(tile == 64 || tile == 128 || (tile >= 129 && tile <= 131 && !gn_a),
-              "conv_gemm: tile must be 0, 64, 128, 129 (128 direct-to-LDS), 130 (persistent stream) or 131 (256x128 direct-to-LDS)");
+  MMD_REQUIRE(tile == 64 || tile == 128 || (tile == 129 && !gn_a), "conv_gemm: tile must be 0, 64, 128 or 129 (128 direct-to-LDS)");
   return dtype == MMD_BF16 ? dispatch_conv_gemm<__bf16>(p, tile, st) : dispatch_conv_gemm<float>(p, tile, st);
 }
 

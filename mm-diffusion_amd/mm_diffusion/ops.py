@@ -151,9 +151,9 @@ AUTOTUNE = True
 _tile_cache = {}
 
 
-def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129, 130)):
+def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129)):
     """launch(tile) enqueues the GEMM on the current stream.  Returns the fastest of `candidates`
-    (64 / 128 = register-staged tiles, 129 = 128x128 direct-to-LDS main loop, 130 = persistent stream of 128x128 tiles)."""
+    (64 / 128 = register-staged tiles, 129 = 128x128 direct-to-LDS main loop)."""
     default = (129 if 129 in candidates else 128) if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
     if not AUTOTUNE or _recorder is None:
         return default
@@ -201,7 +201,7 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     flops = 2 * M * Cout * Cin * nt
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
     _dispatch("mmd_conv_gemm", *base, tile,
-           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{ {129: '128glds', 130: '128stream', 131: '256glds'}.get(tile, tile) }>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
+           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{'128glds' if tile == 129 else tile}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
     return out
 
 

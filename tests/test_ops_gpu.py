@@ -56,7 +56,7 @@ def unrows_video(r, N, F, H, W):
 
 # --------------------------------------------------------------------------- implicit-GEMM convs
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("tile", [64, 128, 129, 130, 131])
+@pytest.mark.parametrize("tile", [64, 128, 129])
 @pytest.mark.parametrize("M,Cin,Cout", [(300, 64, 96), (1024, 128, 384), (77, 32, 8)])
 def test_pointwise(ops, dt, tile, M, Cin, Cout):
     x, w, b, r = rnd(M, Cin, dt=dt, seed=1), rnd(Cout, Cin, dt=dt, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3), rnd(M, Cout, dt=dt, seed=4)
@@ -67,22 +67,21 @@ def test_pointwise(ops, dt, tile, M, Cin, Cout):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("res", [False, True])
-@pytest.mark.parametrize("M,Cin,Cout,taps", [(128 * 300 + 37, 256, 256, "1"), (128 * 700, 64, 128, "1"), (128 * 130, 192, 384 + 8, "1"),
-                                            (2 * 20 * 24 * 24, 64, 128, "3x3")])
-def test_stream_kernel_many_tiles_per_block(ops, dt, res, M, Cin, Cout, taps):
-    """The persistent stream kernel (tile 130) with several tiles per block, ragged M / Cout edges, residual prefetch and
-    3x3 taps: bitwise equal to the one-tile-per-block direct-to-LDS kernel (same K order, same epilogue arithmetic)."""
+@pytest.mark.parametrize("M,Cin,Cout,taps", [(128 * 300 + 37, 256, 256, "1"), (128 * 130, 192, 384 + 8, "1"), (128 * 40, 96, 128, "1"),
+                                            (2 * 20 * 24 * 24, 64, 128, "3x3"), (2 * 20 * 24 * 24, 96, 64, "3x3")])
+def test_direct_to_lds_variants_agree(ops, dt, res, M, Cin, Cout, taps):
+    """The direct-to-LDS kernel (tile 129; uniform-tap fast addressing when Cin is a multiple of one K step, generic
+    otherwise; prefetched bias / residual) against the register-staged 128 tile: same K order and epilogue arithmetic,
+    so bitwise equal, on ragged M / Cout edges, with a residual and with 3x3 taps."""
     tp, dims = (ops.TAPS_1, (1, 1, 1)) if taps == "1" else (ops.TAPS_SPATIAL, (40, 24, 24))
     g = torch.Generator(device="cuda").manual_seed(M + Cin)
     x = torch.randn(M, Cin, device="cuda", generator=g).to(dt)
     w = (torch.randn(Cout, Cin * len(tp), device="cuda", generator=g) * (Cin * len(tp)) ** -0.5).to(dt)
     b = torch.randn(Cout, device="cuda", generator=g)
     r = torch.randn(M, Cout, device="cuda", generator=g).to(dt) if res else None
-    y0 = ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=129)
-    for _ in range(3):          # repeated: a mis-counted wait shows up as a timing-dependent mismatch
-        y1 = ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=130)
-        assert torch.equal(y0, y1)
-    assert torch.equal(y0, ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=131))      # 256x128 tile variant
+    y0 = ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=128)
+    for _ in range(3):
+        assert torch.equal(y0, ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=129))
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -30,7 +30,7 @@ SHAPES = [  # name, M, Cin, taps, dims, Cout, residual
     ("qkv ds8 512->1536", 4096, 512, ops.TAPS_1, (1, 1, 1), 1536, False),
     ("audio qkv 256->768", 25600, 256, ops.TAPS_1, (1, 1, 1), 768, False),
 ]
-TILES = (128, 129, 130, 131)
+TILES = (64, 128, 129)
 
 
 def main():
