@@ -178,6 +178,13 @@ int mmd_lincomb(const float* a, float ca, const float* b, float cb, const float*
 /* backward of mmd_ddpm_update's sample w.r.t. x and the model output (gradient-guided sampling gd:722-817; fixed variance). */
 int mmd_ddpm_update_bwd(const float* x, const float* model_out, const float* dsample, float* dx, float* dmodel_out, const float* tables,
                         const int64_t* t, int T, int N, int64_t per_sample, int flags, void* stream);
+/* DPM-Solver++ dynamic thresholding (multimodal_dpm_solver_plus.py:419-440): out[n] = q-quantile of |x[n,:]| (torch.quantile,
+ * linear interpolation), exact radix select; then x[n,:] = clamp(x, -s, s) / (s / max_val) with s = max(s_n, 1), in place. */
+int mmd_abs_quantile(const float* x, int N, int64_t per_sample, float q, float* out, void* stream);
+int mmd_clamp_scale(float* x, const float* s, float max_val, int N, int64_t per_sample, void* stream);
+/* adaptive-step error term (dpm:1088-1149): out[n] += sum(((hi - lo) / max(atol, rtol max(|lo|, |prev|)))^2), fp64, caller zeroes. */
+int mmd_dpm_err(const float* hi, const float* lo, const float* prev, float atol, float rtol, int N, int64_t per_sample, double* out,
+                void* stream);
 /* backward of mmd_attn_small_fwd (temporal attention): dQKV rows [dq | dk | dv], same slice geometry. */
 int mmd_attn_small_bwd(int dtype, const void* QKV, int64_t ld, const void* dO, int64_t lddo, void* dQKV, int64_t ldd, int C, int heads,
                        int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, void* stream);

@@ -738,3 +738,100 @@ extern "C" int mmd_ddpm_update_bwd(const float* x, const float* model_out, const
   hipLaunchKernelGGL(ddpm_update_bwd_kernel, dim3(ew_grid((int64_t)N * per_sample)), dim3(256), 0, (hipStream_t)stream, p, dsample, dx, dmodel_out);
   return mmd_check_launch("ddpm_update_bwd");
 }
+
+// ----------------------------------------------------------------------------- DPM-Solver helpers
+// Dynamic thresholding of the x0 prediction (multimodal_dpm_solver_plus.py:419-440): per sample, s = the p-quantile of
+// |x0| (torch.quantile 'linear' interpolation), s = max(s, 1), x0 = clamp(x0, -s, s) / (s / max_val).
+// Exact selection: |x| as IEEE bits is order-preserving for non-negative floats -> 4 passes of an 8-bit radix select per
+// wanted rank; one 1024-thread block per sample.
+__device__ __forceinline__ uint32_t absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+__device__ uint32_t radix_select_block(const float* __restrict__ x, int64_t n, int64_t rank, uint32_t* hist, int tid, int nth) {
+  uint32_t prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += nth) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += nth) {
+      const uint32_t b = absbits(x[i]);
+      if ((b & mask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // every thread walks the 256 bins (uniform result, no extra broadcast)
+    int64_t r = rank;
+    uint32_t digit = 0;
+    for (int d = 0; d < 256; ++d) {
+      const uint32_t c = hist[d];
+      if (r < (int64_t)c) { digit = (uint32_t)d; break; }
+      r -= c;
+    }
+    rank = r;
+    prefix |= digit << shift;
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(1024) void abs_quantile_kernel(const float* __restrict__ x, int64_t per, float q, float* __restrict__ out) {
+  __shared__ uint32_t hist[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* xs = x + (int64_t)n * per;
+  const double pos = (double)q * (double)(per - 1);
+  const int64_t lo = (int64_t)floor(pos);
+  const int64_t hi = lo + 1 < per ? lo + 1 : lo;
+  const float frac = (float)(pos - (double)lo);
+  const float vlo = __uint_as_float(radix_select_block(xs, per, lo, hist, tid, blockDim.x));
+  const float vhi = hi == lo ? vlo : __uint_as_float(radix_select_block(xs, per, hi, hist, tid, blockDim.x));
+  if (tid == 0) out[n] = vlo + (vhi - vlo) * frac;          // torch.lerp(lo, hi, frac) for frac < 0.5 and its mirror agree to 1 ulp
+}
+extern "C" int mmd_abs_quantile(const float* x, int N, int64_t per_sample, float q, float* out, void* stream) {
+  MMD_REQUIRE(x && out && N > 0 && per_sample > 0 && q >= 0.f && q <= 1.f, "abs_quantile: bad argument");
+  hipLaunchKernelGGL(abs_quantile_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, x, per_sample, q, out);
+  return mmd_check_launch("abs_quantile");
+}
+
+// x[n, :] = clamp(x, -s_n, s_n) / (s_n / max_val),  s_n = max(s[n], 1)        (in place)
+__global__ __launch_bounds__(256) void clamp_scale_kernel(float* __restrict__ x, const float* __restrict__ s, float max_val, int64_t per,
+                                                          int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float sn = fmaxf(s[i / per], 1.f);
+    x[i] = fminf(fmaxf(x[i], -sn), sn) / (sn / max_val);
+  }
+}
+extern "C" int mmd_clamp_scale(float* x, const float* s, float max_val, int N, int64_t per_sample, void* stream) {
+  MMD_REQUIRE(x && s && N > 0 && per_sample > 0 && max_val > 0.f, "clamp_scale: bad argument");
+  const int64_t total = per_sample * N;
+  hipLaunchKernelGGL(clamp_scale_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, s, max_val, per_sample, total);
+  return mmd_check_launch("clamp_scale");
+}
+
+// Adaptive step-size error term (dpm:1088-1149): out[n] += sum_i ((hi - lo) / max(atol, rtol * max(|lo|, |prev|)))^2
+// (fp64 atomics; caller zeroes out and takes sqrt(out / per)).
+__global__ __launch_bounds__(256) void dpm_err_kernel(const float* __restrict__ hi, const float* __restrict__ lo, const float* __restrict__ prev,
+                                                      float atol, float rtol, int64_t per, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int n = blockIdx.y;
+  const int64_t base = (int64_t)n * per;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    const float l = lo[base + i];
+    const float delta = fmaxf(atol, rtol * fmaxf(fabsf(l), fabsf(prev[base + i])));
+    const float e = (hi[base + i] - l) / delta;
+    acc += (double)e * (double)e;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out + n, red[0]);
+}
+extern "C" int mmd_dpm_err(const float* hi, const float* lo, const float* prev, float atol, float rtol, int N, int64_t per_sample,
+                           double* out, void* stream) {
+  MMD_REQUIRE(hi && lo && prev && out && N > 0 && per_sample > 0, "dpm_err: bad argument");
+  const int chunks = (int)((per_sample + 256 * 16 - 1) / (256 * 16));
+  hipLaunchKernelGGL(dpm_err_kernel, dim3(chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks), N), dim3(256), 0, (hipStream_t)stream, hi, lo, prev,
+                     atol, rtol, per_sample, out);
+  return mmd_check_launch("dpm_err");
+}

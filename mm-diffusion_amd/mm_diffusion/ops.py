@@ -348,6 +348,28 @@ def lincomb(a, ca, b=None, cb=0.0, c=None, cc=0.0, out=None):
     return out
 
 
+def abs_quantile(x, q):
+    """per-sample q-quantile of |x| (fp32 contiguous [N, ...]) -> fp32 [N]."""
+    H.require_cuda(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _dispatch("mmd_abs_quantile", x.data_ptr(), x.shape[0], x[0].numel(), float(q), out.data_ptr(), meta=("abs_quantile", 0, 20 * x.numel()))
+    return out
+
+
+def clamp_scale_(x, s, max_val):
+    H.require_cuda(x, s)
+    _dispatch("mmd_clamp_scale", x.data_ptr(), s.data_ptr(), float(max_val), x.shape[0], x[0].numel(), meta=("clamp_scale", 0, 8 * x.numel()))
+    return x
+
+
+def dpm_err(hi, lo, prev, atol, rtol, out):
+    """out[n] (fp64, pre-zeroed) += squared scaled difference of two solver orders (adaptive step-size control)."""
+    H.require_cuda(hi, lo, prev, out)
+    _dispatch("mmd_dpm_err", hi.data_ptr(), lo.data_ptr(), prev.data_ptr(), float(atol), float(rtol), hi.shape[0], hi[0].numel(),
+              out.data_ptr(), meta=("dpm_err", 0, 12 * hi.numel()))
+    return out
+
+
 def ddpm_update_bwd(x, model_out, dsample, dx, dmo, tables, t, flags):
     H.require_cuda(x, model_out, dsample, tables, t)
     _dispatch("mmd_ddpm_update_bwd", x.data_ptr(), model_out.data_ptr(), dsample.data_ptr(), H.ptr(dx), H.ptr(dmo), tables.data_ptr(),

@@ -205,6 +205,32 @@ def test_posterior_and_predict_helpers():
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=1e-6)
 
 
+DPM_CASES = {
+    "tiny_dpm_singlestep3": (False, dict(steps=20, order=3, skip_type="logSNR", method="singlestep")),
+    "tiny_dpm_singlestep2": (False, dict(steps=7, order=2, skip_type="time_quadratic", method="singlestep")),
+    "tiny_dpm_multistep2": (False, dict(steps=10, order=2, skip_type="time_uniform", method="multistep")),
+    "tiny_dpmpp_multistep2": (True, dict(steps=10, order=2, skip_type="logSNR", method="multistep", denoise=True)),
+    "tiny_dpmpp_adaptive2": (True, dict(order=2, method="adaptive")),
+}
+
+
+@pytest.mark.parametrize("tag", list(DPM_CASES))
+def test_dpm_solver(tag):
+    """Oracle restatement of the multimodal DPM-Solver(++) driver vs the reference's own sample() output."""
+    from oracle import dpm_ref
+    g = gold(tag)
+    pp, kw = DPM_CASES[tag]
+    fl = flags("tiny")
+    B = int(g["B"])
+    model = uref.OracleModel(synth_sd("tiny"), fl, shifts=list(g["shifts"]))
+    torch.manual_seed(int(g["seed"]))
+    x_T = {"video": torch.randn(B, *fl["video_size"]), "audio": torch.randn(B, *fl["audio_size"])}
+    S = dref.Schedule()
+    solver = dpm_ref.Solver(model, torch.tensor(S.alphas_cumprod, dtype=torch.float32), predict_x0=pp, thresholding=pp)
+    out = solver.sample(x_T, **kw)
+    assert rel_l2(out["video"], g["video"]) < 1e-3 and rel_l2(out["audio"], g["audio"]) < 1e-3
+
+
 def test_full_config1_two_step():
     """BASELINE config[0]: Landscape base model, batch 1, 2-step DDPM on the CPU path."""
     g = gold("full_psample2")

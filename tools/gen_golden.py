@@ -302,6 +302,24 @@ def gen_cond(name, B, seed, respacing, which, class_scale):
          shifts=np.asarray(rec.draws), cond=cond, video=sample["video"].detach(), audio=sample["audio"].detach())
 
 
+def gen_dpm(tag, seed, predict_x0, thresholding, **sample_kw):
+    """Multimodal DPM-Solver(++) sample() on the tiny config, B = 2 (B = 1 fails inside the reference, dpm:344-345)."""
+    from ref_mm import multimodal_dpm_solver_plus as rdpm
+    f = flags("tiny")
+    model, diff = msu.create_model_and_diffusion(**f)
+    synth_init(model).eval()
+    B = 2
+    th.manual_seed(seed)
+    random.seed(seed)
+    x_T = {"video": th.randn(B, *f["video_size"]), "audio": th.randn(B, *f["audio_size"])}
+    solver = rdpm.DPM_Solver(model=model, alphas_cumprod=th.tensor(diff.alphas_cumprod, dtype=th.float32), predict_x0=predict_x0,
+                             thresholding=thresholding)
+    import contextlib, io
+    with ShiftRecorder() as rec, contextlib.redirect_stdout(io.StringIO()):
+        out = solver.sample({k: v.clone() for k, v in x_T.items()}, **sample_kw)
+    save(tag, seed=seed, B=B, shifts=np.asarray(rec.draws), nfe=len(rec.draws) // 9,      # 9 shifted cross-attention blocks per tiny forward video=out["video"], audio=out["audio"])
+
+
 def gen_helpers():
     """q_mean_variance / q_posterior_mean_variance / _predict_* (gd:170-229,345-366) on random inputs."""
     f = flags("tiny", timestep_respacing="")
@@ -333,6 +351,13 @@ ALL = {
     "tiny_cond_guided_v": lambda: gen_cond("tiny", 1, 52, "4", "video", 3.0),
     "tiny_cond_guided_a": lambda: gen_cond("tiny", 1, 53, "2", "audio", 3.0),
     "helpers": gen_helpers,
+    "dpm_singlestep3": lambda: gen_dpm("tiny_dpm_singlestep3", 61, False, False, steps=20, order=3, skip_type="logSNR", method="singlestep"),
+    "dpm_singlestep2": lambda: gen_dpm("tiny_dpm_singlestep2", 62, False, False, steps=7, order=2, skip_type="time_quadratic", method="singlestep"),
+    "dpm_multistep2": lambda: gen_dpm("tiny_dpm_multistep2", 63, False, False, steps=10, order=2, skip_type="time_uniform", method="multistep"),
+    "dpmpp_multistep2": lambda: gen_dpm("tiny_dpmpp_multistep2", 64, True, True, steps=10, order=2, skip_type="logSNR", method="multistep",
+                                        denoise=True),
+    "dpmpp_adaptive2": lambda: gen_dpm("tiny_dpmpp_adaptive2", 65, True, True, steps=20, order=2, skip_type="logSNR", method="adaptive"),
+    "dpm_adaptive3": lambda: gen_dpm("tiny_dpm_adaptive3", 66, False, False, order=3, method="adaptive", atol=0.05, rtol=0.1),
     "tiny_train_loss": lambda: gen_train_loss("tiny", 2, 31),
     "tiny_ls_train_loss": lambda: gen_train_loss("tiny", 2, 32, learn_sigma=True),
 }
