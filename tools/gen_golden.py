@@ -317,7 +317,7 @@ def gen_dpm(tag, seed, predict_x0, thresholding, **sample_kw):
     import contextlib, io
     with ShiftRecorder() as rec, contextlib.redirect_stdout(io.StringIO()):
         out = solver.sample({k: v.clone() for k, v in x_T.items()}, **sample_kw)
-    save(tag, seed=seed, B=B, shifts=np.asarray(rec.draws), nfe=len(rec.draws) // 9,      # 9 shifted cross-attention blocks per tiny forward video=out["video"], audio=out["audio"])
+    save(tag, seed=seed, B=B, shifts=np.asarray(rec.draws), nfe=len(rec.draws) // 9, video=out["video"], audio=out["audio"])      # 9 shift draws per tiny forward
 
 
 def gen_helpers():
