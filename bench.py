@@ -194,6 +194,63 @@ def train_bench(args, world, rank, device):
         dist.destroy_process_group()
 
 
+def dpm_bench(args, world, rank, device):
+    """BASELINE configs[4], base-model half: DPM-Solver++ (predict_x0 + dynamic thresholding), multistep order 2, 50 network
+    evaluations per sample batch (the script's literal 'adaptive' method has a data-dependent NFE, so NFE is fixed here as
+    SURVEY 8d prescribes), per-GPU batch --batch.  A "step" is one network evaluation + its solver update."""
+    import random
+    import torch.distributed as dist
+    from mm_diffusion import logger, multimodal_script_util as msu
+    from mm_diffusion.multimodal_dpm_solver_plus import DPM_Solver
+    from mm_diffusion.synth import synth_init_
+    logger.set_quiet(True)
+    fl = msu.model_and_diffusion_defaults()
+    fl.update(FULL)
+    fl.update(use_fp16=(args.dtype == "bf16"))
+    model, diff = msu.create_model_and_diffusion(**fl)
+    synth_init_(model)
+    model.to(device).eval()
+    random.seed(99 + rank)
+    torch.manual_seed(99 + rank)
+    B, NFE = args.batch, 50
+    solver = DPM_Solver(model=model, alphas_cumprod=torch.tensor(diff.alphas_cumprod, dtype=torch.float32), predict_x0=True, thresholding=True)
+
+    def one_sample():
+        x_T = {"video": torch.randn(B, *fl["video_size"], device=device), "audio": torch.randn(B, *fl["audio_size"], device=device)}
+        return solver.sample(x_T, steps=NFE, order=2, skip_type="logSNR", method="multistep")
+
+    for _ in range(max(1, args.warmup)):
+        one_sample()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_sample()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        evals = args.steps * NFE
+        print(json.dumps({
+            "metric": "denoising steps/sec (video+audio pair), DPM-Solver++ multistep-2, 50 NFE", "value": evals * B * world / elapsed,
+            "unit": "pair-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * elapsed / evals,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4] (base-model half): DPM-Solver++ 50 NFE, per-GPU batch {B}; one timed step = one full "
+                                   f"{NFE}-evaluation sample() call", "global_batch": B * world, "seconds_per_sample_batch": elapsed / args.steps,
+                       "finite": bool(torch.isfinite(out["video"]).all())}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +259,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]: 4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--respacing", default="250")
-    ap.add_argument("--mode", default="sample", choices=["sample", "train"], help="sample = headline DDPM step (default); train = configs[3]")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "dpm"],
+                    help="sample = headline DDPM step (default); train = configs[3]; dpm = configs[4] base-model half (DPM-Solver++ 50 NFE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-out", default="")
@@ -218,6 +276,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
     device = dist_util.dev()
+    if args.mode == "dpm":
+        return dpm_bench(args, world, rank, device)
     if args.mode == "train":
         return train_bench(args, world, rank, device)
 

@@ -58,3 +58,54 @@ def test_gloo_world2_shard_gather_sync():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, True, True), (1, True, True, True)]
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mm-diffusion_amd"))
+    from mm_diffusion import dist_util
+    from mm_diffusion.optim import FlatAdamW
+    from mm_diffusion.resample import LossSecondMomentResampler
+    dist_util.setup_dist(backend="gloo")
+    # data-parallel gradient reduction of the training step: ONE all-reduce of the flat gradient buffer -> the mean
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(11))]
+    opt = FlatAdamW(params, lr=1e-3)
+    assert params[0].data_ptr() == opt.flat.data_ptr()                 # parameters re-homed into the flat buffer
+    loss = sum(((p * (rank + 1)) ** 2).sum() for p in params)          # rank-dependent gradient: 2 (rank+1)^2 p
+    loss.backward()
+    assert params[1].grad.data_ptr() == opt.grad[15:].data_ptr()       # autograd accumulated in place
+    opt.all_reduce_grads()
+    expect = torch.cat([p.detach().reshape(-1) for p in params]) * 2 * (1 + 4) / 2
+    ok_grad = torch.allclose(opt.grad, expect, rtol=1e-6)
+
+    # loss-aware timestep sampler: every rank ends with the same history although each contributed different pairs
+    class D:
+        num_timesteps = 6
+    s = LossSecondMomentResampler(D(), history_per_term=2)
+    for it in range(2):
+        ts = torch.tensor([0, 1, 2] if rank == 0 else [3, 4, 5, 5][:3 + it])
+        s.update_with_local_losses(ts, (ts.float() + 1) * (it + 1))
+    hist = torch.from_numpy(s._loss_history.copy())
+    allh = [torch.empty_like(hist) for _ in range(world)]
+    dist.all_gather(allh, hist)
+    ok_hist = all(torch.equal(allh[0], h) for h in allh) and float(hist[5].sum()) > 0 and float(hist[0].sum()) > 0
+    dist.barrier()
+    q.put((rank, ok_grad, ok_hist))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_training_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)]

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (two separate runs, --kernel-trace only) into per-kernel HBM
+traffic per launch.  usage: pmc_summary.py <fetch_dir> <write_dir> <out.txt> [<pmc_traffic.json>] [<header note>]
+
+Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE
+tallies 128-byte requests as 64 bytes, so hbm_read_bytes = 2 * FETCH_SIZE * 1024 for wide coalesced streams; WRITE_SIZE is
+reported as is."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def load(d, counter):
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        seen = set()
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"]
+            tot[k] += float(r["Counter_Value"])
+            key = (r.get("Dispatch_Id"), k)
+            if key not in seen:
+                seen.add(key)
+                cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    jout = sys.argv[4] if len(sys.argv) > 4 else None
+    note = sys.argv[5] if len(sys.argv) > 5 else ""
+    ft, fc = load(fd, "FETCH_SIZE")
+    wt, wc = load(wd, "WRITE_SIZE")
+    rows = []
+    for k in ft:
+        n = fc[k]
+        f = ft[k] / n
+        w = wt.get(k, 0.0) / max(wc.get(k, 1), 1)
+        rows.append((ft[k] + wt.get(k, 0.0), n, f, w, k))
+    rows.sort(reverse=True)
+    with open(out, "w") as fo:
+        fo.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only)" + (f" of: {note}" if note else "") + "\n")
+        fo.write("# counter unit = KiB; gfx950: hbm_read_bytes = 2 * FETCH_SIZE * 1024 (128-B requests tallied at 64 B); WRITE_SIZE as is\n")
+        fo.write("  calls  FETCH_KiB/call  read_MB/call(x2)  WRITE_KiB/call  write_MB/call  kernel\n")
+        for _, n, f, w, k in rows[:24]:
+            fo.write(f"{n:7d} {f:15.1f} {2 * f * 1024 / 1e6:17.2f} {w:15.1f} {w * 1024 / 1e6:14.2f}  {k[:110]}\n")
+    if jout:
+        traffic = {}
+        for _, n, f, w, k in rows:
+            if "conv_gemm_glds_kernel" in k:
+                traffic["conv_gemm<bf16,128glds>"] = traffic.get("conv_gemm<bf16,128glds>", 0.0) + 0.0
+        # launch-weighted mean over the template instances of the dominant kernel family
+        num = den = 0.0
+        for _, n, f, w, k in rows:
+            if "conv_gemm_glds_kernel" in k:
+                num += n * (2 * f + w) * 1024
+                den += n
+        if den:
+            traffic["conv_gemm<bf16,128glds>"] = num / den
+        traffic["_source"] = f"{os.path.basename(out)}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of conv_gemm_glds_kernel<bf16,*>, rocprofv3 --pmc passes"
+        json.dump(traffic, open(jout, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
