@@ -251,6 +251,61 @@ def dpm_bench(args, world, rank, device):
         dist.destroy_process_group()
 
 
+def sr_bench(args, world, rank, device):
+    """BASELINE configs[4], SR half: the shipped 64 -> 256 super-resolution U-Net (192 channels, mult (1,1,2,2,4,4), attention at
+    ds 8/16/32, learned sigma; ssh_scripts/multimodal_sample_sr.sh:10-13,20) sampled with DDIM-25 on the 16 frames of --batch clips
+    (N = 16 * batch images of 256 x 256), start noise repeated over the frames of a clip like multimodal_sample_sr.py:191-196."""
+    import torch.distributed as dist
+    from mm_diffusion import logger, script_util as su
+    from mm_diffusion.synth import synth_init_
+    logger.set_quiet(True)
+    d = su.image_sr_model_and_diffusion_defaults()
+    d.update(large_size=256, small_size=64, sr_num_channels=192, sr_num_heads=4, sr_num_res_blocks=2, sr_attention_resolutions="8,16,32",
+             sr_resblock_updown=True, sr_use_scale_shift_norm=True, sr_learn_sigma=True, use_fp16=(args.dtype == "bf16"),
+             sr_timestep_respacing="ddim25")
+    model, diff = su.image_sr_create_model_and_diffusion(**d)
+    synth_init_(model)
+    model.to(device).eval()
+    torch.manual_seed(7 + rank)
+    B, Fr = args.batch, 16
+    low = (torch.rand(B * Fr, 3, 64, 64) * 2 - 1).to(device)
+
+    def one_clip_batch():
+        noise = torch.randn(B, 3, 256, 256, device=device).repeat_interleave(Fr, dim=0)
+        return diff.ddim_sample_loop(model, (B * Fr, 3, 256, 256), clip_denoised=True, model_kwargs={"low_res": low}, noise=noise, device=device)
+
+    for _ in range(max(1, args.warmup)):
+        one_clip_batch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_clip_batch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        evals = args.steps * diff.num_timesteps
+        print(json.dumps({
+            "metric": "SR denoising steps/sec (256x256 frames), DDIM-25", "value": evals * B * Fr * world / elapsed, "unit": "frame-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * elapsed / evals, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4] (SR half): ImageSuperResModel 64->256, {B} clip(s) x 16 frames per GPU, DDIM-25; one timed step "
+                                   "= one full 25-evaluation ddim_sample_loop", "global_batch": B * world, "seconds_per_clip_batch": elapsed / args.steps,
+                       "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "finite": bool(torch.isfinite(out).all())}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,8 +314,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]: 4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--respacing", default="250")
-    ap.add_argument("--mode", default="sample", choices=["sample", "train", "dpm"],
-                    help="sample = headline DDPM step (default); train = configs[3]; dpm = configs[4] base-model half (DPM-Solver++ 50 NFE)")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "dpm", "sr"],
+                    help="sample = headline DDPM step (default); train = configs[3]; dpm = configs[4] base-model half (DPM-Solver++ 50 NFE); sr = configs[4] SR half (DDIM-25 on 256x256 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-out", default="")
@@ -278,6 +333,8 @@ def main():
     device = dist_util.dev()
     if args.mode == "dpm":
         return dpm_bench(args, world, rank, device)
+    if args.mode == "sr":
+        return sr_bench(args, world, rank, device)
     if args.mode == "train":
         return train_bench(args, world, rank, device)
 

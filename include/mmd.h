@@ -185,6 +185,8 @@ int mmd_clamp_scale(float* x, const float* s, float max_val, int N, int64_t per_
 /* adaptive-step error term (dpm:1088-1149): out[n] += sum(((hi - lo) / max(atol, rtol max(|lo|, |prev|)))^2), fp64, caller zeroes. */
 int mmd_dpm_err(const float* hi, const float* lo, const float* prev, float atol, float rtol, int N, int64_t per_sample, double* out,
                 void* stream);
+/* SR model input (image_unet.py:704-715): out [N,2C,H,W] = concat(x [N,C,H,W], bilinear(low [N,C,h,w] -> H x W)), fp32. */
+int mmd_bilinear_concat(const float* x, const float* low, float* out, int N, int C, int H, int W, int h, int w, void* stream);
 /* backward of mmd_attn_small_fwd (temporal attention): dQKV rows [dq | dk | dv], same slice geometry. */
 int mmd_attn_small_bwd(int dtype, const void* QKV, int64_t ld, const void* dO, int64_t lddo, void* dQKV, int64_t ldd, int C, int heads,
                        int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, void* stream);

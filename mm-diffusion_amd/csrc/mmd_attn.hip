@@ -586,7 +586,8 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
                          int impl, float* lse2_out, void* stream) {
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "attn_fwd: bad dtype %d", dtype);
   MMD_REQUIRE(Q && KV && O, "attn_fwd: null pointer");
-  MMD_REQUIRE(heads > 0 && ch > 0 && ch <= 128 && nb > 0 && G > 0, "attn_fwd: bad heads/ch/nb/G (%d,%d,%d,%d)", heads, ch, nb, G);
+  MMD_REQUIRE(heads > 0 && ch > 0 && ch <= 192 && nb > 0 && G > 0, "attn_fwd: bad heads/ch/nb/G (%d,%d,%d,%d)", heads, ch, nb, G);
+  MMD_REQUIRE(ch <= 128 || (dtype == MMD_BF16 && ch == 192 && impl == 0), "attn_fwd: head width %d needs the bf16 MFMA path (16..128 or 192)", ch);
   MMD_REQUIRE(q_per_group > 0 && (int64_t)(G - 1) * q_per_group < q_rows_per_batch, "attn_fwd: bad query grouping");
   MMD_REQUIRE(k_per_group > 0 && win > 0 && (int64_t)win * k_per_group <= k_rows_per_batch, "attn_fwd: key window exceeds the key rows");
   AttnParams p;
@@ -608,6 +609,7 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
       case 64: return launch_mfma<64>(p, qmax, st);
       case 96: return launch_mfma<96>(p, qmax, st);
       case 128: return launch_mfma<128>(p, qmax, st);
+      case 192: return launch_mfma<192>(p, qmax, st);      // SR U-Net: 768 channels / 4 heads
       default: break;
     }
   }

@@ -835,3 +835,33 @@ extern "C" int mmd_dpm_err(const float* hi, const float* lo, const float* prev, 
                      atol, rtol, per_sample, out);
   return mmd_check_launch("dpm_err");
 }
+
+// ----------------------------------------------------------------------------- super-resolution model input
+// ImageSuperResModel.forward (image_unet.py:704-715): out[n, 0:C] = x[n], out[n, C:2C] = F.interpolate(low_res[n], (H, W),
+// mode="bilinear") (align_corners=False: src = (dst + 0.5) * in/out - 0.5 clamped at 0, neighbours clamped at the edge).
+__global__ __launch_bounds__(256) void bilinear_concat_kernel(const float* __restrict__ x, const float* __restrict__ low, float* __restrict__ out,
+                                                              int N, int C, int H, int W, int h, int w) {
+  const int64_t total = (int64_t)N * 2 * C * H * W;
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int xo = (int)(i % W), yo = (int)((i / W) % H);
+    const int c = (int)((i / ((int64_t)W * H)) % (2 * C));
+    const int64_t n = i / ((int64_t)W * H * 2 * C);
+    if (c < C) {
+      out[i] = x[((n * C + c) * H + yo) * (int64_t)W + xo];
+    } else {
+      const float fy = fmaxf(((float)yo + 0.5f) * sh - 0.5f, 0.f), fx = fmaxf(((float)xo + 0.5f) * sw - 0.5f, 0.f);
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float ly = fy - (float)y0, lx = fx - (float)x0;
+      const float* p = low + (n * C + (c - C)) * (int64_t)h * w;
+      out[i] = (1.f - ly) * ((1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1]) + ly * ((1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+    }
+  }
+}
+extern "C" int mmd_bilinear_concat(const float* x, const float* low, float* out, int N, int C, int H, int W, int h, int w, void* stream) {
+  MMD_REQUIRE(x && low && out && N > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0, "bilinear_concat: bad argument");
+  hipLaunchKernelGGL(bilinear_concat_kernel, dim3(ew_grid((int64_t)N * 2 * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, low, out, N, C, H,
+                     W, h, w);
+  return mmd_check_launch("bilinear_concat");
+}

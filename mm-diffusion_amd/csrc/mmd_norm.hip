@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
   constexpr int ES = 16 / EPV;
   __shared__ float s_sum[256 * EPV];
   __shared__ float s_sq[256 * EPV];
-  __shared__ double s_csum[1024];
-  __shared__ double s_csq[1024];
+  __shared__ double s_csum[2048];
+  __shared__ double s_csq[2048];
   const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int CV = C / EPV;                 // vecs per row (<= 256)
   const int RPP = 256 / CV;               // rows per pass
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void add_rowbias_kernel(char* __restrict__ x, 
 static int check_geom(const char* who, int dtype, int C, int S, int Tn, int inner) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "%s: bad dtype %d", who, dtype);
-  MMD_REQUIRE(C % GN_GROUPS == 0 && C % epv == 0 && C / epv <= 256 && C <= 1024, "%s: unsupported channel count %d", who, C);
+  MMD_REQUIRE(C % GN_GROUPS == 0 && C % epv == 0 && C / epv <= 256 && C <= 2048, "%s: unsupported channel count %d", who, C);
   MMD_REQUIRE(S > 0 && Tn > 0 && inner > 0, "%s: empty slice geometry", who);
   return MMD_OK;
 }

@@ -57,6 +57,7 @@ _PROTOS = {
     "mmd_abs_quantile": (i32, [vp, i32, i64, f32, vp, vp]),
     "mmd_clamp_scale": (i32, [vp, vp, f32, i32, i64, vp]),
     "mmd_dpm_err": (i32, [vp, vp, vp, f32, f32, i32, i64, vp, vp]),
+    "mmd_bilinear_concat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_silu": (i32, [i32, vp, vp, vp, i64, vp]),
     "mmd_dropout": (i32, [i32, vp, vp, f32, vp, i64, vp]),
     "mmd_mse_grad": (i32, [vp, vp, vp, vp, i32, i64, vp]),

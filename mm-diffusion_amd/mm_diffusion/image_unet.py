@@ -1,0 +1,328 @@
+"""64 -> 256 image super-resolution U-Net on the MI355X HIP path (reference mm_diffusion/image_unet.py:395-715:
+`ImageUnet`, `ImageSuperResModel`; blocks image_unet.py:80-305,327-358).
+
+Same surface as the reference: constructor arguments, `forward(x, timesteps, low_res=None)` on `[N, 3, H, W]` images,
+`load_state_dict_`, `convert_to_fp16/32`, and the reference's state-dict keys / shapes / order (a reference
+checkpoint loads unchanged).  The module tree only holds parameters; the arithmetic is a walk over the same libmmd
+kernels as the multimodal U-Net on channels-last rows `[(n h w), C]`:
+
+  ResBlock        gn_stats + gn_apply(+SiLU) -> [avg-pool / nearest x2 on h and x] -> 3x3 implicit-GEMM conv -> FiLM'd
+                  GroupNorm(+SiLU) -> 3x3 conv with the skip (identity or 1x1 conv) as the GEMM residual
+  AttentionBlock  GroupNorm -> 1x1 qkv GEMM (weights re-ordered ONCE at pack time from the legacy
+                  [head][q|k|v][ch] channel order, image_unet.py:336-353, to [q|k|v][head][ch]) -> flash MFMA attention
+                  over T = H*W tokens -> 1x1 proj GEMM with the residual
+  skip `th.cat`   column-slice copies into one pre-sized buffer (mmd_copy2d)
+  SuperRes input  bilinear upsample of `low_res` + channel concat in one kernel (mmd_bilinear_concat) feeding the stem conv
+
+Inference only (the SR model is a sampling-time component of multimodal_sample_sr.py:186-253).  Not built:
+`resblock_updown=False` (strided-conv Downsample / conv Upsample - the shipped SR checkpoint uses resblock_updown),
+class conditioning, `use_new_attention_order` is accepted (it only changes the pack-time re-ordering).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _hip as H
+from . import logger, ops
+from ._hip import MMDError
+from .multimodal_unet import _Affine, _Bag
+from .ops import Geom
+
+
+def _res_block(cin, cout, emb_ch, scale_shift):
+    b = _Bag()
+    il = b.put("in_layers", _Bag())
+    il.put(0, _Affine((cin,), "norm")), il.put(1, nn.Identity()), il.put(2, _Affine((cout, cin, 3, 3)))
+    el = b.put("emb_layers", _Bag())
+    el.put(0, nn.Identity()), el.put(1, _Affine((2 * cout if scale_shift else cout, emb_ch), "linear"))
+    ol = b.put("out_layers", _Bag())
+    ol.put(0, _Affine((cout,), "norm")), ol.put(1, nn.Identity()), ol.put(2, nn.Identity()), ol.put(3, _Affine((cout, cout, 3, 3), zero=True))
+    b.put("skip_connection", nn.Identity() if cin == cout else _Affine((cout, cin, 1, 1)))
+    return b
+
+
+def _attn_block(ch):
+    b = _Bag()
+    b.put("norm", _Affine((ch,), "norm")), b.put("qkv", _Affine((3 * ch, ch, 1))), b.put("proj_out", _Affine((ch, ch, 1), zero=True))
+    return b
+
+
+class ImageUnet(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False, use_fp16=False,
+                 num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False):
+        super().__init__()
+        if dims != 2:
+            raise NotImplementedError("ImageUnet: only dims=2 is built")
+        if num_classes is not None:
+            raise NotImplementedError("ImageUnet: class conditioning is not built")
+        if not resblock_updown:
+            raise NotImplementedError("ImageUnet: resblock_updown=False (strided-conv Downsample / conv Upsample) is not built; the "
+                                      "shipped SR model uses resblock_updown=True (ssh_scripts/multimodal_sample_sr.sh:10-13)")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions, self.dropout = num_res_blocks, tuple(attention_resolutions), dropout
+        self.channel_mult, self.conv_resample, self.num_classes, self.use_checkpoint = tuple(channel_mult), conv_resample, num_classes, use_checkpoint
+        self.dtype = torch.bfloat16 if use_fp16 else torch.float32         # the MI355X 16-bit type is bf16
+        self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
+        self.use_scale_shift_norm, self.use_new_attention_order = use_scale_shift_norm, use_new_attention_order
+        ted = model_channels * 4
+        te = self.time_embed = _Bag()
+        te.put(0, _Affine((ted, model_channels), "linear")), te.put(1, nn.Identity()), te.put(2, _Affine((ted, ted), "linear"))
+
+        # ---- module tree (parameter holders) + the flat layer list the forward walks
+        plan_in, plan_out = [], []
+        ch = input_ch = int(channel_mult[0] * model_channels)
+        self.input_blocks = _Bag()
+        blk = self.input_blocks.put(0, _Bag())
+        blk.put(0, _Affine((ch, in_channels, 3, 3)))
+        plan_in.append([("stem", "input_blocks.0.0", in_channels, ch)])
+        chans = [ch]
+        ds, idx = 1, 1
+
+        def heads_of(c, nh):
+            return nh if num_head_channels == -1 else c // num_head_channels
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                blk = self.input_blocks.put(idx, _Bag())
+                layers = []
+                cout = int(mult * model_channels)
+                blk.put(0, _res_block(ch, cout, ted, use_scale_shift_norm))
+                layers.append(("res", f"input_blocks.{idx}.0", ch, cout, None))
+                ch = cout
+                if ds in self.attention_resolutions:
+                    blk.put(1, _attn_block(ch))
+                    layers.append(("attn", f"input_blocks.{idx}.1", ch, heads_of(ch, num_heads)))
+                plan_in.append(layers)
+                chans.append(ch)
+                idx += 1
+            if level != len(channel_mult) - 1:
+                blk = self.input_blocks.put(idx, _Bag())
+                blk.put(0, _res_block(ch, ch, ted, use_scale_shift_norm))
+                plan_in.append([("res", f"input_blocks.{idx}.0", ch, ch, "down")])
+                chans.append(ch)
+                ds *= 2
+                idx += 1
+        self.middle_block = _Bag()
+        self.middle_block.put(0, _res_block(ch, ch, ted, use_scale_shift_norm))
+        self.middle_block.put(1, _attn_block(ch))
+        self.middle_block.put(2, _res_block(ch, ch, ted, use_scale_shift_norm))
+        plan_mid = [("res", "middle_block.0", ch, ch, None), ("attn", "middle_block.1", ch, heads_of(ch, num_heads)),
+                    ("res", "middle_block.2", ch, ch, None)]
+        self.output_blocks = _Bag()
+        idx = 0
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                blk = self.output_blocks.put(idx, _Bag())
+                cout = int(model_channels * mult)
+                blk.put(0, _res_block(ch + ich, cout, ted, use_scale_shift_norm))
+                layers = [("res", f"output_blocks.{idx}.0", ch + ich, cout, None)]
+                ch = cout
+                j = 1
+                if ds in self.attention_resolutions:
+                    blk.put(j, _attn_block(ch))
+                    layers.append(("attn", f"output_blocks.{idx}.{j}", ch, heads_of(ch, num_heads_upsample)))
+                    j += 1
+                if level and i == num_res_blocks:
+                    blk.put(j, _res_block(ch, ch, ted, use_scale_shift_norm))
+                    layers.append(("res", f"output_blocks.{idx}.{j}", ch, ch, "up"))
+                    ds //= 2
+                plan_out.append(layers)
+                idx += 1
+        self.out = _Bag()
+        self.out.put(0, _Affine((ch,), "norm")), self.out.put(1, nn.Identity()), self.out.put(2, _Affine((out_channels, input_ch, 3, 3), zero=True))
+        self._plan = (plan_in, plan_mid, plan_out)
+        self._packed = None
+
+    # ------------------------------------------------------------------ reference surface
+    def convert_to_fp16(self):
+        self.dtype = torch.bfloat16
+        self._packed = None
+
+    def convert_to_fp32(self):
+        self.dtype = torch.float32
+        self._packed = None
+
+    def load_state_dict_(self, state_dict, is_strict=False):
+        """Tolerant loader (image_unet.py:651-672): drops shape-mismatched keys, logs missing / unused ones."""
+        own = self.state_dict()
+        for key, val in own.items():
+            if key in state_dict:
+                if val.shape != state_dict[key].shape:
+                    state_dict.pop(key)
+                    logger.log("{} not matchable with state_dict with shape {}".format(key, val.shape))
+            else:
+                logger.log("{} not exists in state_dict".format(key))
+        for key in state_dict:
+            if key not in own:
+                logger.log("{} not used in state_dict".format(key))
+        self.load_state_dict(state_dict, strict=is_strict)
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self._packed = None
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._packed = None
+        return out
+
+    # ------------------------------------------------------------------ packed weights
+    def _pack(self, device):
+        P = {k: v.detach() for k, v in self.named_parameters()}
+        dt = self.dtype
+        W = {}
+        f32 = lambda t: t.float().contiguous()          # noqa: E731
+        plan_in, plan_mid, plan_out = self._plan
+        for layers in plan_in + [plan_mid] + plan_out:
+            for L in layers:
+                kind, pre = L[0], L[1]
+                if kind == "stem":
+                    W[pre] = (ops.pack_edge_weight(P[pre + ".weight"]), f32(P[pre + ".bias"]))
+                elif kind == "res":
+                    cin, cout = L[2], L[3]
+                    W[pre] = dict(
+                        g1=f32(P[pre + ".in_layers.0.weight"]), b1=f32(P[pre + ".in_layers.0.bias"]),
+                        w_in=ops.pack_conv_weight(P[pre + ".in_layers.2.weight"].float(), dt), b_in=f32(P[pre + ".in_layers.2.bias"]),
+                        w_e=f32(P[pre + ".emb_layers.1.weight"]), b_e=f32(P[pre + ".emb_layers.1.bias"]),
+                        g2=f32(P[pre + ".out_layers.0.weight"]), b2=f32(P[pre + ".out_layers.0.bias"]),
+                        w_out=ops.pack_conv_weight(P[pre + ".out_layers.3.weight"].float(), dt), b_out=f32(P[pre + ".out_layers.3.bias"]),
+                        w_skip=None if cin == cout else ops.pack_conv_weight(P[pre + ".skip_connection.weight"].float(), dt),
+                        b_skip=None if cin == cout else f32(P[pre + ".skip_connection.bias"]))
+                else:
+                    C, heads = L[2], L[3]
+                    ch = C // heads
+                    wq, bq = P[pre + ".qkv.weight"].float().reshape(3 * C, C), P[pre + ".qkv.bias"].float()
+                    if not self.use_new_attention_order:     # legacy rows [head][q|k|v][ch] -> [q|k|v][head][ch]
+                        perm = torch.arange(3 * C, device=wq.device).reshape(heads, 3, ch).permute(1, 0, 2).reshape(-1)
+                        wq, bq = wq[perm], bq[perm]
+                    W[pre] = dict(g=f32(P[pre + ".norm.weight"]), b=f32(P[pre + ".norm.bias"]), w_qkv=wq.to(dt).contiguous(), b_qkv=bq.contiguous(),
+                                  w_proj=P[pre + ".proj_out.weight"].float().reshape(C, C).to(dt).contiguous(), b_proj=f32(P[pre + ".proj_out.bias"]))
+        W["time_embed"] = tuple(f32(P[k]) for k in ("time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias"))
+        W["out"] = (f32(P["out.0.weight"]), f32(P["out.0.bias"]), ops.pack_edge_weight(P["out.2.weight"]), f32(P["out.2.bias"]))
+        self._packed = (str(device), dt, W)
+        return W
+
+    # ------------------------------------------------------------------ forward
+    def _res(self, x, semb, N, Hh, L, W):
+        _, pre, cin, cout, updown = L
+        w = W[pre]
+        geom = Geom.per_sample(N, Hh * Hh)
+        a, b = ops.gn_stats(x, w["g1"], w["b1"], geom)
+        h = ops.gn_apply(x, a, b, geom, act=True)
+        if updown is not None:
+            Ho = Hh // 2 if updown == "down" else Hh * 2
+            mode = 0 if updown == "down" else 1
+            h2 = torch.empty(N * Ho * Ho, cin, dtype=x.dtype, device=x.device)
+            x2 = torch.empty(N * Ho * Ho, cin, dtype=x.dtype, device=x.device)
+            ops.resample(h, h2, N, Hh, Hh, 2, 2, mode)
+            ops.resample(x, x2, N, Hh, Hh, 2, 2, mode)
+            h, x, Hh = h2, x2, Ho
+            geom = Geom.per_sample(N, Hh * Hh)
+        h = ops.conv_gemm(h, w["w_in"], w["b_in"], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh))
+        emb_out = torch.empty(N, w["w_e"].shape[0], dtype=torch.float32, device=x.device)
+        ops.linear(semb, w["w_e"], w["b_e"], emb_out)
+        if self.use_scale_shift_norm:
+            a, b = ops.gn_stats(h, w["g2"], w["b2"], geom, film=emb_out)
+        else:
+            ops.add_rowbias(h, emb_out, Hh * Hh)
+            a, b = ops.gn_stats(h, w["g2"], w["b2"], geom)
+        h = ops.gn_apply(h, a, b, geom, act=True)
+        skip = x if w["w_skip"] is None else ops.conv_gemm(x, w["w_skip"], w["b_skip"])
+        return ops.conv_gemm(h, w["w_out"], w["b_out"], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh), residual=skip), Hh
+
+    def _attn(self, x, N, Hh, L, W):
+        _, pre, C, heads = L
+        w = W[pre]
+        T = Hh * Hh
+        geom = Geom.per_sample(N, T)
+        a, b = ops.gn_stats(x, w["g"], w["b"], geom)
+        xn = ops.gn_apply(x, a, b, geom, act=False)
+        qkv = ops.conv_gemm(xn, w["w_qkv"], w["b_qkv"])
+        att = torch.empty(N * T, C, dtype=x.dtype, device=x.device)
+        ops.attn(qkv, qkv, att, heads, C // heads, N, 1, T, T, T, T, 1)
+        return ops.conv_gemm(att, w["w_proj"], w["b_proj"], residual=x)
+
+    def _run(self, x6, timesteps):
+        """x6: fp32 API-layout input [N, in_channels, H, W] (already concatenated for the SR model)."""
+        if not x6.is_cuda:
+            raise MMDError("ImageUnet runs on the MI355X HIP path only (GPU tensors); there is no CPU/torch fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x6.requires_grad:
+            raise NotImplementedError("ImageUnet: the SR model is inference-only on the HIP path")
+        dev = x6.device
+        if self._packed is None or self._packed[0] != str(dev) or self._packed[1] != self.dtype:
+            self._pack(dev)
+        W = self._packed[2]
+        dt = self.dtype
+        N, Cin, Hh, Ww = x6.shape
+        assert Hh == Ww, "square images only"
+        mc = self.model_channels
+        te = W["time_embed"]
+        # time_embed MLP (fp32), then SiLU: every emb_layers Sequential starts with SiLU (image_unet.py:176-182)
+        e0 = torch.empty(N, mc, dtype=torch.float32, device=dev)
+        ops.timestep_embedding(timesteps.contiguous(), mc, e0)
+        e1 = torch.empty(N, 4 * mc, dtype=torch.float32, device=dev)
+        ops.linear(e0, te[0], te[1], e1)
+        ops.silu(e1, None, e1)
+        emb = torch.empty(N, 4 * mc, dtype=torch.float32, device=dev)
+        ops.linear(e1, te[2], te[3], emb)
+        semb = torch.empty_like(emb)
+        ops.silu(emb, None, semb)
+        plan_in, plan_mid, plan_out = self._plan
+        hs = []
+        h = None
+        for layers in plan_in:
+            for L in layers:
+                if L[0] == "stem":
+                    h = torch.empty(N * Hh * Hh, L[3], dtype=dt, device=dev)
+                    ops.stem_conv(x6.float().contiguous().view(N, 1, Cin, Hh, Hh), W[L[1]][0], W[L[1]][1], h, N, 1, Cin, Hh, Hh, ops.TAPS_SPATIAL)
+                elif L[0] == "res":
+                    h, Hh = self._res(h, semb, N, Hh, L, W)
+                else:
+                    h = self._attn(h, N, Hh, L, W)
+            hs.append(h)
+        for L in plan_mid:
+            h = self._res(h, semb, N, Hh, L, W)[0] if L[0] == "res" else self._attn(h, N, Hh, L, W)
+        for layers in plan_out:
+            skip = hs.pop()
+            cat = torch.empty(h.shape[0], h.shape[1] + skip.shape[1], dtype=dt, device=dev)       # th.cat([h, hs.pop()], dim=1)
+            ops.copy2d(h, cat[:, :h.shape[1]])
+            ops.copy2d(skip, cat[:, h.shape[1]:])
+            h = cat
+            for L in layers:
+                if L[0] == "res":
+                    h, Hh = self._res(h, semb, N, Hh, L, W)
+                else:
+                    h = self._attn(h, N, Hh, L, W)
+        g, b, w_out, b_out = W["out"]
+        geom = Geom.per_sample(N, Hh * Hh)
+        a, bb = ops.gn_stats(h, g, b, geom)
+        h = ops.gn_apply(h, a, bb, geom, act=True)
+        out = torch.empty(N, 1, self.out_channels, Hh, Hh, dtype=torch.float32, device=dev)
+        ops.head_conv(h, w_out, b_out, out, N, 1, Hh, Hh, ops.TAPS_SPATIAL)
+        return out.view(N, self.out_channels, Hh, Hh)
+
+    def forward(self, x, timesteps, y=None):
+        assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
+        return self._run(x, timesteps)
+
+
+class ImageSuperResModel(ImageUnet):
+    """U-Net conditioned on a low-resolution image: bilinear upsample + channel concat (image_unet.py:700-715)."""
+
+    def __init__(self, image_size, in_channels, *args, **kwargs):
+        super().__init__(image_size, in_channels * 2, *args, **kwargs)
+
+    def forward(self, x, timesteps, low_res=None, **kwargs):
+        if low_res is None:
+            raise MMDError("ImageSuperResModel.forward needs low_res")
+        H.require_cuda(x, low_res)
+        N, C, Hh, Ww = x.shape
+        x6 = torch.empty(N, 2 * C, Hh, Ww, dtype=torch.float32, device=x.device)
+        ops.bilinear_concat(x.float().contiguous(), low_res.float().contiguous(), x6)
+        return super().forward(x6, timesteps, **kwargs)

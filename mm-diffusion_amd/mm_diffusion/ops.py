@@ -348,6 +348,15 @@ def lincomb(a, ca, b=None, cb=0.0, c=None, cc=0.0, out=None):
     return out
 
 
+def bilinear_concat(x, low, out):
+    """out [N,2C,H,W] = concat(x, bilinear-upsampled low) (fp32 API layout): the SR model's input."""
+    H.require_cuda(x, low, out)
+    N, C, Hh, Ww = x.shape
+    _dispatch("mmd_bilinear_concat", x.data_ptr(), low.data_ptr(), out.data_ptr(), N, C, Hh, Ww, low.shape[2], low.shape[3],
+              meta=("bilinear_concat", 0, 4 * (x.numel() + low.numel() + out.numel())))
+    return out
+
+
 def abs_quantile(x, q):
     """per-sample q-quantile of |x| (fp32 contiguous [N, ...]) -> fp32 [N]."""
     H.require_cuda(x)

@@ -9,7 +9,7 @@ can rebuild bit-identical weights without any weight file:
 
     g = torch.Generator().manual_seed(crc32(key))
     weight (ndim >= 2) : randn(shape, g) / sqrt(fan_in)     (fan_in = prod(shape[1:]))
-    GroupNorm weight   : 1 + 0.1 * randn(shape, g)
+    GroupNorm weight   : 1 + 0.1 * randn(shape, g)      (= every 1-D '.weight')
     every bias / GroupNorm bias : 0.1 * randn(shape, g)
 
 This keeps activations O(1) through the whole network, so an error in any
@@ -31,7 +31,7 @@ def synth_tensor(key: str, shape) -> torch.Tensor:
         for s in shape[1:]:
             fan_in *= s
         return x / math.sqrt(fan_in)
-    if key.endswith("GroupNorm.weight"):
+    if key.endswith(".weight"):          # every 1-D weight is a GroupNorm gain ("...GroupNorm.weight", image U-Net "...norm.weight")
         return 1.0 + 0.1 * x
     return 0.1 * x
 

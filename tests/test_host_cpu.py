@@ -117,3 +117,26 @@ def test_shard_batch_partition():
         assert parts[0][0] == 0 and parts[-1][1] == gb
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
         assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+
+
+def test_sr_model_surface_matches_reference_keys():
+    """image_sr_create_model_and_diffusion: same default flag set, and the tiny SR model registers exactly the reference's
+    state-dict keys / shapes / order (tests/golden/sr_state_dict_keys.json, captured from the reference)."""
+    import json
+    import os
+    from helpers import GOLD
+    from mm_diffusion import script_util as su
+    d = su.image_sr_model_and_diffusion_defaults()
+    assert d["sr_learn_sigma"] is True and d["large_size"] == 256 and "diffusion_steps" not in d and "sr_diffusion_steps" in d
+    d.update(large_size=64, small_size=16, sr_num_channels=32, sr_num_res_blocks=1, sr_attention_resolutions="2,4", sr_num_heads=2,
+             sr_resblock_updown=True, sr_timestep_respacing="ddim4")
+    model, diff = su.image_sr_create_model_and_diffusion(**d)
+    with open(os.path.join(GOLD, "sr_state_dict_keys.json")) as f:
+        keys = json.load(f)["tiny"]
+    assert [(k, list(v.shape)) for k, v in model.state_dict().items()] == [(k, s) for k, s in keys]
+    assert diff.num_timesteps == 4 and len(diff.timestep_map) == 4
+    import pytest
+    import torch
+    from mm_diffusion._hip import MMDError
+    with pytest.raises(MMDError):                      # no CPU fallback
+        model(torch.zeros(1, 3, 64, 64), torch.zeros(1, dtype=torch.int64), low_res=torch.zeros(1, 3, 16, 16))

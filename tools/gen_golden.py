@@ -320,6 +320,44 @@ def gen_dpm(tag, seed, predict_x0, thresholding, **sample_kw):
     save(tag, seed=seed, B=B, shifts=np.asarray(rec.draws), nfe=len(rec.draws) // 9, video=out["video"], audio=out["audio"])      # 9 shift draws per tiny forward
 
 
+SR_TINY = dict(large_size=64, small_size=16, sr_num_channels=32, sr_num_res_blocks=1, sr_attention_resolutions="2,4", sr_num_heads=2,
+               sr_resblock_updown=True)
+
+
+def _sr_build(**over):
+    from ref_mm import script_util as rsu
+    d = rsu.image_sr_model_and_diffusion_defaults()
+    d.update(SR_TINY)
+    d.update(over)
+    model, diff = rsu.image_sr_create_model_and_diffusion(**d)
+    synth_init(model).eval()
+    return d, model, diff
+
+
+def gen_sr():
+    """Image super-resolution U-Net (image_unet.ImageSuperResModel) + its tensor-valued diffusion: state-dict keys, one forward,
+    a DDIM loop and a DDPM loop with the clip-repeated start noise of multimodal_sample_sr.py:191-196."""
+    d, model, diff = _sr_build()
+    with open(os.path.join(GOLD, "sr_state_dict_keys.json"), "w") as f:
+        json.dump({"tiny": [[k, list(v.shape)] for k, v in model.state_dict().items()]}, f)
+    g = th.Generator().manual_seed(71)
+    B = 2
+    x = th.randn(B, 3, 64, 64, generator=g)
+    low = th.rand(B, 3, 16, 16, generator=g) * 2 - 1
+    t = th.tensor([3, 977])
+    with th.no_grad():
+        y = model(x, t, low_res=low)
+    save("sr_tiny_forward", x=x, low=low, t=t, y=y)
+    for tag, resp, fn, kw in (("sr_tiny_ddim4", "ddim4", "ddim_sample_loop", {}), ("sr_tiny_ddpm3", "3", "p_sample_loop", dict(progress=False))):
+        d, model, diff = _sr_build(sr_timestep_respacing=resp)
+        th.manual_seed(72)
+        noise = th.randn(1, 3, 64, 64).repeat(B, 1, 1, 1)
+        with th.no_grad():
+            out = getattr(diff, fn)(model, (B, 3, 64, 64), clip_denoised=True, model_kwargs={"low_res": low}, noise=noise.clone(),
+                                    device=th.device("cpu"), **kw)
+        save(tag, low=low, noise=noise, sample=out, timestep_map=np.asarray(diff.timestep_map))
+
+
 def gen_helpers():
     """q_mean_variance / q_posterior_mean_variance / _predict_* (gd:170-229,345-366) on random inputs."""
     f = flags("tiny", timestep_respacing="")
@@ -351,6 +389,7 @@ ALL = {
     "tiny_cond_guided_v": lambda: gen_cond("tiny", 1, 52, "4", "video", 3.0),
     "tiny_cond_guided_a": lambda: gen_cond("tiny", 1, 53, "2", "audio", 3.0),
     "helpers": gen_helpers,
+    "sr": gen_sr,
     "dpm_singlestep3": lambda: gen_dpm("tiny_dpm_singlestep3", 61, False, False, steps=20, order=3, skip_type="logSNR", method="singlestep"),
     "dpm_singlestep2": lambda: gen_dpm("tiny_dpm_singlestep2", 62, False, False, steps=7, order=2, skip_type="time_quadratic", method="singlestep"),
     "dpm_multistep2": lambda: gen_dpm("tiny_dpm_multistep2", 63, False, False, steps=10, order=2, skip_type="time_uniform", method="multistep"),
