@@ -144,7 +144,7 @@ def train_bench(args, world, rank, device):
     model, diff = msu.create_model_and_diffusion(**fl)
     synth_init_(model)
     model.to(device).train()
-    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0, ema_rates=[0.9999])
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0, ema_rates=[0.9999], pack_dtype=model.dtype)
     g = torch.Generator().manual_seed(4321 + rank)
     random.seed(4321 + rank)
     torch.manual_seed(4321 + rank)
@@ -152,8 +152,15 @@ def train_bench(args, world, rank, device):
     x0 = {"video": (torch.rand(B, *fl["video_size"], generator=g) * 2 - 1).to(device),
           "audio": (torch.rand(B, *fl["audio_size"], generator=g) * 2 - 1).to(device)}
 
+    gstep = None
+    if not args.no_graph:         # forward + backward replayed from one captured graph (mm_diffusion/train_graph.py)
+        from mm_diffusion.train_graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, diff, opt, x0)
+
     def one_step():
         t = torch.randint(0, diff.num_timesteps, (B,), generator=g).to(device)
+        if gstep is not None:
+            return gstep.step(x0, t)["loss"].mean()
         opt.zero_grad()
         loss = diff.multimodal_training_losses(model, x0, t)["loss"].mean()
         loss.backward()
@@ -185,7 +192,8 @@ def train_bench(args, world, rank, device):
             "metric": "training steps/sec (multimodal_training_losses fwd+bwd+AdamW, video+audio pairs)", "value": args.steps * B * world / elapsed,
             "unit": "pair-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[3]: base model training step, per-GPU batch {B}, dropout 0.1, flat-buffer gradient all-reduce",
+            "config": {"workload": f"BASELINE configs[3]: base model training step, per-GPU batch {B}, dropout 0.1, flat-buffer gradient all-reduce, "
+                                   f"{'eager' if gstep is None else 'graph-captured forward+backward'}",
                        "global_batch": B * world, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9},
             "host_ms_per_step": 1000 * host_elapsed / args.steps,
             "model_tflops": 3 * MODEL_FLOPS_PER_PAIR * B * args.steps / elapsed / 1e12}))
@@ -317,6 +325,7 @@ def main():
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "dpm", "sr"],
                     help="sample = headline DDPM step (default); train = configs[3]; dpm = configs[4] base-model half (DPM-Solver++ 50 NFE); sr = configs[4] SR half (DDIM-25 on 256x256 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="train mode: eager step instead of the graph-captured one")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-out", default="")
     args = ap.parse_args()

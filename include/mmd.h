@@ -143,7 +143,16 @@ int mmd_loss_terms(const float* x0, const float* xt, const float* model_out, con
  * conv wgrad: dW fp32 [Cout][ntaps*Cin] += dY^T gather(X) (same tap semantics as mmd_conv_gemm; caller zeroes dW), db
  * (nullable, fp32 [Cout]) += column sums of dY.  conv dgrad = mmd_conv_gemm(dY, W^T-packed, taps negated). */
 int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, float* db, int M, int Cout, int Cin,
-                   int ntaps, const int* taps, int D0, int D1, int D2, void* stream);
+                   int ntaps, const int* taps, int D0, int D1, int D2, int torch_layout, void* stream);
+/* Re-pack every conv weight in ONE launch after an optimizer step.  descs_dev: device array of n records
+ *   { const float* src; void* fwd; void* bwd; int Cout, Cin, nt; int block_start; }   (block_start = running sum of ceil(Cout*Cin*nt / 2048))
+ * src fp32 [Cout][Cin][nt] (torch conv layout) -> fwd [Cout][nt*Cin] (mmd_conv_gemm operand of the forward conv) and
+ * bwd [Cin][nt*Cout] (operand of the data-gradient conv), both in `dtype`.  mmd_conv_wgrad with torch_layout = 1 accumulates
+ * dW directly in [Cout][Cin][nt], i.e. straight into the parameter's .grad. */
+int mmd_pack_conv_weights(int dtype, const void* descs_dev, int n, int total_blocks, void* stream);
+/* Gradient counterpart, once per step: for every record (same struct; src = the parameter's fp32 .grad [Cout][Cin][nt], fwd = an
+ * fp32 packed accumulation buffer [Cout][nt*Cin] that mmd_conv_wgrad filled with coalesced atomics) grad += packed, packed = 0. */
+int mmd_unpack_conv_grads(const void* descs_dev, int n, int total_blocks, void* stream);
 /* GroupNorm32(+FiLM)(+SiLU) backward; a, b, mr from the forward mmd_gn_stats; dgamma/dbeta accumulate; dfilm (nullable)
  * [S, >=2C] receives (dscale | dshift); workspace (S*C*2 + S*64) floats. */
 int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C, int S,

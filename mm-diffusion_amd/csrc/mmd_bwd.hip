@@ -7,13 +7,16 @@
 //   elementwise  SiLU forward/backward, d(mse)/d(out), AdamW (+EMA)
 // Accumulation into dW / db uses fp32 L2 atomics over row splits (like the vendor conv backward, run-to-run bit
 // differences of the last ulp are possible); everything else is deterministic.
+#include <cstdlib>
+
 #include "mmd_common.h"
 
 // ============================================================================= conv wgrad (implicit GEMM-TN on MFMA)
 struct WgradParams {
   const char* dY; int64_t lddy;      // [M, Cout]
   const char* X; int64_t ldx;        // [rows, Cin]
-  float* dW;                         // fp32 [Cout][ntaps*Cin], accumulated with atomics
+  float* dW;                         // fp32, accumulated with atomics: [Cout][ntaps*Cin] (packed) or [Cout][Cin][ntaps] (torch conv layout)
+  int torch_layout;
   int M, Cout, Cin, ntaps;
   int D0, D1, D2;
   int rows_per_split;
@@ -95,8 +98,122 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (co < p.Cout && ci < p.Cin) atomicAdd(p.dW + (int64_t)co * K + (int64_t)tap * p.Cin + ci, acc[r]);
+    if (co < p.Cout && ci < p.Cin)
+      atomicAdd(p.dW + (int64_t)co * K + (p.torch_layout ? (int64_t)ci * p.ntaps + tap : (int64_t)tap * p.Cin + ci), acc[r]);
   }
+}
+
+// bf16 weight gradient, 128 (co) x 128 (ci of ONE tap) tile per block, 4 waves each 64 x 64 (2 x 2 MFMA tiles).
+// The reduction index is the row m, so both MFMA operands need 8 CONSECUTIVE ROWS of one channel per lane.  The 64-tile kernel
+// above stages row-major and gathers every fragment with eight 2-byte LDS reads (16 reads per MFMA); here the 64-row chunk is
+// transposed while it is stored to LDS ([channel][64 rows], 136-byte pitch: the 32-rows x 2-vectors lane pattern of the
+// attention V^T staging, conflict free) and a fragment is two ds_read_b64 - 4 LDS reads per 4 MFMAs.  The next chunk's global
+// loads are in flight under the MFMAs (register prefetch).
+#define WG_PITCH 136
+__global__ __launch_bounds__(256, 2) void wgrad128_bf16_kernel(const WgradParams p) {
+  __shared__ __attribute__((aligned(16))) char sA[128 * WG_PITCH];      // dY^T chunk: [co][m]
+  __shared__ __attribute__((aligned(16))) char sB[128 * WG_PITCH];      // X^T  chunk: [ci][m]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = (p.Cin + 127) / 128;
+  const int kt = blockIdx.y;
+  const int tap = kt / ci_tiles, ci0 = (kt % ci_tiles) * 128;
+  const int co0 = blockIdx.x * 128;
+  const int o0 = p.taps[tap * 3], o1 = p.taps[tap * 3 + 1], o2 = p.taps[tap * 3 + 2];
+  const int D12 = p.D1 * p.D2;
+  const int64_t roff = (int64_t)o0 * D12 + o1 * p.D2 + o2;
+  const int m_begin = blockIdx.z * p.rows_per_split;
+  const int m_end = min(m_begin + p.rows_per_split, p.M);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging slots of this thread: 4 x (row j, 8-channel vector v) per operand
+  int sj[4], sv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 256 * i;
+    sj[i] = (id & 31) + 32 * ((id >> 6) & 1);
+    sv[i] = 2 * (id >> 7) + ((id >> 5) & 1);
+  }
+  u32x4 ra[4], rb[4];
+  auto load_chunk = [&](int mc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mc + sj[i];
+      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+      if (m < m_end) {
+        if (co0 + sv[i] * 8 < p.Cout) a = *(const u32x4*)(p.dY + ((int64_t)m * p.lddy + co0 + sv[i] * 8) * 2);
+        const int p2 = m % p.D2, p1 = (m / p.D2) % p.D1, p0 = (m / D12) % p.D0;
+        if (ci0 + sv[i] * 8 < p.Cin && (unsigned)(p0 + o0) < (unsigned)p.D0 && (unsigned)(p1 + o1) < (unsigned)p.D1 &&
+            (unsigned)(p2 + o2) < (unsigned)p.D2)
+          b = *(const u32x4*)(p.X + (((int64_t)m + roff) * p.ldx + ci0 + sv[i] * 8) * 2);
+      }
+      ra[i] = a;
+      rb[i] = b;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint16_t* da = (uint16_t*)(sA + (8 * sv[i]) * WG_PITCH + 2 * sj[i]);
+      uint16_t* db = (uint16_t*)(sB + (8 * sv[i]) * WG_PITCH + 2 * sj[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        da[e * (WG_PITCH / 2)] = (uint16_t)((ra[i][e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        db[e * (WG_PITCH / 2)] = (uint16_t)((rb[i][e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      }
+    }
+  };
+
+  load_chunk(m_begin);
+  for (int mc = m_begin; mc < m_end; mc += 64) {
+    __syncthreads();                 // previous chunk fully consumed
+    store_chunk();
+    __syncthreads();
+    if (mc + 64 < m_end) load_chunk(mc + 64);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const char* q = sA + (wi * 64 + a * 32 + l31) * WG_PITCH + (16 * ks + 8 * half) * 2;
+        const u32x2 v0 = *(const u32x2*)q, v1 = *(const u32x2*)(q + 8);
+        fa[a] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const char* q = sB + (wj * 64 + b * 32 + l31) * WG_PITCH + (16 * ks + 8 * half) * 2;
+        const u32x2 v0 = *(const u32x2*)q, v1 = *(const u32x2*)(q + 8);
+        fb[b] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+    }
+  }
+  // D[row = co][col = ci]: lane holds ci = l31, co = (r&3) + 8*(r>>2) + 4*half of its 32x32 tile
+  const int64_t K = (int64_t)p.Cin * p.ntaps;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ci = ci0 + wj * 64 + b * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < p.Cout && ci < p.Cin)
+          atomicAdd(p.dW + (int64_t)co * K + (p.torch_layout ? (int64_t)ci * p.ntaps + tap : (int64_t)tap * p.Cin + ci), acc[a][b][r]);
+      }
+    }
 }
 
 // db[c] += sum over rows of dY[m, c]
@@ -377,24 +494,36 @@ static inline int ew_grid_b(int64_t total) { return (int)min((int64_t)4096, (tot
 
 // dW (fp32 [Cout][ntaps*Cin], caller zeroes it) += dY^T * gather(X); db (nullable, fp32 [Cout], zeroed) += colsum(dY).
 extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, float* db, int M, int Cout,
-                              int Cin, int ntaps, const int* taps, int D0, int D1, int D2, void* stream) {
+                              int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int torch_layout, void* stream) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_wgrad: bad dtype");
   MMD_REQUIRE(dY && X && dW && taps && M > 0 && ntaps >= 1 && ntaps <= 27, "conv_wgrad: bad argument");
   MMD_REQUIRE(Cin % epv == 0 && Cout % epv == 0 && lddy % epv == 0 && ldx % epv == 0, "conv_wgrad: channel counts / strides must be 16-byte multiples");
   MMD_REQUIRE(((uintptr_t)dY | (uintptr_t)X) % 16 == 0, "conv_wgrad: unaligned pointer");
   WgradParams p;
-  p.dY = (const char*)dY; p.lddy = lddy; p.X = (const char*)X; p.ldx = ldx; p.dW = dW;
+  p.dY = (const char*)dY; p.lddy = lddy; p.X = (const char*)X; p.ldx = ldx; p.dW = dW; p.torch_layout = torch_layout;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
-  const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64) * ntaps;
-  int splits = max(1, min(cdiv(M, 256), 2048 / max(tiles, 1)));
-  p.rows_per_split = cdiv(cdiv(M, splits), 64) * 64;
-  splits = cdiv(M, p.rows_per_split);
-  dim3 grid(cdiv(Cout, 64), cdiv(Cin, 64) * ntaps, splits);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MMD_BF16) hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, p);
+  static const bool use128 = getenv("MMD_WGRAD_TILE64") == nullptr;      // A/B switch for tools/wgrad_bench.py
+  if (use128 && dtype == MMD_BF16 && Cout >= 64 && Cin >= 64) {          // transposed-staging 128x128 kernel
+    const int tiles = cdiv(Cout, 128) * cdiv(Cin, 128) * ntaps;
+    // blocks per launch: every split adds Cout*Cin*ntaps atomics on the same addresses, so pointwise convs (few tiles) get
+    // fewer, longer splits (measured: 512 blocks for 1x1, 1536 for 3-/9-tap convs; tools/wgrad_bench.py)
+    const int target = getenv("MMD_WGRAD_BLOCKS") ? atoi(getenv("MMD_WGRAD_BLOCKS")) : (torch_layout ? 512 : (ntaps > 1 ? 1536 : 512));
+    int splits = max(1, min(cdiv(M, 256), target / max(tiles, 1)));
+    p.rows_per_split = cdiv(cdiv(M, splits), 64) * 64;
+    splits = cdiv(M, p.rows_per_split);
+    hipLaunchKernelGGL(wgrad128_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), 0, st, p);
+  } else {
+    const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64) * ntaps;
+    int splits = max(1, min(cdiv(M, 256), 2048 / max(tiles, 1)));
+    p.rows_per_split = cdiv(cdiv(M, splits), 64) * 64;
+    splits = cdiv(M, p.rows_per_split);
+    dim3 grid(cdiv(Cout, 64), cdiv(Cin, 64) * ntaps, splits);
+    if (dtype == MMD_BF16) hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, p);
+  }
   int rc = mmd_check_launch("conv_wgrad");
   if (rc || !db) return rc;
   MMD_REQUIRE(Cout / epv <= 256, "conv_wgrad: Cout too wide for colsum");
@@ -402,6 +531,10 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
   if (dtype == MMD_BF16) hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
   else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
   return mmd_check_launch("colsum");
+}
+
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
 }
 
 // GroupNorm(+FiLM)(+SiLU) backward.  a, b [S,C] and mr [S,32,2] (mean, rstd) come from the forward mmd_gn_stats.
@@ -419,7 +552,10 @@ extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy,
   hipStream_t st = (hipStream_t)stream;
   float* PQ = workspace;
   float* m12 = workspace + (int64_t)S * C * 2;
-  if (hipMemsetAsync(PQ, 0, (size_t)S * C * 2 * sizeof(float), st) != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "gn_bwd: memset failed");
+  // zeroed by a kernel, not hipMemsetAsync: memset nodes of a captured graph were observed to lose their ordering against the
+  // neighbouring kernel nodes on replay (train_graph.py), a fill kernel is an ordinary node of the chain
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(ew_grid_b((int64_t)S * C * 2)), dim3(256), 0, st, PQ, (int64_t)S * C * 2);
+  if (int zrc = mmd_check_launch("gn_bwd_zero")) return zrc;
   const int rpp = max(1, 256 / (C / epv));
   int R = 4 * rpp;
   while ((int64_t)S * cdiv(Tn, R) > 1280 && R < 1024) R *= 2;
@@ -480,4 +616,66 @@ extern "C" int mmd_adamw_step(float* p, const float* g, float* m, float* v, floa
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid_b(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, lr, beta1, beta2, eps, weight_decay,
                      bc1, bc2, ema_rate);
   return mmd_check_launch("adamw_step");
+}
+
+// ----------------------------------------------------------------------------- weight packing for the training step
+// One launch re-packs EVERY conv weight after an optimizer step: src fp32 [Cout][Cin][nt] (torch conv layout, a view of the
+// flat parameter buffer) -> fwd [Cout][nt*Cin] (GEMM operand of the forward conv) and bwd [Cin][nt*Cout] (operand of the
+// data-gradient conv) in the activation dtype.  The per-weight torch version was ~6 tiny kernels per conv per step.
+struct PackDesc {
+  const float* src; void* fwd; void* bwd;
+  int Cout, Cin, nt;
+  int block_start;                 // first block of this weight; blocks cover 2048 source elements each
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {                // last descriptor whose block_start <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const int64_t total = (int64_t)d.Cout * d.Cin * d.nt;
+  const int64_t e0 = (int64_t)((int)blockIdx.x - d.block_start) * 2048;
+  for (int64_t e = e0 + threadIdx.x; e < min(e0 + 2048, total); e += 256) {
+    const int tap = (int)(e % d.nt), ci = (int)((e / d.nt) % d.Cin), co = (int)(e / ((int64_t)d.nt * d.Cin));
+    const float v = d.src[e];
+    Elt<T>::st(d.fwd, (int64_t)co * d.nt * d.Cin + (int64_t)tap * d.Cin + ci, v);
+    Elt<T>::st(d.bwd, (int64_t)ci * d.nt * d.Cout + (int64_t)tap * d.Cout + co, v);
+  }
+}
+// Reverse direction for the gradients: wgrad accumulates with COALESCED atomics in the packed layout [Cout][nt*Cin] (fp32, `fwd` of
+// the record); once per step this adds every packed gradient into the parameter's .grad ([Cout][Cin][nt], `src` of the record,
+// written here) and clears the packed buffer for the next step.  (Atomics straight into the torch layout are strided by nt
+// floats: 18 64-byte segments per wave instruction instead of 2.)
+__global__ __launch_bounds__(256) void unpack_grads_kernel(const PackDesc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const int64_t total = (int64_t)d.Cout * d.Cin * d.nt;
+  const int64_t e0 = (int64_t)((int)blockIdx.x - d.block_start) * 2048;
+  float* grad = const_cast<float*>(d.src);
+  float* packed = (float*)d.fwd;
+  for (int64_t e = e0 + threadIdx.x; e < min(e0 + 2048, total); e += 256) {      // e walks the PACKED layout (coalesced reads)
+    const int ci = (int)(e % d.Cin), tap = (int)((e / d.Cin) % d.nt), co = (int)(e / ((int64_t)d.nt * d.Cin));
+    const float v = packed[e];
+    packed[e] = 0.f;
+    grad[((int64_t)co * d.Cin + ci) * d.nt + tap] += v;
+  }
+}
+extern "C" int mmd_unpack_conv_grads(const void* descs_dev, int n, int total_blocks, void* stream) {
+  MMD_REQUIRE(descs_dev && n > 0 && total_blocks > 0, "unpack_conv_grads: bad argument");
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n);
+  return mmd_check_launch("unpack_conv_grads");
+}
+
+extern "C" int mmd_pack_conv_weights(int dtype, const void* descs_dev, int n, int total_blocks, void* stream) {
+  MMD_REQUIRE((dtype == MMD_BF16 || dtype == MMD_F32) && descs_dev && n > 0 && total_blocks > 0, "pack_conv_weights: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMD_BF16) hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(total_blocks), dim3(256), 0, st, (const PackDesc*)descs_dev, n);
+  else hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(total_blocks), dim3(256), 0, st, (const PackDesc*)descs_dev, n);
+  return mmd_check_launch("pack_conv_weights");
 }

@@ -41,7 +41,7 @@ _PROTOS = {
     "mmd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_loss_workspace_bytes": (i64, [i32]),
     "mmd_loss_terms": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
-    "mmd_conv_wgrad": (i32, [i32, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, vp]),
+    "mmd_conv_wgrad": (i32, [i32, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_gn_bwd": (i32, [i32, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp]),
     "mmd_attn_bwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32,
                            i32, i64, i64, i64, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp]),
@@ -58,6 +58,8 @@ _PROTOS = {
     "mmd_clamp_scale": (i32, [vp, vp, f32, i32, i64, vp]),
     "mmd_dpm_err": (i32, [vp, vp, vp, f32, f32, i32, i64, vp, vp]),
     "mmd_bilinear_concat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mmd_pack_conv_weights": (i32, [i32, vp, i32, i32, vp]),
+    "mmd_unpack_conv_grads": (i32, [vp, i32, i32, vp]),
     "mmd_silu": (i32, [i32, vp, vp, vp, i64, vp]),
     "mmd_dropout": (i32, [i32, vp, vp, f32, vp, i64, vp]),
     "mmd_mse_grad": (i32, [vp, vp, vp, vp, i32, i64, vp]),

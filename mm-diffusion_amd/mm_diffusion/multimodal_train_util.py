@@ -49,7 +49,8 @@ class TrainLoop:
         if use_db:
             raise NotImplementedError("wandb logging (use_db) is not built")
         self._load_and_sync_parameters()
-        self.opt = FlatAdamW(self.model.parameters(), lr=self.lr, weight_decay=self.weight_decay, ema_rates=self.ema_rate)
+        self.opt = FlatAdamW(self.model.parameters(), lr=self.lr, weight_decay=self.weight_decay, ema_rates=self.ema_rate,
+                             pack_dtype=getattr(self.model, "dtype", None))
         self._names = [n for n, p in self.model.named_parameters() if p.requires_grad]
         if self.resume_step:
             self._load_optimizer_state()

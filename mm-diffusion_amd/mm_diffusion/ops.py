@@ -406,12 +406,13 @@ def loss_terms(model_out, target, tables, t, F, C, HW, flags, x0=None, xt=None, 
 
 
 # ------------------------------------------------------------------ training step (backward) wrappers
-def conv_wgrad(dy, x, dW, db, taps, dims):
-    """dW fp32 [Cout, ntaps*Cin] += dy^T gather(x); db fp32 [Cout] += colsum(dy)  (both pre-zeroed by the caller)."""
+def conv_wgrad(dy, x, dW, db, taps, dims, torch_layout=False):
+    """dW fp32 += dy^T gather(x) in [Cout, ntaps*Cin] (packed) or, with torch_layout, in the parameter's own [Cout, Cin, *k]
+    layout (so dW may be the parameter's .grad); db fp32 [Cout] += colsum(dy).  Accumulating: the caller owns the zeroing."""
     _chk2d(dy), _chk2d(x)
     arr, nt = H.taps_array(taps)
     _dispatch("mmd_conv_wgrad", H.dt_of(x), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), H.ptr(db),
-              dy.shape[0], dy.shape[1], x.shape[1], nt, arr, int(dims[0]), int(dims[1]), int(dims[2]),
+              dy.shape[0], dy.shape[1], x.shape[1], nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), 1 if torch_layout else 0,
               meta=("conv_wgrad", 2 * dy.shape[0] * dy.shape[1] * x.shape[1] * nt, 0))
 
 

@@ -28,7 +28,11 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        if not hasattr(self, "_map_cache"):
+            self._map_cache = {}          # device copies of timestep_map, shared by every wrapper (graph capture forbids new H2D copies)
+        w = _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        w._maps = self._map_cache
+        return w
 
     def _scale_timesteps(self, t):
         return t          # scaling is done by the wrapped model

@@ -114,7 +114,8 @@ def train_forward(model, video, audio, timesteps):
                                  ".audio_proj_out.audio_conv.weight", ".audio_proj_out.audio_conv.bias")]
 
         def run(vv, aa):
-            shift = int(draw(0, Fr - win)) if layer["shift"] else 0       # drawn at EVERY evaluation (forward and recompute)
+            shift = draw(0, Fr - win) if layer["shift"] else 0             # drawn at EVERY evaluation (forward and recompute)
+            shift = shift if torch.is_tensor(shift) else int(shift)       # device slot (graph-captured step) or python int
             vqkv = pw(gn(vv, p + ".v_norm", Geom.per_sample(N, Fr * HW), False), p + ".v_qkv")
             aqkv = pw(gn(aa, p + ".a_norm", Geom.per_sample(N, Ll), False), p + ".a_qkv")
             vatt, aatt = T.CrossAttnFn.apply(vqkv, aqkv, heads, N, Fr, HW, Ll, win, shift)

@@ -17,6 +17,19 @@ def _neg(taps):
     return [(-a, -b, -c) for a, b, c in taps]
 
 
+def _grad_slot(*params):
+    """The parameters' .grad buffers when the backward kernels may accumulate straight into them (fp32, contiguous, already
+    allocated - optim.FlatAdamW re-homes every .grad into one flat buffer), else None.  Skips the per-parameter zeros /
+    permute / AccumulateGrad kernels: ~2000 launches per training step of the base model."""
+    for p in params:
+        if not p.is_leaf:
+            return None
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not p.requires_grad:
+            return None
+    return [p.grad for p in params]
+
+
 class ConvFn(Function):
     """Y = conv(X) (+ R): implicit-GEMM forward, dgrad = same kernel on the transposed weight with mirrored taps,
     wgrad/bias grad = mmd_conv_wgrad.  weight in torch conv layout [Cout, Cin, *k]."""
@@ -24,25 +37,36 @@ class ConvFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, taps, dims):
         x = x.contiguous() if x.stride(1) != 1 else x
-        wp = ops.pack_conv_weight(weight.detach().float(), x.dtype)
+        pk = getattr(weight, "_mmd_packed", None)           # (fwd, bwd) kept current by optim.FlatAdamW's batched re-pack
+        wp = pk[0] if pk is not None and pk[0].dtype == x.dtype else ops.pack_conv_weight(weight.detach().float(), x.dtype)
         y = ops.conv_gemm(x, wp, bias.detach().float().contiguous(), taps=taps, dims=dims,
                           residual=None if residual is None else residual)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, bias)
         ctx.taps, ctx.dims, ctx.has_res = taps, dims, residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         dy = dy.contiguous()
         taps, dims = ctx.taps, ctx.dims
         Cout, Cin = weight.shape[0], weight.shape[1]
         nt = len(taps)
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().float().reshape(Cout, Cin, nt).permute(1, 2, 0).reshape(Cin, nt * Cout).to(x.dtype).contiguous()
+            pk = getattr(weight, "_mmd_packed", None)
+            wt = pk[1] if pk is not None and pk[1].dtype == x.dtype else \
+                weight.detach().float().reshape(Cout, Cin, nt).permute(1, 2, 0).reshape(Cin, nt * Cout).to(x.dtype).contiguous()
             dx = ops.conv_gemm(dy, wt, None, taps=_neg(taps), dims=dims)
         if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):      # frozen weights (gradient-guided sampling)
+            return dx, None, None, (dy if ctx.has_res else None), None, None
+        slot = _grad_slot(weight, bias)
+        if slot is not None:
+            acc = getattr(weight, "_mmd_wgrad", None)         # packed fp32 accumulator (coalesced atomics), folded into .grad once per step
+            if acc is not None:
+                ops.conv_wgrad(dy, x, acc, slot[1], taps, dims)
+            else:                                             # accumulate in the parameter's own layout, straight into .grad
+                ops.conv_wgrad(dy, x, slot[0], slot[1], taps, dims, torch_layout=True)
             return dx, None, None, (dy if ctx.has_res else None), None, None
         dW32 = torch.zeros(Cout, nt * Cin, dtype=torch.float32, device=x.device)
         db32 = torch.zeros(Cout, dtype=torch.float32, device=x.device)
@@ -68,6 +92,7 @@ class GroupNormFn(Function):
         a, b = ops.gn_stats(x, g32, b32, geom, film=f32, mr=mr)
         y = ops.gn_apply(x, a, b, geom, act=act)
         ctx.save_for_backward(x, a, b, mr, g32, b32, f32 if f32 is not None else torch.empty(0, device=x.device))
+        ctx.params = (gamma, beta)
         ctx.geom, ctx.act, ctx.has_film = geom, act, film is not None
         ctx.film_shape = None if film is None else tuple(film.shape)
         return y
@@ -79,9 +104,13 @@ class GroupNormFn(Function):
         dy = dy.contiguous()
         C = x.shape[1]
         dx = torch.empty_like(x)
+        dfilm = torch.empty(geom.S, 2 * C, dtype=torch.float32, device=x.device) if ctx.has_film else None
+        slot = _grad_slot(*ctx.params)
+        if slot is not None:
+            ops.gn_bwd(x, dy, dx, geom, a, b, mr, g32, b32, f32 if ctx.has_film else None, ctx.act, slot[0], slot[1], dfilm)
+            return dx, None, None, dfilm, None, None
         dgamma = torch.zeros(C, dtype=torch.float32, device=x.device)
         dbeta = torch.zeros(C, dtype=torch.float32, device=x.device)
-        dfilm = torch.empty(geom.S, 2 * C, dtype=torch.float32, device=x.device) if ctx.has_film else None
         ops.gn_bwd(x, dy, dx, geom, a, b, mr, g32, b32, f32 if ctx.has_film else None, ctx.act, dgamma, dbeta, dfilm)
         return dx, dgamma, dbeta, dfilm, None, None
 
@@ -142,14 +171,15 @@ class SelfAttnFn(Function):
 
 class CrossAttnFn(Function):
     """Random-shift windowed cross-modal attention, both directions (reference unit QKVAttention.forward):
-    video queries attend the audio window, audio queries the video window.  shift: python int (this call's draw)."""
+    video queries attend the audio window, audio queries the video window.  shift: python int (this call's draw) or a
+    1-element int32 device tensor (graph-captured training: the value is refreshed in place before every replay)."""
 
     @staticmethod
     def forward(ctx, vqkv, aqkv, heads, N, F, HW, L, win, shift):
         vqkv, aqkv = vqkv.contiguous(), aqkv.contiguous()
         C = vqkv.shape[1] // 3
         apf = int(L / F)
-        sh = torch.tensor([shift], dtype=torch.int32, device=vqkv.device)
+        sh = shift if torch.is_tensor(shift) else torch.full((1,), int(shift), dtype=torch.int32, device=vqkv.device)   # fill kernel: capturable
         vatt = torch.empty(N * F * HW, C, dtype=vqkv.dtype, device=vqkv.device)
         aatt = torch.empty(N * L, C, dtype=vqkv.dtype, device=vqkv.device)
         ctx.cfg = (heads, N, F, HW, L, apf, win)
@@ -223,16 +253,22 @@ class LinearFn(Function):
         x = x.float().contiguous()
         y = torch.empty(x.shape[0], weight.shape[0], dtype=torch.float32, device=x.device)
         ops.linear(x, weight.detach().float().contiguous(), bias.detach().float().contiguous(), y)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         dy = dy.float().contiguous()
         J, K = weight.shape
         dx = torch.empty_like(x)
         ops.linear(dy, weight.detach().float().t().contiguous(), None, dx)
+        slot = _grad_slot(weight, bias)
+        if slot is not None:
+            for j0 in range(0, J, 1024):
+                j1 = min(j0 + 1024, J)
+                ops.conv_wgrad(dy[:, j0:j1].contiguous(), x, slot[0][j0:j1], slot[1][j0:j1], ops.TAPS_1, (1, 1, 1))
+            return dx, None, None
         dW = torch.zeros(J, K, dtype=torch.float32, device=x.device)
         db = torch.zeros(J, dtype=torch.float32, device=x.device)
         Jp = (J + 3) // 4 * 4

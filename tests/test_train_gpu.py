@@ -73,3 +73,78 @@ def test_flat_adamw_step_updates_every_parameter():
     d = (p.detach() - before["middle_blocks.1.v_qkv.weight"]).abs()
     assert float(d.max()) <= 1.01e-4 and float(d.median()) > 0.5e-4
     assert len(opt.ema_params) == 1 and opt.ema_params[0].numel() == sum(v.numel() for v in before.values())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_direct_grad_accumulation_and_packed_weights_match_autograd_path(dt):
+    """With FlatAdamW the backward kernels accumulate straight into the flat .grad buffer (wgrad in the parameter's own layout)
+    and the convs read the one-launch packed weights; the result must equal the plain autograd path (fresh .grad tensors,
+    per-call packing) up to the fp32 atomic-add order."""
+    import random
+    from mm_diffusion.optim import FlatAdamW
+    g, fl, model, diff, x0, noise = _setup(dt)
+    t = torch.from_numpy(g["t"]).cuda()
+
+    def run():
+        random.seed(5)
+        model.shift_source = None
+        return diff.multimodal_training_losses(model, x0, t, noise=noise)["loss"].mean()
+    run().backward()                                   # plain path: autograd allocates the .grad tensors
+    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    opt = FlatAdamW(model.parameters(), lr=1e-4, pack_dtype=model.dtype)
+    assert all(hasattr(p, "_mmd_packed") for p in model.parameters() if p.dim() >= 3)
+    opt.zero_grad()
+    run().backward()
+    opt.fold_grads()                                   # conv-weight gradients accumulate in the packed layout until folded
+    worst = 0.0
+    for k, p in model.named_parameters():
+        assert p.grad.data_ptr() >= opt.grad.data_ptr() and p.grad.data_ptr() < opt.grad.data_ptr() + opt.grad.numel() * 4
+        worst = max(worst, rel_l2(p.grad.cpu(), ref[k].cpu().numpy()))
+    print(f"direct accumulation vs autograd path ({dt}): worst rel-L2 {worst:.2e}")
+    assert worst < (1e-5 if dt == torch.float32 else 2e-2)
+    # packed copies follow the parameters after a step
+    w = dict(model.named_parameters())["middle_blocks.1.v_qkv.weight"]
+    opt.step()
+    torch.cuda.synchronize()
+    Cout, Cin = w.shape[0], w.shape[1]
+    assert torch.equal(w._mmd_packed[0], w.detach().reshape(Cout, Cin, -1).permute(0, 2, 1).reshape(Cout, -1).to(dt))
+    assert torch.equal(w._mmd_packed[1], w.detach().reshape(Cout, Cin, -1).permute(1, 2, 0).reshape(Cin, -1).to(dt))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_graph_captured_step_matches_eager_step(dt):
+    """train_graph.GraphedTrainStep (forward + backward replayed from one captured graph, shifts in device slots) produces the
+    same losses and gradients as the eager step given the same batch, timesteps, noise and shift draws."""
+    import random
+    from mm_diffusion.optim import FlatAdamW
+    from mm_diffusion.train_graph import GraphedTrainStep
+    g, fl, model, diff, x0, noise = _setup(dt)
+    t = torch.from_numpy(g["t"]).cuda()
+    opt = FlatAdamW(model.parameters(), lr=0.0, pack_dtype=model.dtype)          # lr 0: the parameters stay put between the runs
+    model.shift_source = None
+    random.seed(7)
+    opt.zero_grad()
+    ref_losses = diff.multimodal_training_losses(model, x0, t, noise=noise)
+    ref_losses["loss"].mean().backward()
+    opt.fold_grads()
+    opt._folded = False
+    ref_grad = opt.grad.clone()
+    ref_loss = ref_losses["loss"].detach().cpu().numpy()
+    del ref_losses           # drop the eager autograd graph: its AccumulateGrad nodes belong to the default stream and a capture on
+    #                          another stream while they are alive crashes hipStreamEndCapture (torch warns about exactly this)
+    gstep = GraphedTrainStep(model, diff, opt, x0)
+    gstep.step(x0, t, noise=noise)                                               # warm-up + capture + first replay
+    for rep in range(2):                                                         # replays with fresh draws reproduce the eager step
+        random.seed(7)
+        out = gstep.step(x0, t, noise=noise)
+        torch.cuda.synchronize()
+        e = rel_l2(opt.grad.cpu(), ref_grad.cpu().numpy())
+        print(f"graph replay {rep} vs eager ({dt}): grad rel-L2 {e:.2e}")
+        assert e < (1e-5 if dt == torch.float32 else 2e-2)
+        np.testing.assert_allclose(out["loss"].cpu().numpy(), ref_loss, rtol=1e-5 if dt == torch.float32 else 2e-2)
+    random.seed(8)                                                               # different shifts -> different gradient
+    gstep.step(x0, t, noise=noise)
+    assert rel_l2(opt.grad.cpu(), ref_grad.cpu().numpy()) > 1e-4
+    gstep.close()
