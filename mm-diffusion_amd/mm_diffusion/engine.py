@@ -481,7 +481,42 @@ class UNetEngine:
         self.aux.wait_stream(torch.cuda.current_stream(self.device))   # aux starts clean behind the inputs
         ops.run_plan((self.plan_f32 if use_f32 else self.plan) + self._join, st, self.aux.cuda_stream)
 
-    def forward(self, video, audio, timesteps, shifts):
+    def _graph(self, use_f32):
+        """hipGraph of the whole forward plan (captured on first use, one per timestep dtype): every no-grad `model(x, t)` call -
+        DPM-Solver, eager DDIM / conditional loops - is then ONE launch instead of ~1100 ctypes launches from Python."""
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        if use_f32 not in self._graphs:
+            import ctypes
+            if not hasattr(self, "_join"):
+                self._join = self.join_plan()
+            plan = (self.plan_f32 if use_f32 else self.plan) + self._join
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                ops.run_plan(plan, side.cuda_stream, self.aux.cuda_stream)      # warm-up: one-time function attributes
+                side.synchronize()
+                H.call("mmd_graph_begin", side.cuda_stream)
+                try:
+                    ops.run_plan(plan, side.cuda_stream, self.aux.cuda_stream)
+                finally:
+                    ex = ctypes.c_void_p()
+                    H.call("mmd_graph_end", side.cuda_stream, ctypes.byref(ex))
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._graphs[use_f32] = ex
+        return self._graphs[use_f32]
+
+    def forward(self, video, audio, timesteps, shifts, use_graph=True):
         use_f32 = self.set_inputs(video, audio, timesteps, shifts)
-        self.run(use_f32)
+        if use_graph:
+            H.call("mmd_graph_launch", self._graph(use_f32), H.stream_handle())
+        else:
+            self.run(use_f32)
         return self.out_video.clone(), self.out_audio.clone()
+
+    def __del__(self):
+        try:
+            for g in getattr(self, "_graphs", {}).values():
+                H.lib().mmd_graph_destroy(g)
+        except Exception:
+            pass

@@ -168,7 +168,7 @@ class DPM_Solver:
 
     def noise_prediction_fn(self, x, t):
         self.nfe += 1
-        t_dev = t.to(x["video"].device) if torch.is_tensor(t) else t
+        t_dev = t.contiguous().to(x["video"].device) if torch.is_tensor(t) else t
         out = self.model(x, t_dev)
         return {k: out[k].float().contiguous() for k in ("video", "audio")}
 
@@ -272,7 +272,7 @@ class DPM_Solver:
             phi_11, phi_1 = torch.expm1(-r1t * h), torch.expm1(-h)
             a1, b1 = _f(sig_s1 / sig_s), -_f(alpha_s1 * phi_11)
             x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
-            model_s1 = self.model_fn(x_s1, s1.to(dev).expand(B))
+            model_s1 = self.model_fn(x_s1, s1.expand(B))
             c0, c1 = _f(sig_t / sig_s), -_f(alpha_t * phi_1)
             c2 = (-(0.5 / r1f) * _f(alpha_t * phi_1)) if solver_type == "dpm_solver" else \
                 ((1. / r1f) * _f(alpha_t * ((torch.exp(-h) - 1.) / h + 1.)))
@@ -280,7 +280,7 @@ class DPM_Solver:
             phi_11, phi_1 = torch.expm1(r1t * h), torch.expm1(h)
             a1, b1 = _f(torch.exp(la_s1 - la_s)), -_f(sig_s1 * phi_11)
             x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
-            model_s1 = self.model_fn(x_s1, s1.to(dev).expand(B))
+            model_s1 = self.model_fn(x_s1, s1.expand(B))
             c0, c1 = _f(torch.exp(la_t - la_s)), -_f(sig_t * phi_1)
             c2 = (-(0.5 / r1f) * _f(sig_t * phi_1)) if solver_type == "dpm_solver" else \
                 (-(1. / r1f) * _f(sig_t * ((torch.exp(h) - 1.) / h - 1.)))
@@ -318,7 +318,7 @@ class DPM_Solver:
             if model_s1 is None:
                 a1, b1 = _f(sig_s1 / sig_s), -_f(alpha_s1 * phi_11)
                 x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
-                model_s1 = self.model_fn(x_s1, s1.to(dev).expand(B))
+                model_s1 = self.model_fn(x_s1, s1.expand(B))
             a2, b2, d2 = _f(sig_s2 / sig_s), -_f(alpha_s2 * phi_12), (r2f / r1f) * _f(alpha_s2 * phi_22)
             c0, c1, c2 = _f(sig_t / sig_s), -_f(alpha_t * phi_1), (1. / r2f) * _f(alpha_t * phi_2)
         else:
@@ -328,11 +328,11 @@ class DPM_Solver:
             if model_s1 is None:
                 a1, b1 = _f(torch.exp(la_s1 - la_s)), -_f(sig_s1 * phi_11)
                 x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
-                model_s1 = self.model_fn(x_s1, s1.to(dev).expand(B))
+                model_s1 = self.model_fn(x_s1, s1.expand(B))
             a2, b2, d2 = _f(torch.exp(la_s2 - la_s)), -_f(sig_s2 * phi_12), -(r2f / r1f) * _f(sig_s2 * phi_22)
             c0, c1, c2 = _f(torch.exp(la_t - la_s)), -_f(sig_t * phi_1), -(1. / r2f) * _f(sig_t * phi_2)
         x_s2 = _streams(lambda k: _comb([(a2, x[k]), (b2 - d2, model_s[k]), (d2, model_s1[k])]))
-        model_s2 = self.model_fn(x_s2, s2.to(dev).expand(B))
+        model_s2 = self.model_fn(x_s2, s2.expand(B))
         x_t = _streams(lambda k: _comb([(c0, x[k]), (c1 - c2, model_s[k]), (c2, model_s2[k])]))
         if return_intermediate:
             return x_t, {"model_s": model_s, "model_s1": model_s1, "model_s2": model_s2}
@@ -413,7 +413,7 @@ class DPM_Solver:
             if verbose:
                 print(f"{torch.abs((s - t_0)).mean()} > {t_err}")
             t = ns.inverse_lambda(lambda_s + h)
-            vs, vt = s.to(dev).expand(B), t.to(dev).expand(B)
+            vs, vt = s.expand(B), t.expand(B)
             x_lower, lower_noise_kwargs = lower_update(x, vs, vt)
             x_higher = higher_update(x, vs, vt, **lower_noise_kwargs)
             acc.zero_()
@@ -444,7 +444,9 @@ class DPM_Solver:
                 x = self.dpm_solver_adaptive(x, order=order, t_T=t_T, t_0=t_0, atol=atol, rtol=rtol, solver_type=solver_type)
             elif method == "multistep":
                 assert steps >= order
-                timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps, device=device)
+                # the time grid stays on the HOST: every coefficient is a host scalar, so no step waits on the device; the model's
+                # integer timestep is uploaded asynchronously inside noise_prediction_fn
+                timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps, device="cpu")
                 assert timesteps.shape[0] - 1 == steps
                 vec_t = timesteps[0].expand(B)
                 model_prev_list = [self.model_fn(x, vec_t)]
@@ -466,11 +468,11 @@ class DPM_Solver:
             elif method in ["singlestep", "singlestep_fixed"]:
                 if method == "singlestep":
                     orders = self.get_orders_for_singlestep_solver(steps=steps, order=order)
-                    timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps, device=device)
+                    timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps, device="cpu")
                 else:
                     K = steps // order
                     orders = [order, ] * K
-                    timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=(K * order), device=device)
+                    timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=(K * order), device="cpu")
                 ns = self.noise_schedule
                 tc = timesteps.detach().float().cpu()
                 i = 0
@@ -482,7 +484,7 @@ class DPM_Solver:
                     x = self.singlestep_dpm_solver_update(x, vec_s, vec_t, order, solver_type=solver_type, r1=r1, r2=r2)
                     i += order
         if denoise:
-            x = self.denoise_fn(x, torch.ones((B,)).to(device) * t_0)
+            x = self.denoise_fn(x, torch.ones((B,)) * t_0)
         return x
 
 
