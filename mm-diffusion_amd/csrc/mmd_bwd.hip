@@ -16,6 +16,7 @@ struct WgradParams {
   const char* dY; int64_t lddy;      // [M, Cout]
   const char* X; int64_t ldx;        // [rows, Cin]
   float* dW;                         // fp32, accumulated with atomics: [Cout][ntaps*Cin] (packed) or [Cout][Cin][ntaps] (torch conv layout)
+  float* db;                         // wgrad128 only: bias gradient (column sums of dY) accumulated by the (tap 0, ci tile 0) blocks
   int torch_layout;
   int M, Cout, Cin, ntaps;
   int D0, D1, D2;
@@ -172,12 +173,22 @@ __global__ __launch_bounds__(256, 2) void wgrad128_bf16_kernel(const WgradParams
     }
   };
 
+  const bool do_db = p.db != nullptr && kt == 0;
+  float dbacc = 0.f;
   load_chunk(m_begin);
   for (int mc = m_begin; mc < m_end; mc += 64) {
     __syncthreads();                 // previous chunk fully consumed
     store_chunk();
     __syncthreads();
     if (mc + 64 < m_end) load_chunk(mc + 64);
+    if (do_db) {                     // bias gradient from the staged dY^T tile: thread = (channel, 32-row half); rows past m_end are zero
+      const char* q = sA + (tid >> 1) * WG_PITCH + (tid & 1) * 64;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const u32x2 v = *(const u32x2*)(q + 8 * u);
+        dbacc += __uint_as_float(v[0] << 16) + __uint_as_float(v[0] & 0xffff0000u) + __uint_as_float(v[1] << 16) + __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       u32x4 fa[2], fb[2];
@@ -199,6 +210,11 @@ __global__ __launch_bounds__(256, 2) void wgrad128_bf16_kernel(const WgradParams
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
     }
+  }
+  if (do_db) {
+    dbacc += __shfl_xor(dbacc, 1, 64);
+    const int co = co0 + (tid >> 1);
+    if ((tid & 1) == 0 && co < p.Cout) atomicAdd(p.db + co, dbacc);
   }
   // D[row = co][col = ci]: lane holds ci = l31, co = (r&3) + 8*(r>>2) + 4*half of its 32x32 tile
   const int64_t K = (int64_t)p.Cin * p.ntaps;
@@ -501,7 +517,7 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
   MMD_REQUIRE(Cin % epv == 0 && Cout % epv == 0 && lddy % epv == 0 && ldx % epv == 0, "conv_wgrad: channel counts / strides must be 16-byte multiples");
   MMD_REQUIRE(((uintptr_t)dY | (uintptr_t)X) % 16 == 0, "conv_wgrad: unaligned pointer");
   WgradParams p;
-  p.dY = (const char*)dY; p.lddy = lddy; p.X = (const char*)X; p.ldx = ldx; p.dW = dW; p.torch_layout = torch_layout;
+  p.dY = (const char*)dY; p.lddy = lddy; p.X = (const char*)X; p.ldx = ldx; p.dW = dW; p.db = nullptr; p.torch_layout = torch_layout;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
@@ -514,7 +530,9 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
     int splits = max(1, min(cdiv(M, 256), target / max(tiles, 1)));
     p.rows_per_split = cdiv(cdiv(M, splits), 64) * 64;
     splits = cdiv(M, p.rows_per_split);
+    p.db = db;                                                   // column sums ride in the (tap 0, ci tile 0) blocks: no colsum launch
     hipLaunchKernelGGL(wgrad128_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), 0, st, p);
+    return mmd_check_launch("conv_wgrad");
   } else {
     const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64) * ntaps;
     int splits = max(1, min(cdiv(M, 256), 2048 / max(tiles, 1)));
