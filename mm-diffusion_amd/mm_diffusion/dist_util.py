@@ -19,7 +19,9 @@ def setup_dist(devices=None, backend=None):
         th.cuda.set_device(local % th.cuda.device_count())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29512")
-    backend = backend or ("nccl" if th.cuda.is_available() else "gloo")
+    # MMD_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices): used to smoke-test the multi-rank
+    # code path of bench.py on a single-GPU box
+    backend = backend or os.environ.get("MMD_DIST_BACKEND") or ("nccl" if th.cuda.is_available() else "gloo")
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
 
