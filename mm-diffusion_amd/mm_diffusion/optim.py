@@ -124,3 +124,9 @@ class FlatAdamW:
         if self.packer is not None:
             self.packer.refresh()
         self._folded = False
+        # the kernel wrote the parameters through the flat buffer: tell autograd / the inference engine (which keys its packed
+        # weights on the parameters' version counters, engine.UNetEngine.stale) that every parameter changed
+        bump = getattr(torch._C, "_increment_version", None)
+        if bump is not None:
+            for p in self.params:
+                bump(p)

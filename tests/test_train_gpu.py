@@ -73,6 +73,17 @@ def test_flat_adamw_step_updates_every_parameter():
     d = (p.detach() - before["middle_blocks.1.v_qkv.weight"]).abs()
     assert float(d.max()) <= 1.01e-4 and float(d.median()) > 0.5e-4
     assert len(opt.ema_params) == 1 and opt.ema_params[0].numel() == sum(v.numel() for v in before.values())
+    # the no-grad engine must notice the update (its packed weights are keyed on the parameters' version counters)
+    model.eval()
+    eng_before = model._engines.copy()
+    with torch.no_grad():
+        model(x0["video"], x0["audio"], torch.from_numpy(g["t"]).cuda())
+    eng = next(iter(model._engines.values()))
+    opt.zero_grad()
+    model.train()
+    diff.multimodal_training_losses(model, x0, torch.from_numpy(g["t"]).cuda(), noise=noise)["loss"].mean().backward()
+    opt.step()
+    assert eng.stale(), "optimizer step must invalidate the inference engine's packed weights"
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
