@@ -75,7 +75,7 @@ def test_flat_adamw_step_updates_every_parameter():
     assert len(opt.ema_params) == 1 and opt.ema_params[0].numel() == sum(v.numel() for v in before.values())
     # the no-grad engine must notice the update (its packed weights are keyed on the parameters' version counters)
     model.eval()
-    eng_before = model._engines.copy()
+    model.shift_source = None                 # the recorded draws are used up: fall back to random.randint
     with torch.no_grad():
         model(x0["video"], x0["audio"], torch.from_numpy(g["t"]).cuda())
     eng = next(iter(model._engines.values()))
