@@ -196,6 +196,11 @@ int mmd_dpm_err(const float* hi, const float* lo, const float* prev, float atol,
                 void* stream);
 /* SR model input (image_unet.py:704-715): out [N,2C,H,W] = concat(x [N,C,H,W], bilinear(low [N,C,h,w] -> H x W)), fp32. */
 int mmd_bilinear_concat(const float* x, const float* low, float* out, int N, int C, int H, int W, int h, int w, void* stream);
+/* Gradient of sum_n(dmse[n] mse[n] + dvb[n] vb[n]) of mmd_loss_terms w.r.t. the model output (same layout, fp32): the mean channels
+ * get the mse gradient only (the vb term detaches the mean, gd:1147-1151), the variance channels the KL / decoder-NLL gradient. */
+int mmd_loss_terms_bwd(const float* x0, const float* xt, const float* model_out, const float* target, const float* tables,
+                       const int64_t* t, int T, int N, int F, int C, int HW, int flags, float vb_scale, const float* dmse,
+                       const float* dvb, float* g_model_out, void* stream);
 /* backward of mmd_attn_small_fwd (temporal attention): dQKV rows [dq | dk | dv], same slice geometry. */
 int mmd_attn_small_bwd(int dtype, const void* QKV, int64_t ld, const void* dO, int64_t lddo, void* dQKV, int64_t ldd, int C, int heads,
                        int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, void* stream);

@@ -865,3 +865,69 @@ extern "C" int mmd_bilinear_concat(const float* x, const float* low, float* out,
                      W, h, w);
   return mmd_check_launch("bilinear_concat");
 }
+
+// ----------------------------------------------------------------------------- training-loss gradient (learned-range variance)
+// Gradient of  sum_n ( dmse[n] * mse[n] + dvb[n] * vb[n] )  w.r.t. the model output [N, F, Cm, HW] (Cm = 2C with flag 4):
+//   mean channels c < C     : dmse[n] * 2 (o - target) / per                      (the vb term sees the mean DETACHED, gd:1147-1151)
+//   variance channels c >= C: dvb[n] * vb_scale / (per ln 2) * d term / d logvar * (max_log - min_log) / 2
+// with term = KL(q || p) for t > 0 and the discretized-Gaussian decoder NLL at t == 0 (losses.py:12-77), exactly the forward
+// arithmetic of loss_terms_kernel.
+__global__ __launch_bounds__(256) void loss_terms_bwd_kernel(const LossParams p, const float* __restrict__ dmse, const float* __restrict__ dvb,
+                                                             float vb_scale, float* __restrict__ g) {
+  const int64_t per = (int64_t)p.F * p.C * p.HW;
+  const int64_t total = per * p.N;
+  const int Cm = (p.flags & 4) ? 2 * p.C : p.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / per, r = i % per;
+    const int hw = (int)(r % p.HW), c = (int)((r / p.HW) % p.C);
+    const int64_t f = r / ((int64_t)p.HW * p.C);
+    const int ti = (int)p.t[n];
+    const int64_t mbase = ((n * (int64_t)p.F + f) * Cm) * (int64_t)p.HW + hw;
+    const float o = p.mo[mbase + (int64_t)c * p.HW];
+    g[mbase + (int64_t)c * p.HW] = dmse[n] * 2.f * (o - p.target[i]) / (float)per;
+    if (p.flags & 4) {
+      const float cr = p.tables[ti], crm1 = p.tables[p.T + ti], c1 = p.tables[2 * p.T + ti], c2 = p.tables[3 * p.T + ti];
+      const float min_log = p.tables[5 * p.T + ti], max_log = p.tables[6 * p.T + ti];
+      const float vv = p.mo[mbase + (int64_t)(c + p.C) * p.HW];
+      const float frac = (vv + 1.f) / 2.f;
+      const float logvar = frac * max_log + (1.f - frac) * min_log;
+      const float xv = p.xt[i], x0 = p.x0[i];
+      const float px0 = (p.flags & 2) ? o : cr * xv - crm1 * o;
+      const float mean = c1 * px0 + c2 * xv;
+      float dterm;                                   // d term / d logvar
+      if (ti == 0) {
+        const float cx = x0 - mean, inv = expf(-0.5f * logvar);
+        const float up = inv * (cx + 1.f / 255.f), um = inv * (cx - 1.f / 255.f);
+        const float cdf_p = approx_std_normal_cdf(up), cdf_m = approx_std_normal_cdf(um);
+        // d cdf(u) / d logvar = pdf~(u) * (-u / 2),  pdf~ = derivative of the tanh approximation
+        auto dcdf = [](float u) {
+          const float k = 0.7978845608028654f, a = 0.044715f;
+          const float th_ = tanhf(k * (u + a * u * u * u));
+          return 0.5f * (1.f - th_ * th_) * k * (1.f + 3.f * a * u * u) * (-0.5f * u);
+        };
+        const float dp = dcdf(up), dm_ = dcdf(um);
+        float dlog;
+        if (x0 < -0.999f) dlog = cdf_p > 1e-12f ? dp / cdf_p : 0.f;
+        else if (x0 > 0.999f) dlog = (1.f - cdf_m) > 1e-12f ? -dm_ / (1.f - cdf_m) : 0.f;
+        else dlog = (cdf_p - cdf_m) > 1e-12f ? (dp - dm_) / (cdf_p - cdf_m) : 0.f;
+        dterm = -dlog;
+      } else {
+        const float dm = (c1 * x0 + c2 * xv) - mean;
+        dterm = 0.5f * (1.f - expf(min_log - logvar) - dm * dm * expf(-logvar));
+      }
+      g[mbase + (int64_t)(c + p.C) * p.HW] = dvb[n] * vb_scale / ((float)per * 0.6931471805599453f) * dterm * 0.5f * (max_log - min_log);
+    }
+  }
+}
+extern "C" int mmd_loss_terms_bwd(const float* x0, const float* xt, const float* model_out, const float* target, const float* tables,
+                                  const int64_t* t, int T, int N, int F, int C, int HW, int flags, float vb_scale, const float* dmse,
+                                  const float* dvb, float* g_model_out, void* stream) {
+  MMD_REQUIRE(model_out && target && tables && t && dmse && g_model_out && T > 0 && N > 0 && F > 0 && C > 0 && HW > 0, "loss_terms_bwd: bad argument");
+  MMD_REQUIRE(!(flags & 4) || (x0 && xt && dvb), "loss_terms_bwd: the vb term needs x0, x_t and dvb");
+  LossParams p;
+  p.x0 = x0; p.xt = xt; p.mo = model_out; p.target = target; p.tables = tables; p.t = t; p.partial = nullptr;
+  p.T = T; p.N = N; p.F = F; p.C = C; p.HW = HW; p.flags = flags; p.nchunk = 0;
+  hipLaunchKernelGGL(loss_terms_bwd_kernel, dim3(ew_grid((int64_t)N * F * C * HW)), dim3(256), 0, (hipStream_t)stream, p, dmse, dvb, vb_scale,
+                     g_model_out);
+  return mmd_check_launch("loss_terms_bwd");
+}

@@ -487,9 +487,9 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ training loss (forward value only for now)
     def multimodal_training_losses(self, model, x_start, t, model_kwargs=None, noise=None):
-        """gd:1114-1203: per-sample loss = mse_video + mse_audio (+ vb_video + vb_audio with learned-range variance; the
-        vb term uses the frozen mean and clip_denoised=False, gd:1147-1174).  Forward VALUES only: q_sample, the U-Net
-        forward and the loss reductions all run in libmmd; the backward pass is not built yet (cfg4, next)."""
+        """gd:1114-1203: per-sample loss = mse_video + mse_audio (+ vb_video + vb_audio with learned-range variance; the vb term
+        uses the frozen mean and clip_denoised=False, gd:1147-1174).  q_sample, the U-Net forward and the loss reductions run in
+        libmmd; with autograd enabled the terms are differentiable (mmd_mse_grad / mmd_loss_terms_bwd feed the U-Net backward)."""
         model_kwargs = model_kwargs or {}
         if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
             raise NotImplementedError("KL / RESCALED_KL losses produce no terms in the reference either (gd:1143)")
@@ -505,9 +505,14 @@ class GaussianDiffusion:
         t64 = t.to(th.int64).contiguous()
         term = {}
         if th.is_grad_enabled() and (video_output.requires_grad or audio_output.requires_grad):
-            # differentiable loss: per-sample mse with its gradient kernel (the vb term's backward is not built yet)
+            # differentiable loss: per-sample terms with their gradient kernels
             if learned:
-                raise NotImplementedError("gradients of the learned-sigma vb term are not built yet; train with learn_sigma=False")
+                from .train_ops import LossTermsFn
+                for key, mo in (("video", video_output), ("audio", audio_output)):
+                    term[f"mse_{key}"], term[f"vb_{key}"] = LossTermsFn.apply(
+                        mo, tgt[key].float().contiguous(), x_start[key].float().contiguous(), xt[key], tab, t64, _geom(xt[key]), flags, vb_scale)
+                term["loss"] = (term["vb_video"] + term["vb_audio"]) + (term["mse_video"] + term["mse_audio"])
+                return term
             from .train_ops import MseLossFn
             term["mse_video"] = MseLossFn.apply(video_output, tgt["video"])
             term["mse_audio"] = MseLossFn.apply(audio_output, tgt["audio"])

@@ -406,6 +406,15 @@ def loss_terms(model_out, target, tables, t, F, C, HW, flags, x0=None, xt=None, 
 
 
 # ------------------------------------------------------------------ training step (backward) wrappers
+def loss_terms_bwd(model_out, target, tables, t, F, C, HW, flags, dmse, dvb, g, x0=None, xt=None, vb_scale=1.0):
+    """g (like model_out) = d(sum dmse*mse + dvb*vb)/d model_out of loss_terms; see include/mmd.h."""
+    H.require_cuda(model_out, target, tables, t, dmse, g)
+    _dispatch("mmd_loss_terms_bwd", H.ptr(x0), H.ptr(xt), model_out.data_ptr(), target.data_ptr(), tables.data_ptr(), t.data_ptr(),
+              tables.shape[1], model_out.shape[0], F, C, HW, flags, float(vb_scale), dmse.data_ptr(), H.ptr(dvb), g.data_ptr(),
+              meta=("loss_terms_bwd", 0, 20 * target.numel()))
+    return g
+
+
 def conv_wgrad(dy, x, dW, db, taps, dims, torch_layout=False):
     """dW fp32 += dy^T gather(x) in [Cout, ntaps*Cin] (packed) or, with torch_layout, in the parameter's own [Cout, Cin, *k]
     layout (so dW may be the parameter's .grad); db fp32 [Cout] += colsum(dy).  Accumulating: the caller owns the zeroing."""

@@ -317,6 +317,29 @@ class MseLossFn(Function):
         return g, None
 
 
+class LossTermsFn(Function):
+    """(mse [N], vb [N]) of one stream with the learned-range variance (gd:1143-1203): model_out [N,F,2C,HW] API layout fp32.
+    The vb term sees the mean prediction detached (gd:1147-1151), so its gradient reaches the variance channels only."""
+
+    @staticmethod
+    def forward(ctx, model_out, target, x0, xt, tables, t, geom, flags, vb_scale):
+        mo = model_out.float().contiguous()
+        F, C, HW = geom
+        mse, vb = ops.loss_terms(mo, target, tables, t, F, C, HW, flags, x0=x0, xt=xt, vb_scale=vb_scale)
+        ctx.save_for_backward(mo, target, x0, xt, tables, t)
+        ctx.cfg = (geom, flags, vb_scale)
+        return mse, vb
+
+    @staticmethod
+    def backward(ctx, dmse, dvb):
+        mo, target, x0, xt, tables, t = ctx.saved_tensors
+        (F, C, HW), flags, vb_scale = ctx.cfg
+        g = torch.empty_like(mo)
+        ops.loss_terms_bwd(mo, target, tables, t, F, C, HW, flags, dmse.float().contiguous(), dvb.float().contiguous(), g, x0=x0, xt=xt,
+                           vb_scale=vb_scale)
+        return g, None, None, None, None, None, None, None, None
+
+
 class DdpmUpdateFn(Function):
     """Differentiable p_sample update of one stream (gd:231-343,415-474; fixed variance): returns (sample, pred_xstart);
     gradients flow through the posterior mean to x_t and to the model output (mmd_ddpm_update_bwd)."""

@@ -16,13 +16,13 @@ GRAD_KEYS = ("time_embed.0.weight", "input_blocks.0.0.video_conv.video_conv_spat
              "video_out.2.video_conv.bias", "audio_out.2.audio_conv.weight")
 
 
-def _setup(dt=torch.float32):
+def _setup(dt=torch.float32, learn_sigma=False):
     from mm_diffusion import logger, multimodal_script_util as msu
     logger.set_quiet(True)
-    g = gold("tiny_train_loss")
-    fl = flags("tiny", use_fp16=(dt == torch.bfloat16))
+    g = gold("tiny_ls_train_loss" if learn_sigma else "tiny_train_loss")
+    fl = flags("tiny", use_fp16=(dt == torch.bfloat16), learn_sigma=learn_sigma)
     model, diff = msu.create_model_and_diffusion(**fl)
-    model.load_state_dict(synth_sd("tiny"))
+    model.load_state_dict(synth_sd("tiny_learn_sigma" if learn_sigma else "tiny"))
     model.cuda().train()
     B, seed = int(g["B"]), int(g["seed"])
     gen = torch.Generator().manual_seed(seed)
@@ -57,6 +57,64 @@ def test_bf16_training_step_runs_and_is_close():
         e = rel_l2(params[k].grad.cpu(), g["grad." + k])
         print(f"bf16 grad {k}: rel-L2 {e:.2e}")
         assert e < 0.15, k
+
+
+def test_learned_sigma_training_gradients_match_reference():
+    """learn_sigma=True: loss = mse + vb (KL / decoder NLL with the mean detached); loss terms and parameter gradients vs the
+    reference's .backward() (tests/golden/tiny_ls_train_loss.npz; t = [3, 977] exercises the KL branch, the decoder-NLL branch
+    is covered by the finite-difference test below)."""
+    g, fl, model, diff, x0, noise = _setup(learn_sigma=True)
+    terms = diff.multimodal_training_losses(model, x0, torch.from_numpy(g["t"]).cuda(), noise=noise)
+    for k in ("loss", "mse_video", "mse_audio", "vb_video", "vb_audio"):
+        np.testing.assert_allclose(terms[k].detach().cpu().numpy(), g[k], rtol=5e-4, atol=1e-6)
+    terms["loss"].mean().backward()
+    params = dict(model.named_parameters())
+    for k in GRAD_KEYS:
+        e = rel_l2(params[k].grad.cpu(), g["grad." + k])
+        print(f"learn_sigma grad {k}: rel-L2 {e:.2e}")
+        assert e < 2e-3, k
+
+
+def test_loss_terms_backward_matches_finite_differences():
+    """mmd_loss_terms_bwd vs central differences of mmd_loss_terms on a tiny tensor, for t == 0 (decoder NLL) and t > 0 (KL)."""
+    from mm_diffusion import multimodal_script_util as msu, ops
+    fl = flags("tiny", learn_sigma=True)
+    _, diff = msu.create_model_and_diffusion(**fl)
+    tab, _ = diff.device_tables(torch.device("cuda"))
+    N, F, C, HW = 2, 1, 2, 8
+    g = torch.Generator().manual_seed(3)
+    mo = (torch.randn(N, F, 2 * C, HW, generator=g) * 0.5).cuda()
+    x0 = (torch.rand(N, F, C, HW, generator=g) * 2 - 1).cuda()
+    x0[0, 0, 0, 0], x0[0, 0, 0, 1] = -1.0, 1.0                       # the two open-ended bins of the discretized likelihood
+    eps = torch.randn(N, F, C, HW, generator=g).cuda()
+    t = torch.tensor([0, 500], device="cuda")
+    _, qtab = diff.device_tables(torch.device("cuda"))
+    xt = torch.empty_like(x0)
+    ops.q_sample(x0.contiguous(), eps.contiguous(), xt, qtab, t)
+    flags_ = 4
+    dmse, dvb = torch.tensor([0.7, -0.3], device="cuda"), torch.tensor([1.3, 0.4], device="cuda")
+
+    def total(m):
+        mse, vb = ops.loss_terms(m.contiguous(), eps, tab, t, F, C, HW, flags_, x0=x0, xt=xt)
+        return float((dmse.double() * mse.double() + dvb.double() * vb.double()).sum())
+    gk = torch.empty_like(mo)
+    ops.loss_terms_bwd(mo, eps, tab, t, F, C, HW, flags_, dmse, dvb, gk, x0=x0, xt=xt)
+    num = torch.zeros_like(mo)
+    h = 1e-2
+    flat = mo.reshape(-1)
+    for i in range(flat.numel()):
+        old = float(flat[i])
+        flat[i] = old + h
+        up = total(mo)
+        flat[i] = old - h
+        dn = total(mo)
+        flat[i] = old
+        num.reshape(-1)[i] = (up - dn) / (2 * h)
+    # the vb term treats the mean as a constant: compare its gradient on the variance channels, the mse gradient on the mean channels
+    np.testing.assert_allclose(gk[:, :, C:].cpu().numpy(), num[:, :, C:].cpu().numpy(), rtol=3e-2, atol=2e-3)
+    mse_only = torch.empty_like(mo)
+    ops.loss_terms_bwd(mo, eps, tab, t, F, C, HW, flags_, dmse, torch.zeros_like(dvb), mse_only, x0=x0, xt=xt)
+    np.testing.assert_allclose(gk[:, :, :C].cpu().numpy(), mse_only[:, :, :C].cpu().numpy(), rtol=1e-6)
 
 
 def test_flat_adamw_step_updates_every_parameter():
