@@ -144,11 +144,15 @@ def _comb(terms):
     return ops.lincomb(a, ca, b, cb, c, cc)
 
 
-def _streams(fn):
-    return {"video": fn("video"), "audio": fn("audio")}
-
-
 class DPM_Solver:
+    KEYS = ("video", "audio")        # state streams; the tensor-valued solver of the SR stage (dpm_solver_plus.py) uses ("x",)
+
+    def _streams(self, fn):
+        return {k: fn(k) for k in self.KEYS}
+
+    def _batch(self, x):
+        return x[self.KEYS[0]].shape[0]
+
     def __init__(self, model, betas=None, alphas_cumprod=None, predict_x0=False, thresholding=False, guidance_type="uncond",
                  max_val=1., model_kwargs={}, rescale=False):
         noise_schedule = NoiseScheduleVP(schedule="discrete", betas=betas, alphas_cumprod=alphas_cumprod)
@@ -162,15 +166,15 @@ class DPM_Solver:
 
     # ------------------------------------------------------------------ model evaluations
     def _prep(self, x):
-        for k in ("video", "audio"):
+        for k in self.KEYS:
             H.require_cuda(x[k])
-        return {k: x[k].float().contiguous() for k in ("video", "audio")}
+        return {k: x[k].float().contiguous() for k in self.KEYS}
 
     def noise_prediction_fn(self, x, t):
         self.nfe += 1
-        t_dev = t.contiguous().to(x["video"].device) if torch.is_tensor(t) else t
+        t_dev = t.contiguous().to(x[self.KEYS[0]].device) if torch.is_tensor(t) else t
         out = self.model(x, t_dev)
-        return {k: out[k].float().contiguous() for k in ("video", "audio")}
+        return {k: out[k].float().contiguous() for k in self.KEYS}
 
     def data_prediction_fn(self, x, t):
         """x0 = (x - sigma_t eps) / alpha_t, optionally with Imagen-style dynamic thresholding (dpm:419-440)."""
@@ -178,7 +182,7 @@ class DPM_Solver:
         tc = t.detach().float().cpu().reshape(-1)[:1]
         alpha_t, sigma_t = _f(self.noise_schedule.marginal_alpha(tc)), _f(self.noise_schedule.marginal_std(tc))
         x0 = {}
-        for k in ("video", "audio"):
+        for k in self.KEYS:
             v = ops.lincomb(x[k].float().contiguous(), 1.0 / alpha_t, noise[k], -sigma_t / alpha_t)
             if self.thresholding:
                 s = ops.abs_quantile(v, 0.995)          # p of the Imagen paper
@@ -241,12 +245,14 @@ class DPM_Solver:
             model_s = self.model_fn(x, s)
         if self.predict_x0:
             phi_1 = torch.expm1(-h)
-            c = {k: (_f(sig_t / sig_s), -_f(alpha_t * phi_1)) for k in ("video", "audio")}
+            c = {k: (_f(sig_t / sig_s), -_f(alpha_t * phi_1)) for k in self.KEYS}
         else:
             phi_1 = torch.expm1(h)
             # the audio stream takes the x0-form coefficients here, exactly like dpm:576-584
-            c = {"video": (_f(torch.exp(la_t - la_s)), -_f(sig_t * phi_1)), "audio": (_f(sig_t / sig_s), -_f(alpha_t * phi_1))}
-        x_t = _streams(lambda k: _comb([(c[k][0], x[k]), (c[k][1], model_s[k])]))
+            c = {k: (_f(torch.exp(la_t - la_s)), -_f(sig_t * phi_1)) for k in self.KEYS}
+            if "audio" in c:
+                c["audio"] = (_f(sig_t / sig_s), -_f(alpha_t * phi_1))
+        x_t = self._streams(lambda k: _comb([(c[k][0], x[k]), (c[k][1], model_s[k])]))
         return (x_t, {"model_s": model_s}) if return_intermediate else x_t
 
     # ------------------------------------------------------------------ single-step second order
@@ -263,15 +269,14 @@ class DPM_Solver:
         (_, la_s1, sig_s1), = self._sc(s1)
         alpha_s1, alpha_t = torch.exp(la_s1), torch.exp(la_t)
         x = self._prep(x)
-        dev = x["video"].device
-        B = x["video"].shape[0]
+        B = self._batch(x)
         if model_s is None:
             model_s = self.model_fn(x, s)
         r1f = _f(r1t)
         if self.predict_x0:
             phi_11, phi_1 = torch.expm1(-r1t * h), torch.expm1(-h)
             a1, b1 = _f(sig_s1 / sig_s), -_f(alpha_s1 * phi_11)
-            x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
+            x_s1 = self._streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
             model_s1 = self.model_fn(x_s1, s1.expand(B))
             c0, c1 = _f(sig_t / sig_s), -_f(alpha_t * phi_1)
             c2 = (-(0.5 / r1f) * _f(alpha_t * phi_1)) if solver_type == "dpm_solver" else \
@@ -279,13 +284,13 @@ class DPM_Solver:
         else:
             phi_11, phi_1 = torch.expm1(r1t * h), torch.expm1(h)
             a1, b1 = _f(torch.exp(la_s1 - la_s)), -_f(sig_s1 * phi_11)
-            x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
+            x_s1 = self._streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
             model_s1 = self.model_fn(x_s1, s1.expand(B))
             c0, c1 = _f(torch.exp(la_t - la_s)), -_f(sig_t * phi_1)
             c2 = (-(0.5 / r1f) * _f(sig_t * phi_1)) if solver_type == "dpm_solver" else \
                 (-(1. / r1f) * _f(sig_t * ((torch.exp(h) - 1.) / h - 1.)))
         # c0 x + c1 m_s + c2 (m_s1 - m_s)
-        x_t = _streams(lambda k: _comb([(c0, x[k]), (c1 - c2, model_s[k]), (c2, model_s1[k])]))
+        x_t = self._streams(lambda k: _comb([(c0, x[k]), (c1 - c2, model_s[k]), (c2, model_s1[k])]))
         return (x_t, {"model_s": model_s, "model_s1": model_s1}) if return_intermediate else x_t
 
     # ------------------------------------------------------------------ single-step third order
@@ -307,7 +312,7 @@ class DPM_Solver:
         (_, la_s1, sig_s1), (_, la_s2, sig_s2) = self._sc(s1, s2)
         alpha_s1, alpha_s2, alpha_t = torch.exp(la_s1), torch.exp(la_s2), torch.exp(la_t)
         x = self._prep(x)
-        dev, B = x["video"].device, x["video"].shape[0]
+        B = self._batch(x)
         r1f, r2f = _f(r1t), _f(r2t)
         if model_s is None:
             model_s = self.model_fn(x, s)
@@ -317,7 +322,7 @@ class DPM_Solver:
             phi_2 = phi_1 / h + 1.
             if model_s1 is None:
                 a1, b1 = _f(sig_s1 / sig_s), -_f(alpha_s1 * phi_11)
-                x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
+                x_s1 = self._streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
                 model_s1 = self.model_fn(x_s1, s1.expand(B))
             a2, b2, d2 = _f(sig_s2 / sig_s), -_f(alpha_s2 * phi_12), (r2f / r1f) * _f(alpha_s2 * phi_22)
             c0, c1, c2 = _f(sig_t / sig_s), -_f(alpha_t * phi_1), (1. / r2f) * _f(alpha_t * phi_2)
@@ -327,13 +332,13 @@ class DPM_Solver:
             phi_2 = phi_1 / h - 1.
             if model_s1 is None:
                 a1, b1 = _f(torch.exp(la_s1 - la_s)), -_f(sig_s1 * phi_11)
-                x_s1 = _streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
+                x_s1 = self._streams(lambda k: _comb([(a1, x[k]), (b1, model_s[k])]))
                 model_s1 = self.model_fn(x_s1, s1.expand(B))
             a2, b2, d2 = _f(torch.exp(la_s2 - la_s)), -_f(sig_s2 * phi_12), -(r2f / r1f) * _f(sig_s2 * phi_22)
             c0, c1, c2 = _f(torch.exp(la_t - la_s)), -_f(sig_t * phi_1), -(1. / r2f) * _f(sig_t * phi_2)
-        x_s2 = _streams(lambda k: _comb([(a2, x[k]), (b2 - d2, model_s[k]), (d2, model_s1[k])]))
+        x_s2 = self._streams(lambda k: _comb([(a2, x[k]), (b2 - d2, model_s[k]), (d2, model_s1[k])]))
         model_s2 = self.model_fn(x_s2, s2.expand(B))
-        x_t = _streams(lambda k: _comb([(c0, x[k]), (c1 - c2, model_s[k]), (c2, model_s2[k])]))
+        x_t = self._streams(lambda k: _comb([(c0, x[k]), (c1 - c2, model_s[k]), (c2, model_s2[k])]))
         if return_intermediate:
             return x_t, {"model_s": model_s, "model_s1": model_s1, "model_s2": model_s2}
         return x_t
@@ -360,7 +365,7 @@ class DPM_Solver:
             c0, c1 = _f(torch.exp(la_t - la_p0)), -_f(sig_t * (torch.exp(h) - 1.))
             cd = -0.5 * _f(sig_t * (torch.exp(h) - 1.))
         # D1_0 = (m0 - m1) / r0
-        return _streams(lambda k: _comb([(c0, x[k]), (c1 + cd * inv_r0, model_prev_0[k]), (-cd * inv_r0, model_prev_1[k])]))
+        return self._streams(lambda k: _comb([(c0, x[k]), (c1 + cd * inv_r0, model_prev_0[k]), (-cd * inv_r0, model_prev_1[k])]))
 
     def multistep_dpm_solver_third_update(self, x, model_prev_list, t_prev_list, t, solver_type="dpm_solver"):
         raise NotImplementedError("multistep third-order update: the reference expands every audio coefficient to the video rank "
@@ -391,7 +396,7 @@ class DPM_Solver:
         the host: one scalar read-back per trial step."""
         ns = self.noise_schedule
         x = self._prep(x)
-        dev, B = x["video"].device, x["video"].shape[0]
+        dev, B = x[self.KEYS[0]].device, self._batch(x)
         s = t_T * torch.ones((1,))
         lambda_s = ns.marginal_lambda(s)
         lambda_0 = ns.marginal_lambda(t_0 * torch.ones_like(s))
@@ -408,7 +413,8 @@ class DPM_Solver:
             higher_update = lambda x, s, t, **kw: self.singlestep_dpm_solver_third_update(x, s, t, r1=r1, r2=r2, solver_type=solver_type, **kw)         # noqa: E731
         else:
             raise ValueError(f"For adaptive step size solver, order must be 2 or 3, got {order}")
-        acc = torch.zeros(2 * B, dtype=torch.float64, device=dev)
+        nk = len(self.KEYS)
+        acc = torch.zeros(nk * B, dtype=torch.float64, device=dev)
         while torch.abs((s - t_0)).mean() > t_err:
             if verbose:
                 print(f"{torch.abs((s - t_0)).mean()} > {t_err}")
@@ -417,9 +423,9 @@ class DPM_Solver:
             x_lower, lower_noise_kwargs = lower_update(x, vs, vt)
             x_higher = higher_update(x, vs, vt, **lower_noise_kwargs)
             acc.zero_()
-            ops.dpm_err(x_higher["video"], x_lower["video"], x_prev["video"], atol, rtol, acc[:B])
-            ops.dpm_err(x_higher["audio"], x_lower["audio"], x_prev["audio"], atol, rtol, acc[B:])
-            per = torch.tensor([x["video"][0].numel()] * B + [x["audio"][0].numel()] * B, dtype=torch.float64, device=dev)
+            for i, k in enumerate(self.KEYS):
+                ops.dpm_err(x_higher[k], x_lower[k], x_prev[k], atol, rtol, acc[i * B:(i + 1) * B])
+            per = torch.tensor([v for k in self.KEYS for v in [x[k][0].numel()] * B], dtype=torch.float64, device=dev)
             E = torch.sqrt(acc / per).max().float().cpu()
             if torch.all(E <= 1.):
                 x = x_higher
@@ -438,7 +444,7 @@ class DPM_Solver:
         t_0 = 1. / self.noise_schedule.total_N if t_end is None else t_end
         t_T = self.noise_schedule.T if t_start is None else t_start
         x = self._prep(x)
-        device, B = x["video"].device, x["video"].shape[0]
+        device, B = x[self.KEYS[0]].device, self._batch(x)
         with torch.no_grad():
             if method == "adaptive":
                 x = self.dpm_solver_adaptive(x, order=order, t_T=t_T, t_0=t_0, atol=atol, rtol=rtol, solver_type=solver_type)

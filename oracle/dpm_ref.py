@@ -49,15 +49,18 @@ def _e(v, x):
 
 
 class Solver:
-    def __init__(self, model, alphas_cumprod, predict_x0=False, thresholding=False, max_val=1.):
+    def __init__(self, model, alphas_cumprod, predict_x0=False, thresholding=False, max_val=1., single=False):
+        """single=True: tensor-valued solver of the SR stage (dpm_solver_plus.py): state {"x": tensor}, model(x, t) -> tensor."""
         self.model, self.ns = model, Schedule(alphas_cumprod)
-        self.predict_x0, self.thresholding, self.max_val = predict_x0, thresholding, max_val
+        self.predict_x0, self.thresholding, self.max_val, self.single = predict_x0, thresholding, max_val, single
 
     def noise(self, x, t):
-        B = x["video"].shape[0]
+        B = next(iter(x.values())).shape[0]
         t = t.reshape(-1)
         t = t.expand(B) if t.shape[0] == 1 else t
         ti = ((t - 1. / self.ns.N) * self.ns.N).to(torch.int)
+        if self.single:
+            return {"x": self.model(x["x"], ti)[:, :3].float()}
         v, a = self.model(x["video"], x["audio"], ti)
         return {"video": v[:, :, :3].float(), "audio": a[:, :1].float()}
 
@@ -89,8 +92,9 @@ class Solver:
             xt = {k: _e(sgt / sgs, x[k]) * x[k] - _e(at * p1, x[k]) * ms[k] for k in x}
         else:
             p1 = torch.expm1(h)
-            xt = {"video": _e(torch.exp(lat - las), x["video"]) * x["video"] - _e(sgt * p1, x["video"]) * ms["video"],
-                  "audio": _e(sgt / sgs, x["audio"]) * x["audio"] - _e(at * p1, x["audio"]) * ms["audio"]}     # reference quirk
+            xt = {k: _e(torch.exp(lat - las), x[k]) * x[k] - _e(sgt * p1, x[k]) * ms[k] for k in x}
+            if "audio" in x:                                                                                # reference quirk
+                xt["audio"] = _e(sgt / sgs, x["audio"]) * x["audio"] - _e(at * p1, x["audio"]) * ms["audio"]
         return (xt, {"ms": ms}) if inter else xt
 
     def second(self, x, s, t, r1=0.5, ms=None, inter=False):
@@ -154,7 +158,7 @@ class Solver:
 
     def adaptive(self, x, order, t_T, t_0, h_init=0.05, atol=0.0078, rtol=0.05, theta=0.9, t_err=1e-5):
         ns = self.ns
-        B = x["video"].shape[0]
+        B = next(iter(x.values())).shape[0]
         s = t_T * torch.ones(B)
         lam_s, lam_0 = ns.lam(s), ns.lam(t_0 * torch.ones(B))
         h = h_init * torch.ones(B)
@@ -169,7 +173,7 @@ class Solver:
                 hi = self.third(x, s, t, ms=kw["ms"], m1=kw["m1"])
             nf = lambda v: torch.sqrt(torch.square(v.reshape(v.shape[0], -1)).mean(dim=-1, keepdim=True))   # noqa: E731
             E = torch.cat([nf((hi[k] - lo[k]) / torch.max(torch.ones_like(x[k]) * atol, rtol * torch.max(lo[k].abs(), xp[k].abs())))
-                           for k in ("video", "audio")]).max()
+                           for k in x]).max()
             if torch.all(E <= 1.):
                 x, s, xp = hi, t, lo
                 lam_s = ns.lam(s)
@@ -187,7 +191,7 @@ class Solver:
     @torch.no_grad()
     def sample(self, x, steps=20, order=3, skip_type="time_uniform", method="singlestep", denoise=False, atol=0.0078, rtol=0.05):
         t_0, t_T = 1. / self.ns.N, 1.
-        B = x["video"].shape[0]
+        B = next(iter(x.values())).shape[0]
         if method == "adaptive":
             x = self.adaptive(x, order, t_T, t_0, atol=atol, rtol=rtol)
         elif method == "multistep":

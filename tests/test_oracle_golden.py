@@ -260,6 +260,18 @@ def test_sr_unet_forward_and_loops():
         assert rel_l2(out, g["sample"]) < 2e-4
 
 
+@pytest.mark.parametrize("tag,px0", [("sr_tiny_dpm_multistep2", False), ("sr_tiny_dpmpp_multistep2", True)])
+def test_sr_single_modal_dpm_solver(tag, px0):
+    from oracle import dpm_ref, sr_ref
+    g = gold(tag)
+    sd = _sr_sd()
+    low, noise = torch.from_numpy(g["low"]), torch.from_numpy(g["noise"])
+    model = lambda x, t: sr_ref.sr_forward(sd, SR_CFG, x, t, low)      # noqa: E731
+    solver = dpm_ref.Solver(model, torch.tensor(dref.Schedule().alphas_cumprod, dtype=torch.float32), predict_x0=px0, single=True)
+    out = solver.sample({"x": noise}, steps=6, order=2, skip_type="time_uniform", method="multistep")["x"]
+    assert rel_l2(out, g["sample"]) < 1e-3
+
+
 def test_full_config1_two_step():
     """BASELINE config[0]: Landscape base model, batch 1, 2-step DDPM on the CPU path."""
     g = gold("full_psample2")

@@ -92,3 +92,18 @@ def test_unbuilt_sr_variants_raise():
     d.update(sr_resblock_updown=False)
     with pytest.raises(NotImplementedError):
         su.image_sr_create_model_and_diffusion(**d)
+
+
+@pytest.mark.parametrize("tag,px0", [("sr_tiny_dpm_multistep2", False), ("sr_tiny_dpmpp_multistep2", True)])
+def test_sr_single_modal_dpm_solver_matches_reference(tag, px0):
+    """dpm_solver_plus.DPM_Solver on the SR model, called like multimodal_sample_sr.py:199-228."""
+    from mm_diffusion.dpm_solver_plus import DPM_Solver
+    g = gold(tag)
+    model, diff = build(torch.float32)
+    low, noise = torch.from_numpy(g["low"]).cuda(), torch.from_numpy(g["noise"]).cuda()
+    solver = DPM_Solver(model=model, alphas_cumprod=torch.tensor(diff.alphas_cumprod, dtype=torch.float32), predict_x0=px0,
+                        model_kwargs={"low_res": low})
+    out = solver.sample(noise.clone(), steps=6, order=2, skip_type="time_uniform", method="multistep")
+    e = rel_l2(out.cpu(), g["sample"])
+    print(f"{tag}: rel-L2 {e:.3e}")
+    assert out.shape == noise.shape and e < 1e-4

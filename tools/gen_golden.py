@@ -358,6 +358,21 @@ def gen_sr():
         save(tag, low=low, noise=noise, sample=out, timestep_map=np.asarray(diff.timestep_map))
 
 
+def gen_sr_dpm():
+    """Single-modal DPM-Solver(++) on the tiny SR model (multimodal_sample_sr.py:199-228: multistep order 2, time_uniform)."""
+    from ref_mm import dpm_solver_plus as rsdpm
+    d, model, diff = _sr_build()
+    g = th.Generator().manual_seed(73)
+    B = 2
+    low = th.rand(B, 3, 16, 16, generator=g) * 2 - 1
+    noise = th.randn(1, 3, 64, 64, generator=g).repeat(B, 1, 1, 1)
+    for tag, px0 in (("sr_tiny_dpm_multistep2", False), ("sr_tiny_dpmpp_multistep2", True)):
+        solver = rsdpm.DPM_Solver(model=model, alphas_cumprod=th.tensor(diff.alphas_cumprod, dtype=th.float32), predict_x0=px0,
+                                  model_kwargs={"low_res": low})
+        out = solver.sample(noise.clone(), steps=6, order=2, skip_type="time_uniform", method="multistep")
+        save(tag, low=low, noise=noise, sample=out)
+
+
 def gen_helpers():
     """q_mean_variance / q_posterior_mean_variance / _predict_* (gd:170-229,345-366) on random inputs."""
     f = flags("tiny", timestep_respacing="")
@@ -390,6 +405,7 @@ ALL = {
     "tiny_cond_guided_a": lambda: gen_cond("tiny", 1, 53, "2", "audio", 3.0),
     "helpers": gen_helpers,
     "sr": gen_sr,
+    "sr_dpm": gen_sr_dpm,
     "dpm_singlestep3": lambda: gen_dpm("tiny_dpm_singlestep3", 61, False, False, steps=20, order=3, skip_type="logSNR", method="singlestep"),
     "dpm_singlestep2": lambda: gen_dpm("tiny_dpm_singlestep2", 62, False, False, steps=7, order=2, skip_type="time_quadratic", method="singlestep"),
     "dpm_multistep2": lambda: gen_dpm("tiny_dpm_multistep2", 63, False, False, steps=10, order=2, skip_type="time_uniform", method="multistep"),
