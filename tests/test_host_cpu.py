@@ -140,3 +140,28 @@ def test_sr_model_surface_matches_reference_keys():
     from mm_diffusion._hip import MMDError
     with pytest.raises(MMDError):                      # no CPU fallback
         model(torch.zeros(1, 3, 64, 64), torch.zeros(1, dtype=torch.int64), low_res=torch.zeros(1, 3, 16, 16))
+
+
+def test_script_shims_common_and_datasets(tmp_path):
+    """The thin counterparts the training / sampling scripts import: run set-up, wav / png writers, clip loader contract."""
+    import types
+    import wave
+    import numpy as np
+    import torch
+    from mm_diffusion import common, logger
+    from mm_diffusion.multimodal_datasets import load_data
+    logger.set_quiet(True)
+    args = types.SimpleNamespace(output_dir=str(tmp_path / "out"), seed=3)
+    assert common.set_seed_logger(args) is args and (tmp_path / "out").is_dir()
+    common.save_audio(np.sin(np.arange(1600) / 10)[None], str(tmp_path / "a.wav"), 16000)
+    with wave.open(str(tmp_path / "a.wav")) as w:
+        assert w.getframerate() == 16000 and w.getnframes() == 1600
+    common.save_one_video(torch.zeros(2, 3, 3, 8, 8), str(tmp_path / "v.gif"), row=2)
+    assert (tmp_path / "v.png").exists()
+    for i in range(3):
+        np.savez(tmp_path / f"clip{i}.npz", video=np.full((4, 8, 8, 3), 10 * i, dtype=np.uint8), audio=np.zeros(64, dtype=np.float32))
+    it = load_data(data_dir=str(tmp_path), batch_size=2, video_size=[4, 3, 8, 8], audio_size=[1, 64], deterministic=True)
+    b = next(it)
+    assert b["video"].shape == (2, 4, 3, 8, 8) and b["audio"].shape == (2, 1, 64) and float(b["video"].min()) == -1.0
+    syn = next(load_data(data_dir="synthetic", batch_size=3, video_size=[4, 3, 8, 8], audio_size=[1, 64]))
+    assert syn["video"].shape == (3, 4, 3, 8, 8) and float(syn["video"].abs().max()) <= 1.0
