@@ -9,14 +9,15 @@
 //   per-sample video/audio GN : S=N,     inner=1,  outer_stride=rows/sample, tstride=1, Tn=rows/sample
 //   spatial self-attn GN      : S=N*F,   inner=1,  outer_stride=HW,          tstride=1, Tn=HW
 //   temporal self-attn GN     : S=N*HW,  inner=HW, outer_stride=F*HW, inner_stride=1, tstride=HW, Tn=F
-// Stage 1 (gn_partial): per (chunk of R rows, slice) per-channel fp32 partial sums, combined in
-//   fp64 in a fixed order (deterministic - no atomics) -> per-group (sum, sumsq) doubles.
+// Stage 1 (gn_partial): per (chunk of R rows, slice) per-thread fp32 partial sums of pivot-shifted data, combined per
+//   group in fp64 in a fixed order (deterministic - no atomics) -> per-group (sum, sumsq) doubles.
 // Stage 2 (gn_finalize): mean / rstd per (slice, group) and the fused affine
 //   a[s,c] = rstd*gamma[c]*(1+scale[s,c]),  b[s,c] = (beta[c]-mean*rstd*gamma[c])*(1+scale[s,c]) + shift[s,c]
 // Stage 3 (gn_apply): y = act(x*a + b), 16-byte vector loads/stores (HBM-bound, 2 bytes moved per byte read).
 #include "mmd_common.h"
 
 #define GN_GROUPS 32
+typedef __attribute__((ext_vector_type(2))) double f64x2;
 
 struct SliceGeom {
   int S, Tn, inner;
@@ -45,8 +46,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
   constexpr int ES = 16 / EPV;
   __shared__ float s_sum[256 * EPV];
   __shared__ float s_sq[256 * EPV];
-  __shared__ double s_csum[2048];
-  __shared__ double s_csq[2048];
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int CV = C / EPV;                 // vecs per row (<= 256)
   const int RPP = 256 / CV;               // rows per pass
@@ -98,32 +98,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
     }
   }
   __syncthreads();
-  // per-channel combine over the RPP row lanes, in double, fixed order (deterministic)
-  for (int c = tid; c < C; c += 256) {
+  // Group combine straight from the per-thread fp32 sums: a group owns RPP*cpg <= 64 of them (RPP*C/32 <= 8*EPV), eight
+  // threads per group sum <= 8 each in double and fold with a fixed xor tree (deterministic; no per-channel staging in LDS:
+  // the earlier version held 32 KB of doubles for it, which capped the kernel at 3 blocks per CU).
+  {
+    const int gi = tid >> 3, k = tid & 7;
+    const int n = RPP * cpg;
     double a = 0.0, b = 0.0;
-    for (int r = 0; r < RPP; ++r) { a += (double)s_sum[r * C + c]; b += (double)s_sq[r * C + c]; }
-    s_csum[c] = a;
-    s_csq[c] = b;
-  }
-  __syncthreads();
-  if (tid < GN_GROUPS) {
-    double a = 0.0, b = 0.0;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += s_csum[c]; b += s_csq[c]; }
-    if (!ONE) {
-      double* o = part + (((int64_t)s * nchunks + chunk) * GN_GROUPS + tid) * 2;
-      o[0] = a;
-      o[1] = b;
-    } else {
-      const double cnt = (double)g.Tn * (double)cpg;
-      const double piv0 = (double)Elt<T>::ld(x, base * ld + (int64_t)tid * cpg);
-      const double dm = a / cnt;
-      double var = b / cnt - dm * dm;
-      if (var < 0.0) var = 0.0;
-      s_csum[tid] = piv0 + dm;                         // mean
-      s_csq[tid] = 1.0 / sqrt(var + (double)eps);      // rstd
-      if (mr_out) {
-        mr_out[((int64_t)s * GN_GROUPS + tid) * 2] = (float)s_csum[tid];
-        mr_out[((int64_t)s * GN_GROUPS + tid) * 2 + 1] = (float)s_csq[tid];
+    for (int e = k; e < n; e += 8) {
+      const int r = e / cpg, c = gi * cpg + (e - r * cpg);
+      a += (double)s_sum[r * C + c];
+      b += (double)s_sq[r * C + c];
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      a += __shfl_xor(a, m);
+      b += __shfl_xor(b, m);
+    }
+    if (k == 0) {
+      if (!ONE) {
+        double* o = part + (((int64_t)s * nchunks + chunk) * GN_GROUPS + gi) * 2;
+        o[0] = a;
+        o[1] = b;
+      } else {
+        const double cnt = (double)g.Tn * (double)cpg;
+        const double piv0 = (double)Elt<T>::ld(x, base * ld + (int64_t)gi * cpg);
+        const double dm = a / cnt;
+        double var = b / cnt - dm * dm;
+        if (var < 0.0) var = 0.0;
+        s_mean[gi] = (float)(piv0 + dm);
+        s_rstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mr_out) {
+          mr_out[((int64_t)s * GN_GROUPS + gi) * 2] = s_mean[gi];
+          mr_out[((int64_t)s * GN_GROUPS + gi) * 2 + 1] = s_rstd[gi];
+        }
       }
     }
   }
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
       const int gi = c / cpg;
-      float a = (float)s_csq[gi] * gamma[c];
-      float b = beta[c] - (float)s_csum[gi] * a;
+      float a = s_rstd[gi] * gamma[c];
+      float b = beta[c] - s_mean[gi] * a;
       if (film) {
         const float sc = 1.f + film[(int64_t)s * film_ld + c];
         const float sh = film[(int64_t)s * film_ld + C + c];
@@ -153,34 +161,52 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const char* __restrict
   __shared__ double s_pa[8][GN_GROUPS], s_pb[8][GN_GROUPS];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int s = blockIdx.x, tid = threadIdx.x;
-  {   // 8 chunk lanes x 32 groups, each lane strides the chunks; combined below in a fixed order
+  const int cpg = C / GN_GROUPS;
+  // Everything that does not depend on the partials is requested first (pivot, gamma / beta / FiLM of this thread's channels):
+  // the kernel is a chain of memory round trips on S blocks, so they must overlap rather than queue behind the reduction.
+  constexpr int CPT = 2048 / 256;         // channels per thread, C <= 2048
+  float gm[CPT], bt[CPT], fsc[CPT], fsh[CPT];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int c = tid + k * 256;
+    if (c < C) {
+      gm[k] = gamma[c];
+      bt[k] = beta[c];
+      fsc[k] = film ? 1.f + film[(int64_t)s * film_ld + c] : 1.f;
+      fsh[k] = film ? film[(int64_t)s * film_ld + C + c] : 0.f;
+    }
+  }
+  double piv = 0.0;
+  if (tid < GN_GROUPS) {
+    const int64_t pidx = slice_base(g, s) * ld + (int64_t)tid * cpg;
+    piv = dtype == MMD_BF16 ? (double)Elt<__bf16>::ld(x, pidx) : (double)Elt<float>::ld(x, pidx);
+  }
+  {   // 8 chunk lanes x 32 groups, each lane strides the chunks with four independent chains; combined below in a fixed order
     const int gi = tid & 31, cl = tid >> 5;
-    double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
     const double* p0 = part + ((int64_t)s * nchunks * GN_GROUPS + gi) * 2;
     int k = cl;
-    for (; k + 8 < nchunks; k += 16) {          // two independent chains -> loads overlap
-      const double* p = p0 + (int64_t)k * GN_GROUPS * 2;
-      const double* q = p0 + (int64_t)(k + 8) * GN_GROUPS * 2;
-      a += p[0];
-      b += p[1];
-      a2 += q[0];
-      b2 += q[1];
+    for (; k + 24 < nchunks; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f64x2 v = *(const f64x2*)(p0 + (int64_t)(k + 8 * u) * GN_GROUPS * 2);
+        a[u] += v[0];
+        b[u] += v[1];
+      }
     }
-    if (k < nchunks) {
-      const double* p = p0 + (int64_t)k * GN_GROUPS * 2;
-      a += p[0];
-      b += p[1];
+    for (; k < nchunks; k += 8) {
+      const f64x2 v = *(const f64x2*)(p0 + (int64_t)k * GN_GROUPS * 2);
+      a[0] += v[0];
+      b[0] += v[1];
     }
-    s_pa[cl][gi] = a + a2;
-    s_pb[cl][gi] = b + b2;
+    s_pa[cl][gi] = (a[0] + a[1]) + (a[2] + a[3]);
+    s_pb[cl][gi] = (b[0] + b[1]) + (b[2] + b[3]);
   }
   __syncthreads();
   if (tid < GN_GROUPS) {
     double a = 0.0, b = 0.0;
     for (int k = 0; k < 8; ++k) { a += s_pa[k][tid]; b += s_pb[k][tid]; }
-    const double cnt = (double)Tn * (double)(C / GN_GROUPS);
-    const int64_t pidx = slice_base(g, s) * ld + (int64_t)tid * (C / GN_GROUPS);
-    const double piv = dtype == MMD_BF16 ? (double)Elt<__bf16>::ld(x, pidx) : (double)Elt<float>::ld(x, pidx);
+    const double cnt = (double)Tn * (double)cpg;
     const double dm = a / cnt;
     double var = b / cnt - dm * dm;
     if (var < 0.0) var = 0.0;
@@ -192,19 +218,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const char* __restrict
     }
   }
   __syncthreads();
-  const int cpg = C / GN_GROUPS;
-  for (int c = tid; c < C; c += 256) {
-    const int gi = c / cpg;
-    float a = s_rstd[gi] * gamma[c];
-    float b = beta[c] - s_mean[gi] * a;
-    if (film) {
-      const float sc = 1.f + film[(int64_t)s * film_ld + c];
-      const float sh = film[(int64_t)s * film_ld + C + c];
-      a *= sc;
-      b = b * sc + sh;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int c = tid + k * 256;
+    if (c < C) {
+      const int gi = c / cpg;
+      const float a = s_rstd[gi] * gm[k];
+      const float b = bt[k] - s_mean[gi] * a;
+      a_out[(int64_t)s * C + c] = a * fsc[k];
+      b_out[(int64_t)s * C + c] = b * fsc[k] + fsh[k];
     }
-    a_out[(int64_t)s * C + c] = a;
-    b_out[(int64_t)s * C + c] = b;
   }
 }
 
@@ -289,8 +312,9 @@ static int check_geom(const char* who, int dtype, int C, int S, int Tn, int inne
 static int gn_rows_per_block(int dtype, int C, int S, int Tn) {
   const int cv = C / (dtype == MMD_BF16 ? 8 : 4);
   const int rpp = 256 / cv > 0 ? 256 / cv : 1;
+  static const int cap = [] { const char* e = getenv("MMD_GN_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1280; }();
   int R = 4 * rpp;
-  while ((int64_t)S * cdiv(Tn, R) > 1280 && R < 1024) R *= 2;   // ~one resident wave of blocks (5/CU x 256 CUs)
+  while ((int64_t)S * cdiv(Tn, R) > cap && R < 1024) R *= 2;   // ~one resident wave of blocks (5/CU x 256 CUs); MMD_GN_BLOCKS: tuning
   return R;
 }
 
@@ -320,7 +344,7 @@ extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, 
                          gamma, beta, film, film_ld, eps, a_out, b_out, mr_out);
     return mmd_check_launch("gn_stats_one");
   }
-  MMD_REQUIRE(workspace, "gn_stats: workspace required for multi-block slices");
+  MMD_REQUIRE(workspace && ((uintptr_t)workspace) % 16 == 0, "gn_stats: 16-byte aligned workspace required for multi-block slices");
   dim3 grid(nchunks, S);
   if (dtype == MMD_BF16)
     hipLaunchKernelGGL((gn_partial_kernel<__bf16, false>), grid, dim3(256), 0, st, (const char*)x, ld, C, g, R, (double*)workspace, nchunks,

@@ -379,15 +379,19 @@ def test_gn_fused_into_conv1x1(ops, dt, N, C, F, H, W, Cout, film_on):
         assert rel_l2(y.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.5e-2)
 
 
-def test_groupnorm_two_stage_path(ops):
-    """Slices longer than one block's share (Tn > 256 rows) take the partial + finalize route."""
-    N, C, R = 2, 128, 1500
-    x = rnd(N * R, C, seed=67) * 1.5 - 0.3
-    g, b = 1 + 0.1 * rnd(C, seed=68), rnd(C, seed=69)
+@pytest.mark.parametrize("dt,C,R", [(torch.float32, 128, 1500), (torch.float32, 1024, 700), (torch.bfloat16, 64, 5000), (torch.bfloat16, 384, 1500),
+                                    (torch.bfloat16, 896, 900), (torch.bfloat16, 2048, 300)])
+def test_groupnorm_two_stage_path(ops, dt, C, R):
+    """Slices longer than one block's share take the partial + finalize route (channel counts whose vectors do not tile the
+    256-thread block, and the 2048-channel SR width, included)."""
+    N = 2
+    x = (rnd(N * R, C, seed=67) * 1.5 - 0.3).to(dt).float()
+    g, b, film = 1 + 0.1 * rnd(C, seed=68), rnd(C, seed=69), rnd(N, 2 * C, seed=70, scale=0.3)
     geom = ops.Geom.per_sample(N, R)
-    y = ops.gn_apply(x.cuda(), *ops.gn_stats(x.cuda(), g.cuda(), b.cuda(), geom), geom, act=False)
-    ref = uref.group_norm(x.reshape(N, R, C).permute(0, 2, 1), g, b).permute(0, 2, 1).reshape(-1, C)
-    assert rel_l2(y.cpu(), ref) < 2e-5
+    xa = dev(x, dt)
+    y = ops.gn_apply(xa, *ops.gn_stats(xa, g.cuda(), b.cuda(), geom, film=film.cuda()), geom, act=False)
+    ref = uref.group_norm(x.reshape(N, R, C).permute(0, 2, 1), g, b) * (1 + film[:, :C, None]) + film[:, C:, None]
+    assert rel_l2(y.float().cpu(), ref.permute(0, 2, 1).reshape(-1, C)) < (2e-5 if dt == torch.float32 else tol(dt))
 
 
 @pytest.mark.parametrize("learn_sigma", [False, True])
