@@ -555,6 +555,103 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const SmallAttnParams p
   }
 }
 
+// attn_small_mfma_kernel (bf16, Tn <= 16, ch in {32,64,96,128}): the same (slice, head) item per wave, on
+// v_mfma_f32_16x16x32_bf16 with NO LDS staging - the VALU kernel above re-reads its K / V quarter from LDS for every query
+// (128 KB of LDS reads per 6 KB item: LDS-return bound at ~1.4 TB/s of HBM traffic).
+//   S^T = K Q^T : A = K rows, B = Q rows, both loaded straight into fragment layout (lane&15 = token, lane>>4 = 8-channel
+//                 k-slot group); D gives the lane of query t = lane&15 the scores of keys 4g .. 4g+3 (g = lane>>4).
+//   softmax     : over the lane's 4 keys and the 4 lanes sharing lane&15 (xor 16, 32), fp32, exp2 with the scale folded in.
+//   O^T = V^T P^T: k-slot (g, e<4) <-> key 4g+e (slots e >= 4 repeat the keys for the low half of P), so P^T is the lane's own
+//                 4 probabilities; V^T rows
+//                 are 2-byte gathers (4 keys of one channel).  Row r of tile tt carries channel (CH/4)*(r>>2) + 4*tt + (r&3),
+//                 which leaves lane (t, g) with the CH/4 contiguous channels g*CH/4 .. of query t -> 16-byte stores.
+template <int CH>
+__global__ __launch_bounds__(256) void attn_small_mfma_kernel(const SmallAttnParams p) {
+  constexpr int NT = CH / 16, KK = CH / 32, OWN = CH / 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)p.S * p.heads) return;
+  const int s = (int)(item / p.heads), h = (int)(item % p.heads);
+  const int64_t base = (int64_t)(s / p.inner) * p.outer_stride + (int64_t)(s % p.inner) * p.inner_stride;
+  const int t = lane & 15, g = lane >> 4;
+  const bool tok = t < p.Tn;
+  const char* qrow = p.QKV + ((base + (int64_t)(tok ? t : 0) * p.tstride) * p.ld + h * CH) * 2;
+  u32x4 qf[KK], kf[KK];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const u32x4 q = *(const u32x4*)(qrow + (kk * 32 + g * 8) * 2);
+    const u32x4 k = *(const u32x4*)(qrow + (p.C + kk * 32 + g * 8) * 2);
+    qf[kk] = tok ? q : zero4;
+    kf[kk] = tok ? k : zero4;
+  }
+  // V^T fragments: channel of this lane's A row per tile, keys 4g .. 4g+3 (clamped to a valid row: their P is zero)
+  uint32_t vlo[NT], vhi[NT];
+  {
+    const char* vcol = p.QKV + (2 * p.C + h * CH + OWN * (t >> 2) + (t & 3)) * 2;
+    const char* vr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = 4 * g + e;
+      vr[e] = vcol + (base + (int64_t)(key < p.Tn ? key : 0) * p.tstride) * p.ld * 2;
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const uint32_t v0 = *(const uint16_t*)(vr[0] + tt * 8), v1 = *(const uint16_t*)(vr[1] + tt * 8);
+      const uint32_t v2 = *(const uint16_t*)(vr[2] + tt * 8), v3 = *(const uint16_t*)(vr[3] + tt * 8);
+      vlo[tt] = v0 | (v1 << 16);
+      vhi[tt] = v2 | (v3 << 16);
+    }
+  }
+  f32x4 sT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+    sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kk]), __builtin_bit_cast(bf16x8, qf[kk]), sT, 0, 0, 0);
+  const float sc = p.scale * 1.44269504088896f;
+  float e4[4], mx = -3e38f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    e4[i] = 4 * g + i < p.Tn ? sT[i] * sc : -3e38f;
+    mx = fmaxf(mx, e4[i]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    e4[i] = 4 * g + i < p.Tn ? __builtin_amdgcn_exp2f(e4[i] - mx) : 0.f;
+    sum += e4[i];
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  // probabilities as a bf16 hi + lo pair in k-slots 0-3 / 4-7 (V duplicated likewise): the product keeps ~16 mantissa bits
+  // of P, i.e. the fp32-softmax numerics of the VALU kernel, for the price of the otherwise empty half of the MFMA
+  float lo4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lo4[i] = e4[i] - bf16_bits_to_f32(f32_to_bf16_bits(e4[i]));
+  const u32x4 pf = {pack_bf16x2(e4[0], e4[1]), pack_bf16x2(e4[2], e4[3]), pack_bf16x2(lo4[0], lo4[1]), pack_bf16x2(lo4[2], lo4[3])};
+  float o[NT * 4];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const u32x4 vf = {vlo[tt], vhi[tt], vlo[tt], vhi[tt]};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), z, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[tt * 4 + i] = r[i];
+  }
+  if (tok) {
+    const float inv = 1.f / sum;
+    char* op = p.O + ((base + (int64_t)t * p.tstride) * p.ldo + h * CH + OWN * g) * 2;
+#pragma unroll
+    for (int c = 0; c < OWN; c += 8) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = o[c + j] * inv;
+      *(u32x4*)(op + c * 2) = Elt<__bf16>::pack(f);
+    }
+  }
+}
+
 // ============================================================================= C-ABI
 template <int D>
 static int launch_mfma(const AttnParams& p, int qmax, hipStream_t st) {
@@ -678,5 +775,16 @@ extern "C" int mmd_attn_small_fwd(int dtype, const void* QKV, int64_t ld, void* 
   p.S = S; p.Tn = Tn; p.inner = inner; p.outer_stride = outer_stride; p.inner_stride = inner_stride; p.tstride = tstride;
   p.scale = 1.0f / sqrtf((float)p.ch);
   hipStream_t st = (hipStream_t)stream;
+  const bool vec = ld % 8 == 0 && ldo % 8 == 0 && C % 8 == 0 && ((uintptr_t)QKV) % 16 == 0 && ((uintptr_t)O) % 16 == 0;
+  if (dtype == MMD_BF16 && Tn <= 16 && vec && (p.ch == 32 || p.ch == 64 || p.ch == 96 || p.ch == 128)) {
+    const dim3 grid((unsigned)(((int64_t)S * heads + 3) / 4));
+    switch (p.ch) {
+      case 32: hipLaunchKernelGGL(attn_small_mfma_kernel<32>, grid, dim3(256), 0, st, p); break;
+      case 64: hipLaunchKernelGGL(attn_small_mfma_kernel<64>, grid, dim3(256), 0, st, p); break;
+      case 96: hipLaunchKernelGGL(attn_small_mfma_kernel<96>, grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL(attn_small_mfma_kernel<128>, grid, dim3(256), 0, st, p); break;
+    }
+    return mmd_check_launch("attn_small_mfma");
+  }
   return dtype == MMD_BF16 ? dispatch_small<__bf16>(p, st) : dispatch_small<float>(p, st);
 }

@@ -168,6 +168,84 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const EdgeConvParams p) 
   }
 }
 
+// Strip variant (W % 4 == 0, Cin in {1, 3}): thread = (one 16-byte chunk of output channels, FOUR consecutive pixels along w).
+// The per-pixel kernel above walks its taps one dependent scalar load at a time (27 L2 round trips per thread: 210 us for the
+// 16x64x64 stem, 8.6 TFLOP/s) and re-reads every weight from LDS per pixel; here three taps x Cin x 4 pixels of loads are in
+// flight before the first FMA, borders are handled branch-free (clamped address, zeroed value), and each weight read from LDS
+// feeds four pixels.
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void stem_conv_strip_kernel(const EdgeConvParams p) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  constexpr int PX = 4;
+  extern __shared__ float sw[];    // [ntaps*CIN][Cout]
+  for (int i = threadIdx.x; i < p.ntaps * CIN * p.Cout; i += 256) sw[i] = p.w[i];
+  __syncthreads();
+  const int CV = p.Cout / EPV;
+  const int WS = p.W / PX;
+  const int64_t total = (int64_t)p.N * p.F * p.H * WS * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t sidx = i / CV;
+    const int w0 = (int)(sidx % WS) * PX;
+    sidx /= WS;
+    const int h0 = (int)(sidx % p.H);
+    sidx /= p.H;
+    const int f0 = (int)(sidx % p.F);
+    const int64_t n = sidx / p.F;
+    float acc[PX][EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float b = p.bias ? p.bias[cv * EPV + e] : 0.f;
+#pragma unroll
+      for (int px = 0; px < PX; ++px) acc[px][e] = b;
+    }
+    for (int tg = 0; tg < p.ntaps; tg += 3) {
+      float xv[3][CIN][PX];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int t = min(tg + u, p.ntaps - 1);
+        const int f = f0 + p.taps[t * 3], h = h0 + p.taps[t * 3 + 1], wb = w0 + p.taps[t * 3 + 2];
+        const bool okfh = (tg + u < p.ntaps) && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H;
+        const int fc = okfh ? f : f0, hc = okfh ? h : h0;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const float* xr = p.x + (((n * p.F + fc) * CIN + ci) * p.H + hc) * (int64_t)p.W;
+#pragma unroll
+          for (int px = 0; px < PX; ++px) {
+            const int w = wb + px;
+            const float v = xr[min(max(w, 0), p.W - 1)];
+            xv[u][ci][px] = (okfh && (unsigned)w < (unsigned)p.W) ? v : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (tg + u < p.ntaps) {
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) {
+            const float* wr = sw + ((tg + u) * CIN + ci) * p.Cout + cv * EPV;
+            float wv[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4) {
+              const f32x4 w4 = *(const f32x4*)(wr + e);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) wv[e + k] = w4[k];
+            }
+#pragma unroll
+            for (int px = 0; px < PX; ++px)
+#pragma unroll
+              for (int e = 0; e < EPV; ++e) acc[px][e] += xv[u][ci][px] * wv[e];
+          }
+        }
+      }
+    }
+    const int64_t m0 = ((n * p.F + f0) * p.H + h0) * (int64_t)p.W + w0;
+#pragma unroll
+    for (int px = 0; px < PX; ++px) *(u32x4*)(p.y + ((m0 + px) * p.ldy + (int64_t)cv * EPV) * ES) = Elt<T>::pack(acc[px]);
+  }
+}
+
 // ----------------------------------------------------------------------------- head conv (channels-last -> API layout)
 // in: T rows [N*F*H*W, Cin] (already GN+SiLU'd)   W packed fp32 [ntaps][Cin][Co] (Co <= 8)   out fp32 [N,F,Co,H,W]
 struct HeadConvParams {
@@ -403,6 +481,14 @@ extern "C" int mmd_stem_conv(int dtype, const float* x, const float* w, const fl
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   const int64_t total = (int64_t)N * F * H * W * (Cout / epv);
   hipStream_t st = (hipStream_t)stream;
+  if (W % 4 == 0 && (Cin == 1 || Cin == 3) && Cout % 4 == 0) {
+    const dim3 grid(ew_grid(total / 4));
+    if (dtype == MMD_BF16 && Cin == 3) hipLaunchKernelGGL((stem_conv_strip_kernel<__bf16, 3>), grid, dim3(256), lds, st, p);
+    else if (dtype == MMD_BF16) hipLaunchKernelGGL((stem_conv_strip_kernel<__bf16, 1>), grid, dim3(256), lds, st, p);
+    else if (Cin == 3) hipLaunchKernelGGL((stem_conv_strip_kernel<float, 3>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((stem_conv_strip_kernel<float, 1>), grid, dim3(256), lds, st, p);
+    return mmd_check_launch("stem_conv_strip");
+  }
   if (dtype == MMD_BF16) hipLaunchKernelGGL(stem_conv_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(ew_grid(total)), dim3(256), lds, st, p);
   return mmd_check_launch("stem_conv");
@@ -484,6 +570,127 @@ __global__ __launch_bounds__(256) void head_conv_coop_kernel(const HeadConvParam
   }
 }
 
+// Strip variant of the cooperative kernel (W % 4 == 0): the LPR lanes of a group own FOUR consecutive output pixels, so
+// every weight quad read from LDS feeds four pixels (the per-row version re-reads all ntaps*Cin*CO weights per output row:
+// 14 GB of LDS returns for the 16x64x64 head, 355 us), CO is the exact output width (3, not 4), and twelve row reads are in
+// flight per tap group.
+template <typename T, int CO, int LPR>
+__global__ __launch_bounds__(256) void head_conv_strip_kernel(const HeadConvParams p) {
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  constexpr int PX = 4;
+  constexpr int NQ = EPV * CO / 4;       // float4 quads of weights per (tap, lane)
+  constexpr int SPW = 64 / LPR;          // strips per wave pass
+  extern __shared__ __attribute__((aligned(16))) float sw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < p.ntaps * NQ * LPR * 4; i += 256) {
+    const int k = i & 3, cvi = (i >> 2) % LPR, j = ((i >> 2) / LPR) % NQ, t = (i >> 2) / (LPR * NQ);
+    const int ec = j * 4 + k, e = ec / CO, c = ec % CO;
+    sw[i] = p.w[((int64_t)t * p.Cin + cvi * EPV + e) * CO + c];
+  }
+  __syncthreads();
+  const int HW = p.H * p.W, WS = p.W / PX;
+  const int64_t strips = (int64_t)p.N * p.F * p.H * WS;
+  const int cvi = lane % LPR, rsel = lane / LPR;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t sb = wave_id * SPW; sb < strips; sb += nwaves * SPW) {
+    const bool rok = sb + rsel < strips;
+    int64_t sidx = rok ? sb + rsel : 0;
+    const int w0 = (int)(sidx % WS) * PX;
+    sidx /= WS;
+    const int h0 = (int)(sidx % p.H);
+    sidx /= p.H;
+    const int f0 = (int)(sidx % p.F);
+    const int64_t n = sidx / p.F;
+    const int64_t m0 = ((n * p.F + f0) * p.H + h0) * (int64_t)p.W + w0;
+    float acc[PX][CO];
+#pragma unroll
+    for (int px = 0; px < PX; ++px)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[px][c] = 0.f;
+    for (int tg = 0; tg < p.ntaps; tg += 3) {
+      u32x4 v[3][PX];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int t = min(tg + u, p.ntaps - 1);
+        const int df = p.taps[t * 3], dh = p.taps[t * 3 + 1], dw = p.taps[t * 3 + 2];
+        const bool okfh = rok && (tg + u < p.ntaps) && (unsigned)(f0 + df) < (unsigned)p.F && (unsigned)(h0 + dh) < (unsigned)p.H;
+        const int64_t src = m0 + (int64_t)df * HW + dh * p.W + dw;
+#pragma unroll
+        for (int px = 0; px < PX; ++px) {
+          const bool ok = okfh && (unsigned)(w0 + px + dw) < (unsigned)p.W;
+          const char* sp = ok ? p.x + ((src + px) * p.ldx + (int64_t)cvi * EPV) * ES : (const char*)g_zero_page_misc;
+          v[u][px] = *(const u32x4*)sp;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (tg + u < p.ntaps) {
+          const float* wq = sw + ((int64_t)(tg + u) * NQ * LPR + cvi) * 4;
+          float wv[NQ * 4];
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) {
+            const f32x4 w4 = *(const f32x4*)(wq + j * LPR * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[j * 4 + k] = w4[k];
+          }
+#pragma unroll
+          for (int px = 0; px < PX; ++px) {
+            float f[EPV];
+            Elt<T>::unpack(v[u][px], f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e)
+#pragma unroll
+              for (int c = 0; c < CO; ++c) acc[px][c] += f[e] * wv[e * CO + c];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int px = 0; px < PX; ++px)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) acc[px][c] += __shfl_xor(acc[px][c], o, 64);
+      }
+    if (rok && cvi == 0) {
+      const int hw = h0 * p.W + w0;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const float b = p.bias ? p.bias[c] : 0.f;
+        const f32x4 o4 = {acc[0][c] + b, acc[1][c] + b, acc[2][c] + b, acc[3][c] + b};
+        *(f32x4*)(p.y + ((n * p.F + f0) * CO + c) * HW + hw) = o4;
+      }
+    }
+  }
+}
+
+template <typename T, int CO>
+static int launch_head_strip(const HeadConvParams& p, int lpr, hipStream_t st) {
+  constexpr int EPV = Elt<T>::EPV;
+  const size_t lds = (size_t)p.ntaps * (EPV * CO / 4) * lpr * 4 * sizeof(float);
+  const int64_t strips = (int64_t)p.N * p.F * p.H * (p.W / 4);
+  const int spb = 4 * (64 / lpr);                       // strips per block pass
+  const int grid = (int)min((int64_t)2048, (strips + spb - 1) / spb);
+#define MMD_HEADS_LAUNCH(L)                                                                                         \
+  do {                                                                                                              \
+    if (lds > 64 * 1024) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void*)head_conv_strip_kernel<T, CO, L>,                             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "head_conv: set LDS attr: %s", hipGetErrorString(e)); \
+    }                                                                                                               \
+    hipLaunchKernelGGL((head_conv_strip_kernel<T, CO, L>), dim3(grid), dim3(256), lds, st, p);                      \
+  } while (0)
+  switch (lpr) {
+    case 4: MMD_HEADS_LAUNCH(4); break;
+    case 8: MMD_HEADS_LAUNCH(8); break;
+    case 16: MMD_HEADS_LAUNCH(16); break;
+    default: MMD_HEADS_LAUNCH(32); break;
+  }
+#undef MMD_HEADS_LAUNCH
+  return mmd_check_launch("head_conv_strip");
+}
+
 template <typename T, int CO>
 static int launch_head_coop(const HeadConvParams& p, int lpr, hipStream_t st) {
   constexpr int EPV = Elt<T>::EPV;
@@ -515,6 +722,20 @@ template <typename T>
 static int launch_head(const HeadConvParams& p, hipStream_t st) {
   const int64_t rows = (int64_t)p.N * p.F * p.H * p.W;
   const int grid = (int)min((int64_t)8192, (rows + 255) / 256);
+  {   // strip kernel: four pixels per lane group, exact output width
+    const int lpr = p.Cin / Elt<T>::EPV;
+    const bool lpr_ok = p.Cin % Elt<T>::EPV == 0 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32);
+    const size_t lds_s = (size_t)p.ntaps * Elt<T>::EPV * p.Co * lpr * sizeof(float);
+    if (p.W % 4 == 0 && ((uintptr_t)p.y) % 16 == 0 && lpr_ok && lds_s <= 150 * 1024) {
+      switch (p.Co) {
+        case 1: return launch_head_strip<T, 1>(p, lpr, st);
+        case 2: return launch_head_strip<T, 2>(p, lpr, st);
+        case 3: return launch_head_strip<T, 3>(p, lpr, st);
+        case 6: return launch_head_strip<T, 6>(p, lpr, st);
+        default: break;
+      }
+    }
+  }
   const int CO = p.Co <= 2 ? 2 : (p.Co <= 4 ? 4 : 8);
   {   // cooperative kernel whenever the channel chunks of a row map onto a power-of-two lane group
     const int lpr = p.Cin / Elt<T>::EPV;

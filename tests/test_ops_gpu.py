@@ -247,7 +247,7 @@ def test_attention_softmax_spike(ops):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("F,HW,heads,ch", [(16, 9, 4, 64), (8, 5, 4, 16), (16, 3, 4, 96), (20, 2, 2, 32), (3, 7, 4, 128)])
+@pytest.mark.parametrize("F,HW,heads,ch", [(16, 9, 4, 64), (8, 5, 4, 16), (16, 3, 4, 96), (20, 2, 2, 32), (3, 7, 4, 128), (8, 5, 4, 64), (13, 4, 2, 32), (1, 6, 2, 64)])
 def test_temporal_attention(ops, dt, F, HW, heads, ch):
     N, C = 2, heads * ch
     qkv = _qkv_rows(N, F * HW, C, dt, 29)
@@ -305,19 +305,21 @@ def test_temb_and_linear(ops):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_stem_and_head(ops, dt):
-    N, F, H, W, C = 2, 3, 8, 6, 64
+@pytest.mark.parametrize("H,W,L,C", [(8, 6, 50, 64), (4, 8, 52, 128), (5, 12, 8, 32)])
+def test_stem_and_head(ops, dt, H, W, L, C):
+    """Per-pixel kernels (W, L not multiples of 4) and the four-pixel strip kernels (W % 4 == 0)."""
+    N, F = 2, 3
     xv = rnd(N, F, 3, H, W, seed=39)
     ws, bs = rnd(C, 3, 3, 3, seed=40, scale=27 ** -0.5), rnd(C, seed=41)
     out = torch.empty(N * F * H * W, C, dtype=dt, device="cuda")
     ops.stem_conv(xv.cuda(), ops.pack_edge_weight(ws).cuda(), bs.cuda(), out, N, F, 3, H, W, ops.TAPS_SPATIAL)
     ref = F_.conv3d(xv.permute(0, 2, 1, 3, 4), ws[:, :, None], bs, padding=(0, 1, 1))
     assert rel_l2(unrows_video(out.float().cpu(), N, F, H, W), ref) < tol(dt)
-    xa = rnd(N, 1, 50, seed=42)
+    xa = rnd(N, 1, L, seed=42)
     wa, ba = rnd(C, 1, 3, seed=43), rnd(C, seed=44)
-    out = torch.empty(N * 50, C, dtype=dt, device="cuda")
-    ops.stem_conv(xa.cuda(), ops.pack_edge_weight(wa).cuda(), ba.cuda(), out, N, 1, 1, 1, 50, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
-    assert rel_l2(out.float().cpu().reshape(N, 50, C).permute(0, 2, 1), F_.conv1d(xa, wa, ba, padding=1)) < tol(dt)
+    out = torch.empty(N * L, C, dtype=dt, device="cuda")
+    ops.stem_conv(xa.cuda(), ops.pack_edge_weight(wa).cuda(), ba.cuda(), out, N, 1, 1, 1, L, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+    assert rel_l2(out.float().cpu().reshape(N, L, C).permute(0, 2, 1), F_.conv1d(xa, wa, ba, padding=1)) < tol(dt)
     for Co in (3, 6):
         h = rnd(N, C, F, H, W, dt=dt, seed=45)
         wh, bh = rnd(Co, C, 3, 3, 3, seed=46, scale=(27 * C) ** -0.5), rnd(Co, seed=47)
@@ -326,10 +328,10 @@ def test_stem_and_head(ops, dt):
         ref = F_.conv3d(h, wh, bh, padding=1).permute(0, 2, 1, 3, 4)
         assert rel_l2(y.cpu(), ref) < 2e-5
     for Co in (1, 2):
-        h = rnd(N, C, 50, dt=dt, seed=48)
+        h = rnd(N, C, L, dt=dt, seed=48)
         wh, bh = rnd(Co, C, 3, seed=49), rnd(Co, seed=50)
-        y = torch.empty(N, Co, 50, device="cuda")
-        ops.head_conv(dev(rows_audio(h), dt), ops.pack_edge_weight(wh).cuda(), bh.cuda(), y, N, 1, 1, 50, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
+        y = torch.empty(N, Co, L, device="cuda")
+        ops.head_conv(dev(rows_audio(h), dt), ops.pack_edge_weight(wh).cuda(), bh.cuda(), y, N, 1, 1, L, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
         assert rel_l2(y.cpu(), F_.conv1d(h, wh, bh, padding=1)) < 2e-5
 
 
