@@ -537,6 +537,241 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Halo-tile main loop for spatial 3x3 convolutions (tile code 130, EXPERIMENTAL: opt-in, not in the autotune set yet).
+// The direct-to-LDS kernel above is bound by the L2 -> LDS fill rate (~27 B/clk/CU measured against the 64 B/clk/CU the
+// MFMA rate would need at 64 flop per staged byte), and a 9-tap conv stages every activation row nine times.  Here a block
+// owns an 8x16 pixel patch of ONE frame: per 128-byte channel chunk the (8+2)x(16+2) halo of the patch is staged once
+// (23 KB) and the nine taps read shifted windows of it, so a chunk stages 23 + 9*16 = 167 KB instead of 288 KB and padding
+// is a zero row of the halo (no per-tap predicates).  K order is chunk-major (the other main loops are tap-major: results
+// agree to fp32 rounding, not bitwise).  Halo row r = (ph+1+dh)*18 + (pw+1+dw); the 16-byte chunk swizzle is keyed on r,
+// and 16 consecutive pixels of a patch row are 16 consecutive halo rows, so the fragment reads stay conflict free.
+// Requires: taps with d0 offset 0 and |dh|,|dw| <= 1, D1 % 8 == 0, D2 % 16 == 0, M = D0*D1*D2, Cin % (128 B) == 0.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmParams p) {
+  constexpr int BM = 128, BN = 128, PH = 8, PW = 16, HWD = PW + 2, HR = (PH + 2) * HWD, HG = (HR + 7) / 8, HJ = (HG + 3) / 4;
+  constexpr int EPV = Elt<T>::EPV;
+  constexpr int ES = 16 / EPV;
+  constexpr int LDC = BN + 4;
+  constexpr int A_B = HG * 8 * 128;            // halo stage: 23 groups of 8 rows
+  constexpr int W_B = 128 * 128;
+  constexpr int MAIN_B = (2 * A_B + 2 * W_B > BM * LDC * 4) ? 2 * A_B + 2 * W_B : BM * LDC * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                             // [2][HG*8 rows][128 B]
+  char* sW = smem + 2 * A_B;                   // [2][128 rows][128 B]
+  float* sC = (float*)smem;
+  int* s_taps = (int*)(smem + MAIN_B);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  if (tid < p.ntaps * 3) s_taps[tid] = p.taps[tid];
+
+  const int Nt = (p.Cout + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wgid % Nt, mt = wgid / Nt;
+  const int n0 = nt * BN;
+  const int TW = p.D2 / PW, tpf = TW * (p.D1 / PH);
+  const int d0 = mt / tpf, trem = mt - d0 * tpf;
+  const int h0 = (trem / TW) * PH, w0 = (trem % TW) * PW;
+  const int64_t mframe = (int64_t)d0 * p.D1 * p.D2;
+
+  const int CinV = p.Cin / EPV;
+  const int nchunk = CinV >> 3;
+  const int64_t K = (int64_t)p.Cin * p.ntaps;
+  const int nit = nchunk * p.ntaps;
+
+  const int lrow = lane >> 3, pc = lane & 7;
+  // halo DMA: wave w stages row groups g = w + 4j; lane-constant source (row pointer + logical chunk), uniform chunk offset
+  const char* h_ptr[HJ];
+  bool h_ok[HJ];
+#pragma unroll
+  for (int j = 0; j < HJ; ++j) {
+    const int g = wave + 4 * j;
+    const int r = 8 * g + lrow;
+    const int hr = r / HWD, hc = r - hr * HWD;
+    const int hh = h0 - 1 + hr, ww = w0 - 1 + hc;
+    h_ok[j] = g < HG && r < HR && (unsigned)hh < (unsigned)p.D1 && (unsigned)ww < (unsigned)p.D2;
+    const int logical = pc ^ ((r >> 1) & 7);
+    h_ptr[j] = p.A + ((mframe + (int64_t)hh * p.D2 + ww) * p.lda + (int64_t)logical * EPV) * ES;
+  }
+  const char* w_ptr[4];
+  bool w_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int logical = pc ^ (((8 * i + lrow) >> 1) & 7);
+    const int co = n0 + wave * 32 + 8 * i + lrow;
+    w_ok[i] = co < p.Cout;
+    w_ptr[i] = p.W + ((int64_t)(w_ok[i] ? co : 0) * K + (int64_t)logical * EPV) * ES;
+  }
+  __syncthreads();   // s_taps visible
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_w = [&](int buf, int t, int c) {
+    const int64_t offW = ((int64_t)t * p.Cin + (int64_t)c * 8 * EPV) * ES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* src = w_ok[i] ? w_ptr[i] + offW : (const char*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + buf * W_B + (wave * 32 + 8 * i) * 128), 16, 0, 0);
+    }
+  };
+  auto issue_h = [&](int buf, int c, int j) {
+    if (wave + 4 * j < HG) {                                   // wave-uniform
+      const char* src = h_ok[j] ? h_ptr[j] + (int64_t)c * 128 : (const char*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * A_B + (wave + 4 * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int xsw = (l31 >> 1) & 7;
+  int rb[2];                                   // halo row of this lane's pixel (tap 0,0) per m sub-tile
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int px = wr * 64 + b * 32 + l31;
+    rb[b] = ((px >> 4) + 1) * HWD + (px & 15) + 1;
+  }
+  auto compute = [&](int bufw, int bufa, int t) {
+    const int o1 = __builtin_amdgcn_readfirstlane(s_taps[t * 3 + 1]), o2 = __builtin_amdgcn_readfirstlane(s_taps[t * 3 + 2]);
+    const int toff = o1 * HWD + o2;
+    const char* bW = sW + bufw * W_B + (wc * 64 + l31) * 128;
+    const char* bA[2];
+    int key[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int r = rb[b] + toff;
+      key[b] = (r >> 1) & 7;
+      bA[b] = sA + bufa * A_B + r * 128;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      u32x4 fw[2], fa[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fw[a] = *(const u32x4*)(bW + a * 32 * 128 + (((2 * c + half) ^ xsw) * 16));
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fa[b] = *(const u32x4*)(bA[b] + (((2 * c + half) ^ key[b]) * 16));
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
+    }
+  };
+
+  // prologue: whole halo of chunk 0 + weights of step 0
+#pragma unroll
+  for (int j = 0; j < HJ; ++j) issue_h(0, 0, j);
+  issue_w(0, 0, 0);
+  constexpr int CVN = BN / 8, RP = 256 / CVN, NPASS = BM / RP;
+  const int e_cg = tid % CVN, e_rr = tid / CVN;
+  const int e_co = n0 + e_cg * 8;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = (p.bias && e_co < p.Cout) ? p.bias[e_co + j] : 0.f;
+  u32x4 rres[NPASS][8 / EPV];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int c = 0, t = 0;
+  for (int it = 0; it + 1 < nit; ++it) {
+    int tn = t + 1, cn = c;
+    if (tn == p.ntaps) { tn = 0; ++cn; }
+    issue_w((it + 1) & 1, tn, cn);                           // next step's weights under this step's MFMAs
+    if (c + 1 < nchunk) {                                    // next chunk's halo, spread over this chunk's steps
+#pragma unroll
+      for (int j = 0; j < HJ; ++j)
+        if (j % p.ntaps == t) issue_h((c + 1) & 1, c + 1, j);
+    }
+    compute(it & 1, c & 1, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    t = tn;
+    c = cn;
+  }
+  auto row_of = [&](int ml) { return mframe + (int64_t)(h0 + (ml >> 4)) * p.D2 + w0 + (ml & 15); };
+  if (p.R) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int64_t m = row_of(e_rr + ps * RP);
+#pragma unroll
+      for (int h = 0; h < 8 / EPV; ++h)
+        rres[ps][h] = *(const u32x4*)(e_co < p.Cout ? p.R + (m * p.ldr + e_co + h * EPV) * ES : (const char*)g_zero_page);
+    }
+  }
+  compute((nit - 1) & 1, c & 1, t);
+  __syncthreads();                                           // every wave is past its last operand read: sC may alias
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const int ml = wr * 64 + b2 * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = wc * 64 + a * 32 + 8 * q + 4 * half;
+        f32x4 v = {acc[a][b2][4 * q], acc[a][b2][4 * q + 1], acc[a][b2][4 * q + 2], acc[a][b2][4 * q + 3]};
+        *(f32x4*)(sC + ml * LDC + col) = v;
+      }
+    }
+  __syncthreads();
+  if (e_co < p.Cout) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int ml = e_rr + ps * RP;
+      const int64_t m = row_of(ml);
+      float v[8];
+      const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + e_cg * 8);
+      const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + e_cg * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
+      if (p.R) {
+#pragma unroll
+        for (int h = 0; h < 8 / EPV; ++h) {
+          float rf[EPV];
+          Elt<T>::unpack(rres[ps][h], rf);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 8 / EPV; ++h)
+        *(u32x4*)(p.Y + (m * p.ldy + e_co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
+    }
+  }
+}
+
+template <typename T>
+static int launch_conv_gemm_halo(const ConvGemmParams& p, hipStream_t st) {
+  bool taps_ok = p.ntaps <= 9;
+  for (int t = 0; t < p.ntaps && taps_ok; ++t)
+    taps_ok = p.taps[t * 3] == 0 && p.taps[t * 3 + 1] >= -1 && p.taps[t * 3 + 1] <= 1 && p.taps[t * 3 + 2] >= -1 && p.taps[t * 3 + 2] <= 1;
+  if (!taps_ok || p.D1 % 8 != 0 || p.D2 % 16 != 0 || (int64_t)p.D0 * p.D1 * p.D2 != p.M || p.Cin % (8 * Elt<T>::EPV) != 0)
+    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 130 (halo): needs spatial taps (|dh|,|dw| <= 1), D1 %% 8 == 0, D2 %% 16 == 0, "
+                         "full frames and Cin a multiple of one 128-byte K step");
+  const size_t lds = 2 * (size_t)(23 * 8 * 128) + 2 * (size_t)(128 * 128) + 336;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_halo: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = (p.M / 128) * cdiv(p.Cout, 128);
+  hipLaunchKernelGGL((conv_gemm_halo_kernel<T>), dim3(grid), dim3(256), lds, st, p);
+  return mmd_check_launch("conv_gemm_halo");
+}
+
 template <typename T>
 static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds = 128 * 132 * sizeof(float) + 336;
@@ -577,6 +812,7 @@ static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st)
     return launch_conv_gemm<T, 64, 64, true>(p, st);
   }
   if (tile == 129) return launch_conv_gemm_glds<T>(p, st);
+  if (tile == 130) return launch_conv_gemm_halo<T>(p, st);
   if (tile == 128) return launch_conv_gemm<T, 128, 128, false>(p, st);
   return launch_conv_gemm<T, 64, 64, false>(p, st);
 }
@@ -604,7 +840,8 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
-  MMD_REQUIRE(tile == 64 || tile == 128 || (tile == 129 && !gn_a), "conv_gemm: tile must be 0, 64, 128 or 129 (128 direct-to-LDS)");
+  MMD_REQUIRE(tile == 64 || tile == 128 || ((tile == 129 || tile == 130) && !gn_a),
+              "conv_gemm: tile must be 0, 64, 128, 129 (128 direct-to-LDS) or 130 (halo-tile 3x3, experimental)");
   return dtype == MMD_BF16 ? dispatch_conv_gemm<__bf16>(p, tile, st) : dispatch_conv_gemm<float>(p, tile, st);
 }
 

@@ -7,6 +7,7 @@ Tolerances (rel-L2 against the fp32 CPU oracle on the same inputs):
 Index/window/padding errors produce O(1) errors, far above either bound.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -82,6 +83,24 @@ def test_direct_to_lds_variants_agree(ops, dt, res, M, Cin, Cout, taps):
     y0 = ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=128)
     for _ in range(3):
         assert torch.equal(y0, ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=129))
+
+
+@pytest.mark.skipif(os.environ.get("MMD_TEST_EXPERIMENTAL") != "1", reason="tile 130 (halo-tile 3x3 main loop) is opt-in until it has been measured")
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("D0,H,W,Cin,Cout", [(5, 16, 32, 64, 128), (3, 8, 16, 128, 96), (2, 24, 48, 192, 256 + 8)])
+def test_halo_tile_variant(ops, dt, res, D0, H, W, Cin, Cout):
+    """3x3 conv with one staged halo per channel chunk (tile 130) against the direct-to-LDS kernel: chunk-major K order, so
+    equal to fp32 rounding (not bitwise); patches on every border of the frame, ragged Cout, residual."""
+    M = D0 * H * W
+    g = torch.Generator(device="cuda").manual_seed(M + Cin)
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(dt)
+    w = (torch.randn(Cout, Cin * 9, device="cuda", generator=g) * (Cin * 9) ** -0.5).to(dt)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(M, Cout, device="cuda", generator=g).to(dt) if res else None
+    y0 = ops.conv_gemm(x, w, b, taps=ops.TAPS_SPATIAL, dims=(D0, H, W), residual=r, tile=129)
+    y1 = ops.conv_gemm(x, w, b, taps=ops.TAPS_SPATIAL, dims=(D0, H, W), residual=r, tile=130)
+    assert rel_l2(y1.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

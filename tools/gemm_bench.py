@@ -30,7 +30,7 @@ SHAPES = [  # name, M, Cin, taps, dims, Cout, residual
     ("qkv ds8 512->1536", 4096, 512, ops.TAPS_1, (1, 1, 1), 1536, False),
     ("audio qkv 256->768", 25600, 256, ops.TAPS_1, (1, 1, 1), 768, False),
 ]
-TILES = (64, 128, 129)
+TILES = (64, 128, 129, 130)     # 130 = halo-tile 3x3 main loop (experimental; spatial taps only)
 
 
 def main():
@@ -50,6 +50,8 @@ def main():
         ref = None
         line = f"{name:26s} M={M:6d} K={Cin*len(taps):5d} N={Cout:4d}"
         for tile in TILES:
+            if tile == 130 and not (len(taps) == 9 and dims[1] % 8 == 0 and dims[2] % 16 == 0 and Cin % 64 == 0):
+                continue
             y = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile)
             if ref is None:
                 ref = y.clone()
