@@ -139,6 +139,7 @@ def add_rowbias(x, e, rows_per_sample):
 TAPS_1 = [(0, 0, 0)]
 TAPS_SPATIAL = [(0, dh, dw) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]      # D = (1|F, H, W)
 TAPS_TEMPORAL = [(df, 0, 0) for df in (-1, 0, 1)]                           # D = (F, HW, 1)
+TAPS_TEMPORAL_D1 = [(0, df, 0) for df in (-1, 0, 1)]                        # the same conv with D = (N, F, HW): the form tile 130 accepts
 TAPS_3D = [(df, dh, dw) for df in (-1, 0, 1) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]
 
 

@@ -14,6 +14,8 @@ SHAPES = [  # name, M, Cin, taps, dims, Cout, residual
     ("3x3 ds1 128->128", 262144, 128, ops.TAPS_SPATIAL, (64, 64, 64), 128, False),
     ("3x3 ds1 256->128", 262144, 256, ops.TAPS_SPATIAL, (64, 64, 64), 128, False),
     ("k3t ds1 128->128", 262144, 128, ops.TAPS_TEMPORAL, (16, 4096, 1), 128, False),
+    ("k3t ds1 128->128 (N,F,HW)", 262144, 128, ops.TAPS_TEMPORAL_D1, (4, 16, 4096), 128, False),
+    ("k3t ds2 256->256 (N,F,HW)", 65536, 256, ops.TAPS_TEMPORAL_D1, (4, 16, 1024), 256, False),
     ("3x3 ds2 256->256", 65536, 256, ops.TAPS_SPATIAL, (64, 32, 32), 256, False),
     ("3x3 ds4 384->384", 16384, 384, ops.TAPS_SPATIAL, (64, 16, 16), 384, False),
     ("3x3 ds8 512->512", 4096, 512, ops.TAPS_SPATIAL, (64, 8, 8), 512, False),
@@ -50,7 +52,8 @@ def main():
         ref = None
         line = f"{name:26s} M={M:6d} K={Cin*len(taps):5d} N={Cout:4d}"
         for tile in TILES:
-            if tile == 130 and not (len(taps) == 9 and dims[1] % 8 == 0 and dims[2] % 16 == 0 and Cin % 64 == 0):
+            if tile == 130 and not (all(t[0] == 0 and abs(t[1]) <= 1 and abs(t[2]) <= 1 for t in taps) and len(taps) > 1
+                                    and dims[1] % 8 == 0 and dims[2] % 16 == 0 and Cin % 64 == 0):
                 continue
             y = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile)
             if ref is None:
