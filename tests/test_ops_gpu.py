@@ -103,6 +103,21 @@ def test_halo_tile_variant(ops, dt, res, D0, H, W, Cin, Cout):
     assert rel_l2(y1.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
 
 
+@pytest.mark.skipif(os.environ.get("MMD_TEST_EXPERIMENTAL") != "1", reason="tile 130 (halo-tile main loop) is opt-in until it has been measured")
+@pytest.mark.parametrize("dt", DTYPES)
+def test_halo_tile_variant_temporal_form(ops, dt):
+    """The temporal k=3 conv written as D = (N, F, HW), taps (0, +-1, 0): tile 130 against the (F, HW, 1) form on tile 129."""
+    N, F, HW, Cin, Cout = 2, 16, 48, 128, 128
+    M = N * F * HW
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(dt)
+    w = (torch.randn(Cout, Cin * 3, device="cuda", generator=g) * (Cin * 3) ** -0.5).to(dt)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    y0 = ops.conv_gemm(x, w, b, taps=ops.TAPS_TEMPORAL, dims=(F, HW, 1), tile=129)
+    y1 = ops.conv_gemm(x, w, b, taps=ops.TAPS_TEMPORAL_D1, dims=(N, F, HW), tile=130)
+    assert rel_l2(y1.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_strided_views(ops, dt):
     """Input, residual and output as column slices of wider buffers (free skip-concat views)."""
