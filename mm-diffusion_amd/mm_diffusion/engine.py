@@ -111,6 +111,13 @@ class UNetEngine:
         self.keep.append(t)
         return t
 
+    def _temporal(self, Hh):
+        """taps / dims of the k=3 conv along frames: (F, HW, 1) with taps (df, 0, 0); the equivalent (N, F, HW) form with taps
+        (0, df, 0) when the halo-tile main loop is a candidate (it wants the taps inside the (D1, D2) plane)."""
+        if ops.HALO_CANDIDATE:
+            return dict(taps=ops.TAPS_TEMPORAL_D1, dims=(self.N, self.F, Hh * Hh))
+        return dict(taps=ops.TAPS_TEMPORAL, dims=(self.F, Hh * Hh, 1))
+
     def _gn(self, x, prefix, geom, act, film=None, out=None):
         """GroupNorm32(+FiLM)(+SiLU): stats -> fused affine -> apply.  Returns the normalised tensor."""
         C = x.shape[1]
@@ -197,8 +204,8 @@ class UNetEngine:
                                    dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
                 self._release(t0)
                 h = ops.conv_gemm(t1, self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight"),
-                                  self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), taps=ops.TAPS_TEMPORAL,
-                                  dims=(F, Hh * Hh, 1), out=self._alloc(rows_in, cout))
+                                  self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), **self._temporal(Hh),
+                                  out=self._alloc(rows_in, cout))
                 self._release(t1)
             else:
                 h = ops.conv_gemm(t0, self._gemm_w(f"{p}.audio_in_layers.2.audio_conv.weight"),
@@ -382,8 +389,8 @@ class UNetEngine:
                                   self._f32(p + ".video_conv.video_conv_spatial.bias"), s1, N, F, self.Cv_in, Hh, Hh,
                                   ops.TAPS_SPATIAL)
                     nv = ops.conv_gemm(s1, self._gemm_w(p + ".video_conv.video_conv_temporal.weight"),
-                                       self._f32(p + ".video_conv.video_conv_temporal.bias"), taps=ops.TAPS_TEMPORAL,
-                                       dims=(F, Hh * Hh, 1), out=tv if tv is not None else self._alloc(N * F * Hh * Hh, C0))
+                                       self._f32(p + ".video_conv.video_conv_temporal.bias"), **self._temporal(Hh),
+                                       out=tv if tv is not None else self._alloc(N * F * Hh * Hh, C0))
                     self._release(s1)
                     ops.cur_sid = 1
                     na = ta if ta is not None else self._alloc(N * L, C0)

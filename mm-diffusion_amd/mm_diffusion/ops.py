@@ -4,6 +4,7 @@ Activations are 2-D torch tensors [rows, C] with stride(1) == 1 and any row stri
 wider buffer is fine); torch is used for device memory and the current stream only - every arithmetic
 op runs in libmmd."""
 import math
+import os
 
 import torch
 
@@ -182,6 +183,18 @@ def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129)):
     return best
 
 
+# tile 130 (halo-tile main loop for 3x3 / temporal-k3 convs) joins the autotune candidates only on request until it has been measured
+HALO_CANDIDATE = os.environ.get("MMD_GEMM_HALO") == "1"
+
+
+def halo_tile_ok(x, taps, dims):
+    """Shapes conv_gemm tile 130 accepts: taps inside the (D1, D2) plane with |offset| <= 1, D1 % 8 == 0, D2 % 16 == 0, full frames,
+    Cin a multiple of one 128-byte K step."""
+    M, Cin = x.shape
+    return (len(taps) > 1 and all(t[0] == 0 and abs(t[1]) <= 1 and abs(t[2]) <= 1 for t in taps) and dims[1] % 8 == 0
+            and dims[2] % 16 == 0 and dims[0] * dims[1] * dims[2] == M and Cin % (128 // x.element_size()) == 0)
+
+
 def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0):
     """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None."""
     _chk2d(x)
@@ -197,12 +210,13 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, nt, arr,
             int(dims[0]), int(dims[1]), int(dims[2]))
     if tile == 0:
-        tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False),
-                          lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout)
+        cands = (64, 128, 129) + ((130,) if HALO_CANDIDATE and halo_tile_ok(x, taps, dims) else ())
+        tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False, tuple(dims) if 130 in cands else None),
+                          lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout, cands)
     flops = 2 * M * Cout * Cin * nt
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
     _dispatch("mmd_conv_gemm", *base, tile,
-           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{'128glds' if tile == 129 else tile}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
+           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{'128glds' if tile == 129 else ('128halo' if tile == 130 else tile)}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
     return out
 
 
