@@ -165,3 +165,17 @@ def test_script_shims_common_and_datasets(tmp_path):
     assert b["video"].shape == (2, 4, 3, 8, 8) and b["audio"].shape == (2, 1, 64) and float(b["video"].min()) == -1.0
     syn = next(load_data(data_dir="synthetic", batch_size=3, video_size=[4, 3, 8, 8], audio_size=[1, 64]))
     assert syn["video"].shape == (3, 4, 3, 8, 8) and float(syn["video"].abs().max()) <= 1.0
+
+
+def test_halo_tile_addressing_model():
+    """numpy model of conv_gemm tile 130's addressing (tools/halo_index_check.py): the DMA lane mapping + chunk swizzle must put
+    every (pixel + tap, channel chunk) where the fragment reads look for it - zero rows on the frame border - with no two lanes of
+    a 16-lane ds_read_b128 group in the same 16-byte bank slot."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("halo_index_check", os.path.join(os.path.dirname(__file__), "..", "tools", "halo_index_check.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.run(2, 16, 32, 128, m.taps, 1, 0, 0)            # top-left patch: halo rows / columns outside the frame
+    assert m.run(2, 16, 32, 64, m.taps, 0, 8, 16)            # bottom-right patch
+    assert m.run(2, 16, 48, 64, [(-1, 0), (0, 0), (1, 0)], 1, 8, 16)   # temporal form: taps along D1 only

@@ -64,6 +64,8 @@ def run(D0, D1, D2, Cin, taps, d0, h0, w0):
                                     slots.add(((r * 128 + phys * 16) // 16) % 16)     # 16-byte slot within the 256-byte bank row
                                 if len(slots) != 16:
                                     print("bank conflict", dh, dw, wr, b, cc, half, grp, len(slots))
+                                    ok_all = False
     return ok_all
 taps = [(dh, dw) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]
-print(run(2, 16, 32, 128, taps, 1, 0, 0), run(2, 16, 32, 128, taps, 0, 8, 16), run(1, 8, 16, 64, taps, 0, 0, 0), run(3, 24, 48, 64, taps, 2, 16, 32))
+if __name__ == "__main__":
+    print(run(2, 16, 32, 128, taps, 1, 0, 0), run(2, 16, 32, 128, taps, 0, 8, 16), run(1, 8, 16, 64, taps, 0, 0, 0), run(3, 24, 48, 64, taps, 2, 16, 32))
