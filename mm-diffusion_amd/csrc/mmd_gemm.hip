@@ -39,6 +39,22 @@ struct ConvGemmParams {
 // s_waitcnt vmcnt(N) (a load under a divergent branch forces vmcnt(0) and serialises the pipeline).
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+#ifdef GEMM_TIMELINE
+// Debug builds (tools/gemm_timeline.py, -DGEMM_TIMELINE): thread 0 of every direct-to-LDS GEMM block stamps s_memrealtime
+// (100 MHz) at block start / first operands landed / main loop done / stores issued, plus its XCC and CU ids.
+__device__ unsigned long long* g_gemm_timeline = nullptr;
+extern "C" int mmd_debug_set_gemm_timeline(void* buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_timeline), &buf, sizeof(buf));
+  return e == hipSuccess ? MMD_OK : mmd_set_error(MMD_ERR_LAUNCH, "set_gemm_timeline: %s", hipGetErrorString(e));
+}
+#define GEMM_TL(slot)                                                                            \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && g_gemm_timeline) g_gemm_timeline[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define GEMM_TL(slot) do { } while (0)
+#endif
+
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
   __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
@@ -311,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
   float* sC = (float*)smem;
   int* s_taps = (int*)(smem + MAIN_B);
 
+  GEMM_TL(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -470,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
   u32x4 rres[NPASS][8 / EPV];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  GEMM_TL(1);
   int cur = 0;
   for (int it = 0; it + 1 < nit; ++it) {
 #ifndef GEMM_ABLATE_NODMA                                   // ablation builds (tools/gemm_bench.py): compute-only / DMA-only loops
@@ -495,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
   }
   compute(cur);
   __syncthreads();                                       // every wave is past its last operand read: sC may alias
+  GEMM_TL(2);
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -535,6 +554,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
       }
     }
   }
+  GEMM_TL(3);
+#ifdef GEMM_TIMELINE
+  if (threadIdx.x == 0 && g_gemm_timeline) {
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    g_gemm_timeline[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
