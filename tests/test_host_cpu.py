@@ -179,3 +179,17 @@ def test_halo_tile_addressing_model():
     assert m.run(2, 16, 32, 128, m.taps, 1, 0, 0)            # top-left patch: halo rows / columns outside the frame
     assert m.run(2, 16, 32, 64, m.taps, 0, 8, 16)            # bottom-right patch
     assert m.run(2, 16, 48, 64, [(-1, 0), (0, 0), (1, 0)], 1, 8, 16)   # temporal form: taps along D1 only
+
+
+def test_halo_tile_block_flow_model():
+    """Sequential model of a tile-130 block (tools/halo_flow_check.py): double-buffered weight stages, the halo of the next
+    channel chunk issued across the taps of the current one, chunk-major K offsets and the patch -> row mapping of the epilogue
+    reproduce a direct convolution (3x3 with several chunks and a ragged Cout, temporal form, 1x1)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("halo_flow_check", os.path.join(os.path.dirname(__file__), "..", "tools", "halo_flow_check.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.check(1, 8, 32, 128, 136, m.sp) < 1e-10
+    assert m.check(1, 16, 16, 64, 64, [(0, -1, 0), (0, 0, 0), (0, 1, 0)]) < 1e-10
+    assert m.check(1, 8, 16, 64, 8, [(0, 0, 0)]) < 1e-10
