@@ -590,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   float* sC = (float*)smem;
   int* s_taps = (int*)(smem + MAIN_B);
 
+  GEMM_TL(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   u32x4 rres[NPASS][8 / EPV];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  GEMM_TL(1);
   int c = 0, t = 0;
   for (int it = 0; it + 1 < nit; ++it) {
     int tn = t + 1, cn = c;
@@ -740,6 +742,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   }
   compute((nit - 1) & 1, c & 1, t);
   __syncthreads();                                           // every wave is past its last operand read: sC may alias
+  GEMM_TL(2);
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -778,6 +781,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
         *(u32x4*)(p.Y + (m * p.ldy + e_co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
     }
   }
+  GEMM_TL(3);
 }
 
 template <typename T>
