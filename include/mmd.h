@@ -37,6 +37,10 @@ int mmd_graph_begin(void* stream);
 int mmd_graph_end(void* stream, void** exec_out);
 int mmd_graph_launch(void* exec, void* stream);
 int mmd_graph_destroy(void* exec);
+/* private launch streams of the host mirror (hipStreamNonBlocking): the video / audio chains and the capture stream */
+int mmd_stream_create(void** stream_out);
+int mmd_stream_sync(void* stream);
+int mmd_stream_destroy(void* stream);
 int mmd_event_create(void** ev);
 int mmd_event_record(void* ev, void* stream);
 int mmd_stream_wait_event(void* stream, void* ev);   /* fork/join of the video and audio launch streams (also under capture) */

@@ -666,7 +666,8 @@ static int launch_mfma(const AttnParams& p, int qmax, hipStream_t st) {
 template <typename T>
 static int launch_generic(const AttnParams& p, int qmax, hipStream_t st) {
   const size_t lds = (size_t)(64 * (p.ch + 1) * 2 + 64 * p.ch + 64 * 65 + 192) * sizeof(float);
-  static bool attr_set = false;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_generic_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_generic: set LDS attr: %s", hipGetErrorString(e));
@@ -738,7 +739,8 @@ extern "C" int mmd_attn_fwd_lse(int dtype, const void* Q, int64_t ldq, int q_off
 template <typename T, int CHQ>
 static int launch_small(const SmallAttnParams& p, hipStream_t st) {
   const size_t lds = (size_t)4 * 2 * 32 * (CHQ * 4) * sizeof(float);
-  static bool attr_set = false;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_small_kernel<T, CHQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_small: set LDS attr: %s", hipGetErrorString(e));

@@ -343,7 +343,8 @@ static int launch_bwd_mfma(const AttnBwdMParams& p, hipStream_t st) {
   const size_t lds_kv = 128 * SK + 2 * DT * 32 * TSTRIDE + 128 * sizeof(float);
   const int qmax = (int)(p.q_rows_per_batch - (int64_t)(p.G - 1) * p.q_per_group);
   if (lds_kv > 64 * 1024) {
-    static bool attr_set = false;
+    static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
     if (!attr_set) {
       if (hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess)
         return mmd_set_error(MMD_ERR_LAUNCH, "attn_bwd_mfma: set LDS attr failed");

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include "../../include/mmd.h"   // the C ABI: every extern "C" definition is checked against its declaration
 
 #define MMD_F32 0
 #define MMD_BF16 1
@@ -103,3 +104,12 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: the launchers remember it per device slot
+// (the only process-lifetime state of the library besides the read-only zero pages; a benign race sets it twice).
+#define MMD_MAX_DEVICES 16
+static inline int mmd_device_slot() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d & (MMD_MAX_DEVICES - 1);
+}

@@ -48,6 +48,25 @@ extern "C" int mmd_graph_destroy(void* exec) {
   return MMD_OK;
 }
 
+// ---- launch streams owned by the host mirror (video / audio chains, capture stream): private non-blocking streams, so the
+// library's fork/join never aliases a stream of the framework's pool
+extern "C" int mmd_stream_create(void** stream_out) {
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "stream_create: %s", hipGetErrorString(e));
+  *stream_out = (void*)s;
+  return MMD_OK;
+}
+extern "C" int mmd_stream_sync(void* stream) {
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "stream_sync: %s", hipGetErrorString(e));
+  return MMD_OK;
+}
+extern "C" int mmd_stream_destroy(void* stream) {
+  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+  return MMD_OK;
+}
+
 // ---- stream-ordered timing on the stream the kernels are launched on (bench.py roofline leg)
 extern "C" int mmd_event_create(void** ev) {
   hipEvent_t e;

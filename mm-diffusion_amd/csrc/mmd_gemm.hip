@@ -793,7 +793,8 @@ static int launch_conv_gemm_halo(const ConvGemmParams& p, hipStream_t st) {
     return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 130 (halo): needs spatial taps (|dh|,|dw| <= 1), D1 %% 8 == 0, D2 %% 16 == 0, "
                          "full frames and Cin a multiple of one 128-byte K step");
   const size_t lds = 2 * (size_t)(23 * 8 * 128) + 2 * (size_t)(128 * 128) + 336;
-  static bool attr_set = false;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_halo: set LDS attr: %s", hipGetErrorString(e));
@@ -807,7 +808,8 @@ static int launch_conv_gemm_halo(const ConvGemmParams& p, hipStream_t st) {
 template <typename T>
 static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds = 128 * 132 * sizeof(float) + 336;
-  static bool attr_set = false;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -825,7 +827,8 @@ static int launch_conv_gemm(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds_ops = 2 * (size_t)(BM + BN) * ROWB;
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   const size_t lds = (lds_ops > lds_c ? lds_ops : lds_c) + 336 + (GN ? 16 * 256 : 0);   // + tap table (+ GN affine cache, Cin <= 256)
-  static bool attr_set = false;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<T, BM, BN, GN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

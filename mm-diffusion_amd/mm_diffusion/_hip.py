@@ -1,6 +1,7 @@
 """ctypes binding of libmmd.so (include/mmd.h).  There is NO fallback: if the library is missing or a
 call fails this raises - the product path never silently computes on the CPU or with stock torch ops."""
 import ctypes as C
+import gc
 import os
 
 import torch
@@ -19,6 +20,9 @@ _PROTOS = {
     "mmd_graph_end": (i32, [vp, C.POINTER(vp)]),
     "mmd_graph_launch": (i32, [vp, vp]),
     "mmd_graph_destroy": (i32, [vp]),
+    "mmd_stream_create": (i32, [C.POINTER(vp)]),
+    "mmd_stream_sync": (i32, [vp]),
+    "mmd_stream_destroy": (i32, [vp]),
     "mmd_event_create": (i32, [C.POINTER(vp)]),
     "mmd_event_record": (i32, [vp, vp]),
     "mmd_stream_wait_event": (i32, [vp, vp]),
@@ -120,3 +124,128 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise MMDError("the MI355X HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")
+
+
+# ----------------------------------------------------------------------------- lifetime of HIP handles
+# Graph execs, events and streams are owned by Python objects (engines, steppers) that sit in reference cycles, so their
+# finalisers run from the cyclic GC at arbitrary points - e.g. in the middle of ANOTHER engine's stream capture, where
+# hipGraphExecDestroy / hipStreamDestroy are illegal.  Rule: close() / __del__ never touch the HIP runtime; they `retire` the
+# handle, and `reap()` destroys retired handles at safe points only (engine construction, before a capture begins).
+_retired = []
+_capturing = 0
+
+
+def retire(kind, handle):
+    """kind: "graph" | "event" | "stream".  Safe from a finaliser (appends to a list, nothing else)."""
+    if isinstance(handle, C.c_void_p):
+        handle = handle.value
+    if handle and _retired is not None:
+        _retired.append((kind, int(handle)))
+
+
+def reap():
+    """Destroy retired handles.  No-op during a capture.  Work enqueued with them is drained first."""
+    if _capturing or not _retired:
+        return 0
+    items = list(_retired)
+    del _retired[:]
+    torch.cuda.synchronize()
+    l = lib()
+    for kind in ("graph", "event", "stream"):          # execs before the events/streams their nodes were recorded with
+        fn = getattr(l, "mmd_%s_destroy" % kind)
+        for k, h in items:
+            if k == kind:
+                fn(h)
+    return len(items)
+
+
+class capture:
+    """`with capture(stream) as c:` records the launches made on `stream` (and the streams forked from it through events) into a
+    hipGraph; c.exec is the instantiated executable.  The cyclic GC is off inside (no finaliser runs mid-capture)."""
+
+    def __init__(self, stream):
+        self.stream, self.exec = stream, None
+
+    def __enter__(self):
+        global _capturing
+        reap()
+        self._gc = gc.isenabled()
+        gc.disable()
+        try:
+            call("mmd_graph_begin", self.stream)
+        except Exception:
+            if self._gc:
+                gc.enable()
+            raise
+        _capturing += 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _capturing
+        ex = C.c_void_p()
+        try:
+            rc = lib().mmd_graph_end(self.stream, C.byref(ex))
+        finally:
+            _capturing -= 1
+            if self._gc:
+                gc.enable()
+        if rc == 0:
+            self.exec = ex
+            if et is not None:
+                retire("graph", ex)
+                self.exec = None
+        elif et is None:
+            raise MMDError(f"mmd_graph_end failed ({rc}): {lib().mmd_last_error().decode()}")
+        return False
+
+
+class Stream:
+    """A private launch stream (hipStreamNonBlocking, created by libmmd - never one of torch's 32 pooled streams, which alias
+    each other once more than 32 have been handed out) with its torch view for wait_stream() / `with torch.cuda.stream()`."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            call("mmd_stream_create", C.byref(h))
+        self.handle = h.value
+        self.torch = torch.cuda.ExternalStream(self.handle, device=device)
+
+    def close(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            retire("stream", h)
+
+    __del__ = close
+
+
+def plan_events(*plans):
+    """The fork/join events a recorded plan owns (ops.record_sync)."""
+    return [args[2] for plan in plans for fn, args, *_ in plan if fn is None]
+
+
+class Staged:
+    """Asynchronous host->device upload of a small per-step buffer through a RING of pinned slots.  The host runs several
+    steps ahead of the GPU (a replayed step is ~15 ms of GPU time against < 1 ms of host time), so ONE pinned buffer refilled
+    every step would be overwritten before the earlier hipMemcpyAsync has read it; a slot is rewritten only after the event
+    recorded behind its last copy has completed (which also bounds the host's lead to `depth` steps)."""
+
+    def __init__(self, dev, depth=8):
+        self.dev = dev
+        self.slots = [torch.empty(dev.shape, dtype=dev.dtype).pin_memory() for _ in range(depth)]
+        self.events = [None] * depth
+        self.k = 0
+
+    def host(self):
+        ev = self.events[self.k]
+        if ev is not None:
+            ev.synchronize()
+        return self.slots[self.k]
+
+    def push(self):
+        k = self.k
+        self.dev.copy_(self.slots[k], non_blocking=True)
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record()
+        self.k = (k + 1) % len(self.slots)

@@ -62,7 +62,10 @@ class UNetEngine:
                 raise H.MMDError(f"parameter {k} is on {v.device}: move the model to the GPU first (model.to('cuda'))")
         self._sig = self._signature()
         self.pools = [_Pool(self.device), _Pool(self.device)]   # one per launch stream (video / audio run concurrently)
-        self.aux = torch.cuda.Stream(device=self.device)          # audio-stream launches
+        H.reap()
+        self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
+        self.aux = self._aux.torch          # audio-chain launches
+        self.side = self._side.torch        # capture stream (graphs of this engine and of the samplers driving it)
         self.keep = []          # packed weights etc. (kept alive)
         self.plan = []
         self.graph = None
@@ -96,20 +99,28 @@ class UNetEngine:
         self.keep.append(t)
         return t
 
-    def _f32(self, key):
-        t = self.params[key].detach().float().contiguous()
+    def _packed(self, kind, key, make):
+        """Packed kernel operands are shared by every engine of the model that was built from the same parameter versions
+        (the batch lanes of a sampler, engines of different batch sizes): one copy in HBM / MALL, not one per engine."""
+        cache = self.model.__dict__.setdefault("_wcache", {})
+        if cache.get("sig") != self._sig:
+            cache.clear()
+            cache["sig"] = self._sig
+        k = (kind, key, self.dtype if kind == "gemm" else None, str(self.device))
+        t = cache.get(k)
+        if t is None:
+            t = cache[k] = make()
         self.keep.append(t)
         return t
+
+    def _f32(self, key):
+        return self._packed("f32", key, lambda: self.params[key].detach().float().contiguous())
 
     def _gemm_w(self, key):
-        t = ops.pack_conv_weight(self.params[key].detach().float(), self.dtype)
-        self.keep.append(t)
-        return t
+        return self._packed("gemm", key, lambda: ops.pack_conv_weight(self.params[key].detach().float(), self.dtype))
 
     def _edge_w(self, key):
-        t = ops.pack_edge_weight(self.params[key].detach())
-        self.keep.append(t)
-        return t
+        return self._packed("edge", key, lambda: ops.pack_edge_weight(self.params[key].detach()))
 
     def _temporal(self, Hh):
         """taps / dims of the k=3 conv along frames: (F, HW, 1) with taps (df, 0, 0); the equivalent (N, F, HW) form with taps
@@ -326,7 +337,7 @@ class UNetEngine:
                     off += W.shape[0]
         self.nshift = nshift
         self.shift_dev = self._static((max(nshift, 1),), torch.int32)
-        self.shift_host = torch.zeros(max(nshift, 1), dtype=torch.int32).pin_memory()
+        self._shift_up = H.Staged(self.shift_dev)
         self.emb_W = torch.cat(Ws).contiguous()
         self.emb_b = torch.cat(bs).contiguous()
         self.emb_silu = self._static((N, self.mc), torch.float32)
@@ -470,9 +481,10 @@ class UNetEngine:
         if self.nshift:
             if len(shifts) != self.nshift:
                 raise H.MMDError(f"expected {self.nshift} window shifts, got {len(shifts)}")
+            host = self._shift_up.host()
             for i, s in enumerate(shifts):
-                self.shift_host[i] = int(s)
-            self.shift_dev.copy_(self.shift_host, non_blocking=True)
+                host[i] = int(s)
+            self._shift_up.push()
 
     def join_plan(self):
         """Plan tail: the main stream waits for the audio stream (everything after it sees both outputs)."""
@@ -494,23 +506,17 @@ class UNetEngine:
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         if use_f32 not in self._graphs:
-            import ctypes
             if not hasattr(self, "_join"):
                 self._join = self.join_plan()
             plan = (self.plan_f32 if use_f32 else self.plan) + self._join
-            side = torch.cuda.Stream(device=self.device)
+            side = self.side
             side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                ops.run_plan(plan, side.cuda_stream, self.aux.cuda_stream)      # warm-up: one-time function attributes
-                side.synchronize()
-                H.call("mmd_graph_begin", side.cuda_stream)
-                try:
-                    ops.run_plan(plan, side.cuda_stream, self.aux.cuda_stream)
-                finally:
-                    ex = ctypes.c_void_p()
-                    H.call("mmd_graph_end", side.cuda_stream, ctypes.byref(ex))
+            ops.run_plan(plan, side.cuda_stream, self.aux.cuda_stream)      # warm-up: one-time function attributes
+            torch.cuda.synchronize(self.device)
+            with H.capture(side.cuda_stream) as cap:
+                ops.run_plan(plan, side.cuda_stream, self.aux.cuda_stream)
             torch.cuda.current_stream(self.device).wait_stream(side)
-            self._graphs[use_f32] = ex
+            self._graphs[use_f32] = cap.exec
         return self._graphs[use_f32]
 
     def forward(self, video, audio, timesteps, shifts, use_graph=True):
@@ -521,9 +527,25 @@ class UNetEngine:
             self.run(use_f32)
         return self.out_video.clone(), self.out_audio.clone()
 
-    def __del__(self):
+    def close(self):
+        """Give up the HIP handles of this engine (graph execs, fork/join events, the two private streams).  Nothing is destroyed
+        here - a finaliser may run in the middle of another engine's capture - the handles are retired and H.reap() frees them
+        at the next safe point."""
         try:
-            for g in getattr(self, "_graphs", {}).values():
-                H.lib().mmd_graph_destroy(g)
+            graphs, self._graphs = getattr(self, "_graphs", {}), {}
+            for g in graphs.values():
+                H.retire("graph", g)
+            plans = [p for p in (getattr(self, "plan", None), getattr(self, "plan_f32", None), getattr(self, "_join", None)) if p]
+            seen = set()
+            for ev in H.plan_events(*plans):
+                if ev.value not in seen:
+                    seen.add(ev.value)
+                    H.retire("event", ev)
+            self.plan, self.plan_f32, self._join = [], [], []
+            for s in (getattr(self, "_aux", None), getattr(self, "_side", None)):
+                if s is not None:
+                    s.close()
         except Exception:
             pass
+
+    __del__ = close

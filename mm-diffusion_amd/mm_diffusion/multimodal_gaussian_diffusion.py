@@ -325,9 +325,12 @@ class GaussianDiffusion:
         if use_graph and unet is not None and not (model_kwargs or {}):
             stepper = GraphStepper(self, unet, shape["video"][0], device, clip_denoised, update="ddim", eta=eta)
             stepper.load(x["video"], x["audio"])
-            for i in indices:
-                stepper.step(i)
-                yield stepper.current()
+            try:
+                for i in indices:
+                    stepper.step(i)
+                    yield stepper.current()
+            finally:
+                stepper.close()
             return
         for i in indices:
             t = th.tensor([i] * shape["video"][0], device=device)
@@ -392,7 +395,7 @@ class GaussianDiffusion:
                 if k in cond:
                     x[k] = self.q_sample(cond[k], t, noise=noise[k])
                     if stepper is not None:
-                        (stepper.eng.x_video if k == "video" else stepper.eng.x_audio).copy_(x[k])
+                        stepper.set_x(k, x[k])
             if stepper is not None:
                 stepper.step(i)
                 x = stepper.current()
@@ -474,9 +477,12 @@ class GaussianDiffusion:
         if use_graph and unet is not None and not (model_kwargs or {}):
             stepper = GraphStepper(self, unet, shape["video"][0], device, clip_denoised)
             stepper.load(x["video"], x["audio"])
-            for i in indices:
-                stepper.step(i)
-                yield stepper.current()
+            try:
+                for i in indices:
+                    stepper.step(i)
+                    yield stepper.current()
+            finally:
+                stepper.close()
             return
         for i in indices:
             t = th.tensor([i] * shape["video"][0], device=device)

@@ -295,9 +295,11 @@ class MultimodalUNet(nn.Module):
                     out.append(int(src(0, F - layer["window"])))
         return out
 
-    def engine(self, batch, device):
+    def engine(self, batch, device, replica=0):
+        """The launch plan for `batch` samples (built on first use).  `replica` > 0 = a further, independent engine of the same
+        batch size (own activation buffers and streams, shared packed weights): the batch lanes of sampler.GraphStepper."""
         from .engine import UNetEngine
-        key = (int(batch), self.dtype, str(device))
+        key = (int(batch), self.dtype, str(device)) + ((int(replica),) if replica else ())
         eng = self._engines.get(key)
         if eng is None or eng.stale():
             eng = UNetEngine(self, int(batch), self.dtype, device)

@@ -153,22 +153,42 @@ AUTOTUNE = True
 _tile_cache = {}
 
 
-def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129)):
+def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129), out=None, scratch=()):
     """launch(tile) enqueues the GEMM on the current stream.  Returns the fastest of `candidates`
-    (64 / 128 = register-staged tiles, 129 = 128x128 direct-to-LDS main loop)."""
+    (64 / 128 = register-staged tiles, 129 = 128x128 direct-to-LDS main loop).
+
+    A candidate is only eligible after its output on the real buffers agrees with the first candidate's (tile 64, the reference
+    variant): bitwise for 64 / 128 / 129 (same K order, same epilogue), within rounding for tile 130 (chunk-major K order).  A
+    variant that disagrees is a kernel bug and raises - timing alone never admits a kernel into a captured graph.  `scratch` =
+    the input buffers (plan-time garbage) that are filled with N(0,1) first so the comparison sees finite, representative data."""
     default = (129 if 129 in candidates else 128) if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
     if not AUTOTUNE or _recorder is None:
         return default
     if key in _tile_cache:
         return _tile_cache[key]
     import ctypes
-    best, best_ms = default, None
+    verify = out is not None and not any(t is not None and t.untyped_storage().data_ptr() == out.untyped_storage().data_ptr() for t in scratch)
+    if verify:
+        for t in scratch:
+            if t is not None:
+                t.normal_()
+    best, best_ms, ref = default, None, None
     ev = [ctypes.c_void_p(), ctypes.c_void_p()]
     for e in ev:
         H.call("mmd_event_create", ctypes.byref(e))
     st = H.stream_handle()
     for tile in candidates:
         launch(tile)                      # warm (function attributes, caches)
+        if verify:
+            if ref is None:
+                ref = out.clone()
+            elif tile == 130:
+                err = float((out.float() - ref.float()).norm() / ref.float().norm().clamp_min(1e-30))
+                if not err < (1e-2 if out.element_size() == 2 else 1e-5):
+                    raise H.MMDError(f"conv_gemm tile 130 disagrees with tile {candidates[0]} on {key}: rel-L2 {err:.3e}")
+            elif not torch.equal(out.view(torch.int16 if out.element_size() == 2 else torch.int32),
+                                 ref.view(torch.int16 if ref.element_size() == 2 else torch.int32)):
+                raise H.MMDError(f"GEMM tile {tile} is not bitwise equal to tile {candidates[0]} on {key}")
         H.call("mmd_event_record", ev[0], st)
         for _ in range(3):
             launch(tile)
@@ -212,7 +232,7 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     if tile == 0:
         cands = (64, 128, 129) + ((130,) if HALO_CANDIDATE and halo_tile_ok(x, taps, dims) else ())
         tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False, tuple(dims) if 130 in cands else None),
-                          lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout, cands)
+                          lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout, cands, out=out, scratch=(x, residual))
     flops = 2 * M * Cout * Cin * nt
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
     _dispatch("mmd_conv_gemm", *base, tile,
@@ -243,7 +263,8 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
     if tile == 0:
         tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
-                          lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout, candidates=(64, 128))
+                          lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout, candidates=(64, 128), out=out,
+                          scratch=(x, residual, a, b))
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
     _dispatch("mmd_gn_conv1x1", *base, tile,
               meta=(f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes))

@@ -113,9 +113,10 @@ class FlatAdamW:
         self.fold_grads()             # no-op when all_reduce_grads already folded (the accumulators are cleared by the fold)
         self.steps += 1
         # autograd accumulates into p.grad in place, so self.grad already holds the flat gradient
+        lo, hi = self.grad.data_ptr(), self.grad.data_ptr() + self.grad.numel() * 4
         for p in self.params:
-            if p.grad is not None and p.grad.data_ptr() < self.grad.data_ptr() or p.grad.data_ptr() >= self.grad.data_ptr() + self.grad.numel() * 4:
-                raise RuntimeError("a parameter's .grad was replaced; FlatAdamW needs in-place gradient accumulation")
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                raise RuntimeError("a parameter's .grad was replaced or dropped; FlatAdamW needs in-place gradient accumulation")
         ema0 = self.ema_params[0] if self.ema_params else None
         ops.adamw_step(self.flat, self.grad, self.m, self.v, ema0, self.lr, self.betas[0], self.betas[1], self.eps,
                        self.weight_decay, self.steps, ema_rate=self.ema_rates[0] if self.ema_rates else 0.0)

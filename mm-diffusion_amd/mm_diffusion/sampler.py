@@ -4,6 +4,8 @@ timestep (loop index + model timestep), the window shifts and the noise.
 
 Replaces the per-step host work of the reference loop (gd:561-582 + resp:134-139): th.tensor([i]*B) H2D,
 the timestep_map tensor rebuild, ~16 table uploads and ~55k ATen dispatches."""
+import os
+
 import torch as th
 
 from . import _hip as H
@@ -22,17 +24,37 @@ def unwrap_unet(model):
     return None
 
 
+def default_lanes(batch):
+    """Batch lanes of a sampling step (see GraphStepper): MMD_LANES overrides; otherwise 2 when the batch splits evenly."""
+    v = os.environ.get("MMD_LANES")
+    lanes = int(v) if v else (2 if batch >= 4 and batch % 2 == 0 else 1)
+    return lanes if lanes >= 1 and batch % lanes == 0 else 1
+
+
 class GraphStepper:
-    def __init__(self, diffusion, unet, batch, device, clip_denoised=True, use_graph=True, update="ddpm", eta=0.0):
+    """One denoising step of `batch` trajectories as one graph replay.
+
+    lanes > 1 splits the batch into independent sub-batches, each with its own engine (activation buffers, video + audio launch
+    streams; packed weights are shared) and all captured into the SAME graph as parallel branches.  Every sample's trajectory is
+    independent (GroupNorm / attention never mix batch elements, tests: batch sharding is bitwise exact), so the result is
+    identical; what changes is that the many latency-bound launches of the low-resolution levels (ds4 / ds8 GEMMs, GroupNorm
+    statistics: most of the ~1100 launches of a step) of one lane run beside the other lane's work instead of leaving most of the
+    256 CUs idle.  Noise and timestep buffers stay full-batch (lanes read slices), so the RNG stream does not depend on `lanes`."""
+
+    def __init__(self, diffusion, unet, batch, device, clip_denoised=True, use_graph=True, update="ddpm", eta=0.0, lanes=None):
         self.diff, self.unet, self.N = diffusion, unet, int(batch)
         self.device = th.device(device)
-        self.eng = unet.engine(self.N, self.device)
-        e = self.eng
+        self.lanes = default_lanes(self.N) if lanes is None else int(lanes)
+        if self.N % self.lanes:
+            raise H.MMDError(f"batch {self.N} does not split into {self.lanes} lanes")
+        n = self.n = self.N // self.lanes
+        self.engs = [unet.engine(n, self.device, replica=r) for r in range(self.lanes)]
+        self.eng = e = self.engs[0]
         self.tab, _ = diffusion.device_tables(self.device)
         self.flags = diffusion._flags(clip_denoised)
         self.t_idx = th.zeros(self.N, dtype=th.int64, device=self.device)      # loop index (table row)
-        self.noise_v = th.zeros_like(e.x_video)
-        self.noise_a = th.zeros_like(e.x_audio)
+        self.noise_v = th.zeros((self.N,) + tuple(e.x_video.shape[1:]), dtype=th.float32, device=self.device)
+        self.noise_a = th.zeros((self.N,) + tuple(e.x_audio.shape[1:]), dtype=th.float32, device=self.device)
         # model timestep: SpacedDiffusion maps the loop index to the original step (resp:134-139)
         tmap = getattr(diffusion, "timestep_map", None)
         self.tmap = list(tmap) if tmap is not None else list(range(diffusion.num_timesteps))
@@ -40,66 +62,95 @@ class GraphStepper:
         self.orig_T = getattr(diffusion, "original_num_steps", diffusion.num_timesteps)
         self.use_f32 = self.rescale
         F, C, HW = e.F, e.Cv_in, e.H0 * e.W0
-        self.update_plan = []
-        with ops.recording(self.update_plan):
-            # in place: x_{t-1} overwrites x_t (purely elementwise); each update rides its own stream, then join
-            ops.cur_sid = 0
-            if update == "ddim":       # ddim_sample (gd:821-901): same graph, different fused update
-                tab3 = diffusion.ddim_tables(self.device)
-                ops.ddim_update(e.x_video, e.out_video, self.noise_v, e.x_video, self.tab, tab3, self.t_idx, F, C, HW, self.flags, eta)
-                ops.cur_sid = 1
-                ops.ddim_update(e.x_audio, e.out_audio, self.noise_a, e.x_audio, self.tab, tab3, self.t_idx, 1, e.Ca_in, e.L0, self.flags, eta)
-            else:
-                ops.ddpm_update(e.x_video, e.out_video, self.noise_v, e.x_video, self.tab, self.t_idx, F, C, HW, self.flags)
-                ops.cur_sid = 1
-                ops.ddpm_update(e.x_audio, e.out_audio, self.noise_a, e.x_audio, self.tab, self.t_idx, 1, e.Ca_in, e.L0, self.flags)
-            ops.cur_sid = 0
-            ops.record_sync(1, 0)
+        self.update_plans = []
+        for r, e in enumerate(self.engs):
+            sl = slice(r * n, (r + 1) * n)
+            t_idx, nv, na = self.t_idx[sl], self.noise_v[sl], self.noise_a[sl]
+            plan = []
+            with ops.recording(plan):
+                # in place: x_{t-1} overwrites x_t (purely elementwise); each update rides its own stream, then join
+                ops.cur_sid = 0
+                if update == "ddim":       # ddim_sample (gd:821-901): same graph, different fused update
+                    tab3 = diffusion.ddim_tables(self.device)
+                    ops.ddim_update(e.x_video, e.out_video, nv, e.x_video, self.tab, tab3, t_idx, F, C, HW, self.flags, eta)
+                    ops.cur_sid = 1
+                    ops.ddim_update(e.x_audio, e.out_audio, na, e.x_audio, self.tab, tab3, t_idx, 1, e.Ca_in, e.L0, self.flags, eta)
+                else:
+                    ops.ddpm_update(e.x_video, e.out_video, nv, e.x_video, self.tab, t_idx, F, C, HW, self.flags)
+                    ops.cur_sid = 1
+                    ops.ddpm_update(e.x_audio, e.out_audio, na, e.x_audio, self.tab, t_idx, 1, e.Ca_in, e.L0, self.flags)
+                ops.cur_sid = 0
+                ops.record_sync(1, 0)
+            self.update_plans.append(plan)
+        self.update_plan = self.update_plans[0]
         self.graph = None
         self.use_graph = use_graph
-        self._host_t = th.zeros(self.N, dtype=th.int64).pin_memory()
-        self._host_tm = (th.zeros(self.N, dtype=th.float32) if self.use_f32 else th.zeros(self.N, dtype=th.int64)).pin_memory()
+        # per-step scalars go up through pinned rings (H.Staged): the host runs ahead of the GPU, one reused pinned buffer would race
+        self._up_t = H.Staged(self.t_idx)
+        self._up_tm = [H.Staged(e.t_f32 if self.use_f32 else e.t_i64) for e in self.engs]
+        # lane fork / join events (lane 0 rides the origin stream, lane r > 0 its engine's private `side` stream)
+        import ctypes
+        self._lane_ev = []
+        for _ in range(self.lanes if self.lanes > 1 else 0):
+            ev = ctypes.c_void_p()
+            H.call("mmd_event_create", ctypes.byref(ev))
+            self._lane_ev.append(ev)
 
     def load(self, video, audio):
-        self.eng.x_video.copy_(video)
-        self.eng.x_audio.copy_(audio)
+        n = self.n
+        for r, e in enumerate(self.engs):
+            e.x_video.copy_(video[r * n:(r + 1) * n])
+            e.x_audio.copy_(audio[r * n:(r + 1) * n])
+
+    def set_x(self, key, value):
+        """Overwrite one stream of the current state (replacement-method conditional sampling)."""
+        n = self.n
+        for r, e in enumerate(self.engs):
+            (e.x_video if key == "video" else e.x_audio).copy_(value[r * n:(r + 1) * n])
 
     def current(self):
-        return {"video": self.eng.x_video.clone(), "audio": self.eng.x_audio.clone()}
+        if self.lanes == 1:
+            return {"video": self.eng.x_video.clone(), "audio": self.eng.x_audio.clone()}
+        return {"video": th.cat([e.x_video for e in self.engs]), "audio": th.cat([e.x_audio for e in self.engs])}
 
     def _launch_all(self, stream):
-        aux = self.eng.aux.cuda_stream
-        ops.run_plan(self.eng.plan_f32 if self.use_f32 else self.eng.plan, stream, aux)
-        ops.run_plan(self.update_plan, stream, aux)
+        lib = H.lib()
+        if self.lanes > 1:
+            lib.mmd_event_record(self._lane_ev[0], stream)                    # fork point: before any lane's first launch
+        for r, e in enumerate(self.engs):
+            vs = stream if r == 0 else e.side.cuda_stream
+            if r:
+                lib.mmd_stream_wait_event(vs, self._lane_ev[0])
+            aux = e.aux.cuda_stream
+            ops.run_plan(e.plan_f32 if self.use_f32 else e.plan, vs, aux)
+            ops.run_plan(self.update_plans[r], vs, aux)
+            if r:
+                lib.mmd_event_record(self._lane_ev[r], vs)
+        for r in range(1, self.lanes):
+            if lib.mmd_stream_wait_event(stream, self._lane_ev[r]):
+                raise H.MMDError(f"lane join failed: {lib.mmd_last_error().decode()}")
 
     def _capture(self):
-        side = th.cuda.Stream(device=self.device)
+        side = self.eng.side                            # lane 0's private capture stream
         side.wait_stream(th.cuda.current_stream(self.device))
-        with th.cuda.stream(side):
-            self._launch_all(side.cuda_stream)          # warm-up: one-time function attributes, lazy module load
-            side.synchronize()
-            H.call("mmd_graph_begin", side.cuda_stream)
-            try:
-                self._launch_all(side.cuda_stream)
-            finally:
-                import ctypes
-                ex = ctypes.c_void_p()
-                H.call("mmd_graph_end", side.cuda_stream, ctypes.byref(ex))
-            self.graph = ex
+        self._launch_all(side.cuda_stream)              # warm-up: one-time function attributes, lazy module load
+        th.cuda.synchronize(self.device)
+        with H.capture(side.cuda_stream) as cap:
+            self._launch_all(side.cuda_stream)
+        self.graph = cap.exec
         th.cuda.current_stream(self.device).wait_stream(side)
 
     def set_step(self, i, shifts=None, noise=None):
         """Refresh the per-step device state: timestep, shifts, noise (video first, then audio - gd:453-454)."""
-        self._host_t.fill_(int(i))
-        self.t_idx.copy_(self._host_t, non_blocking=True)
+        self._up_t.host().fill_(int(i))
+        self._up_t.push()
         tm = self.tmap[int(i)]
-        if self.use_f32:
-            self._host_tm.fill_(float(tm) * (1000.0 / self.orig_T))
-            self.eng.t_f32.copy_(self._host_tm, non_blocking=True)
-        else:
-            self._host_tm.fill_(int(tm))
-            self.eng.t_i64.copy_(self._host_tm, non_blocking=True)
-        self.eng.set_shifts(self.unet.draw_shifts() if shifts is None else shifts)
+        for up in self._up_tm:
+            up.host().fill_(float(tm) * (1000.0 / self.orig_T) if self.use_f32 else int(tm))
+            up.push()
+        shifts = self.unet.draw_shifts() if shifts is None else shifts      # one draw per block for the whole batch (unet:619-620)
+        for e in self.engs:
+            e.set_shifts(shifts)
         if noise is not None:
             self.noise_v.copy_(noise["video"])
             self.noise_a.copy_(noise["audio"])
@@ -114,22 +165,32 @@ class GraphStepper:
         if self.use_graph:
             if self.graph is None:
                 # capture replays the step once as warm-up: keep x intact around it
-                xv, xa = self.eng.x_video.clone(), self.eng.x_audio.clone()
+                keep = [(e.x_video.clone(), e.x_audio.clone()) for e in self.engs]
                 self._capture()
-                self.eng.x_video.copy_(xv)
-                self.eng.x_audio.copy_(xa)
+                for e, (xv, xa) in zip(self.engs, keep):
+                    e.x_video.copy_(xv)
+                    e.x_audio.copy_(xa)
             H.call("mmd_graph_launch", self.graph, H.stream_handle())
         else:
-            self.eng.aux.wait_stream(th.cuda.current_stream(self.device))
+            for e in self.engs:
+                e.aux.wait_stream(th.cuda.current_stream(self.device))
             self._launch_all(H.stream_handle())
 
     def step(self, i, shifts=None, noise=None):
         self.set_step(i, shifts, noise)
         self.launch()
 
-    def __del__(self):
+    def close(self):
+        """Retire the graph exec and the update plan's join event (destroyed by H.reap() at the next safe point, never here: this
+        also runs as a finaliser from the cyclic GC)."""
         try:
-            if self.graph is not None:
-                H.lib().mmd_graph_destroy(self.graph)
+            g, self.graph = getattr(self, "graph", None), None
+            if g is not None:
+                H.retire("graph", g)
+            for ev in H.plan_events(*(getattr(self, "update_plans", None) or [])) + list(getattr(self, "_lane_ev", [])):
+                H.retire("event", ev)
+            self.update_plans, self.update_plan, self._lane_ev = [], [], []
         except Exception:
             pass
+
+    __del__ = close

@@ -13,6 +13,8 @@ import random
 
 import torch as th
 
+from . import _hip as H
+
 
 class ShiftSlots:
     """Stands in for `random.randint` as `model.shift_source`: hands out 1-element views of a persistent device table in call
@@ -20,7 +22,7 @@ class ShiftSlots:
 
     def __init__(self, device, capacity=256):
         self.table = th.zeros(capacity, dtype=th.int32, device=device)
-        self.host = th.zeros(capacity, dtype=th.int32).pin_memory()
+        self._up = H.Staged(self.table)        # pinned ring: the host runs ahead of the replayed steps
         self.ranges = []
         self.idx = 0
         self.frozen = False              # True while capturing / replaying: the slot sequence must repeat exactly
@@ -43,10 +45,10 @@ class ShiftSlots:
 
     def randomize(self):
         """Fresh draws for every slot (same `random.randint(lo, hi)` calls, same order as an eager step would make)."""
+        host = self._up.host()
         for i, (lo, hi) in enumerate(self.ranges):
-            self.host[i] = random.randint(lo, hi)
-        n = len(self.ranges)
-        self.table[:n].copy_(self.host[:n], non_blocking=True)
+            host[i] = random.randint(lo, hi)
+        self._up.push()
 
 
 class GraphedTrainStep:
