@@ -31,6 +31,9 @@ extern "C" {
 
 int mmd_version(void);
 const char* mmd_last_error(void);
+/* test-suite aid: print the native backtrace of a fatal signal (SIGSEGV / SIGBUS / SIGABRT) to stderr, then chain to the handler
+ * installed before (Python's faulthandler).  Never called by the product path. */
+int mmd_debug_install_crash_handler(void);
 
 /* --- HIP graph capture of one denoising step + stream-ordered timing (bench roofline leg) --- */
 int mmd_graph_begin(void* stream);

@@ -298,6 +298,251 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
   }
 }
 
+// ============================================================================= staged-window MFMA attention (bf16)
+// For the long windows of the ds-2 level (spatial self-attention 1024 x 1024, RS cross-attention 1024 x 400 / 400 x 1024: ~80 % of
+// the attention FLOPs of a step).  attn_mfma_kernel above re-stages K/V for every 128 queries, pays two barriers per 64 keys with
+// one tile in flight, and issues every fragment read right in front of the MFMA that consumes it (the LDS latency of all 16 reads
+// of a sub-tile is exposed): ~15-20 % of the MFMA peak.  Here:
+//   * a block is 8 waves x one 32-query tile = 256 queries; keys go through LDS in stages of ATS_KEYS = 256 keys (K row-major with
+//     padded rows, V transposed and key-permuted so a P.V fragment is ONE ds_read_b128); the NEXT stage's rows are fetched into
+//     registers while this stage is consumed (issue early / write late): two barriers per 256 keys instead of two per 64;
+//   * inside a stage a wave walks four 64-key sub-tiles with no barrier, in three clean phases per sub-tile: 8 back-to-back
+//     S^T = K Q^T MFMAs on fragments that were read a phase earlier; the online softmax (pure VALU) under which the V fragments of
+//     this sub-tile and the K fragments of the next one are fetched; 8 back-to-back O^T += V^T P^T MFMAs.  With two waves per SIMD
+//     one wave's MFMA phase runs under the other's softmax phase.
+//   * the running (m, l, O^T) stay in registers across stages; lane owns a query, P never leaves the registers.
+#define ATS_KEYS 256
+#define ATS_VT_STRIDE (ATS_KEYS * 2 + 16)   // bytes per V^T row ((stride/16) odd -> conflict-free ds_read_b128)
+
+// position of key j inside its 16-key group of a V^T row: the 4-key quads are stored in the order 0, 2, 1, 3, so the eight keys
+// {0-3, 8-11} + 4 half that a lane feeds to one MFMA (k-slot e <-> S^T register 8 st + e) are 16 contiguous bytes
+__device__ __forceinline__ int ats_vt_col(int j) {
+  const int q = (j >> 2) & 3;
+  return (j & ~12) | ((((q & 1) << 1) | (q >> 1)) << 2);
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) {
+  constexpr int DV = D / 8;
+  constexpr int SK = D * 2 + 16;
+  constexpr int KST = D / 16;
+  constexpr int DT = D / 32;
+  constexpr int NK = (ATS_KEYS * DV + 511) / 512;
+  static_assert(D % 32 == 0, "staged attention: head width must be a multiple of 32");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                         // [ATS_KEYS][SK]
+  char* sVt = smem + ATS_KEYS * SK;        // [D][ATS_VT_STRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  int qc, h, bg;
+  attn_block_coords(qc, h, bg);
+  const GroupInfo gi = group_info(p, bg);
+  const int q0 = qc * 256;
+  if (q0 >= gi.q_count) return;            // uniform per block
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l31, half) holds d = 16 s + 8 half + [0, 8)
+  const int tq = q0 + wave * 32;
+  const bool live = tq < gi.q_count;       // wave-uniform: a dead wave only helps staging
+  const int qi = tq + l31;
+  u32x4 qf[KST];
+  {
+    const char* qp = p.Q + ((gi.q_row0 + qi) * p.ldq + p.q_off + h * D) * 2;
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qi < gi.q_count) v = *(const u32x4*)(qp + (s * 16 + half * 8) * 2);
+      qf[s] = v;
+    }
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
+
+  u32x4 rk[NK], rv[NK];
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const int id = tid + 512 * i;
+      {   // K: row-major, DV lanes per key row (coalesced)
+        const int j = id / DV, v = id % DV;
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (id < ATS_KEYS * DV && k0 + j < gi.k_count)
+          x = *(const u32x4*)(p.KV + (key_row(gi, k0 + j) * p.ldkv + p.k_off + h * D + v * 8) * 2);
+        rk[i] = x;
+      }
+      {   // V: per 64-key block, 32 keys x 2 d-vecs per wave instruction (transposed 2-byte writes)
+        const int kb = id / (64 * DV), idl = id % (64 * DV);
+        const int j = kb * 64 + (idl & 31) + 32 * ((idl >> 6) & 1);
+        const int v = 2 * (idl >> 7) + ((idl >> 5) & 1);
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (id < ATS_KEYS * DV && k0 + j < gi.k_count)
+          x = *(const u32x4*)(p.KV + (key_row(gi, k0 + j) * p.ldkv + p.v_off + h * D + v * 8) * 2);
+        rv[i] = x;
+      }
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const int id = tid + 512 * i;
+      if (id < ATS_KEYS * DV) {
+        {
+          const int j = id / DV, v = id % DV;
+          *(u32x4*)(sK + j * SK + v * 16) = rk[i];
+        }
+        {
+          const int kb = id / (64 * DV), idl = id % (64 * DV);
+          const int j = kb * 64 + (idl & 31) + 32 * ((idl >> 6) & 1);
+          const int v = 2 * (idl >> 7) + ((idl >> 5) & 1);
+          uint16_t* dst = (uint16_t*)(sVt + (8 * v) * ATS_VT_STRIDE + 2 * ats_vt_col(j));
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            dst[e * (ATS_VT_STRIDE / 2)] = (uint16_t)((rv[i][e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        }
+      }
+    }
+  };
+
+  // fragment addresses: K rows (sub*64 + kt*32 + l31), 16-byte chunk (half + 2 st); V^T rows (dt*32 + l31), keys of k-slot group
+  // (kt, st) of this half = 16 contiguous bytes at column (sub*64 + 32 kt + 16 st) + 8 half
+  const char* kbase = sK + l31 * SK + half * 16;
+  const char* vbase = sVt + l31 * ATS_VT_STRIDE + half * 16;
+  u32x4 kf[2 * KST];
+  auto read_k = [&](int sub) {
+#pragma unroll
+    for (int st = 0; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) kf[st * 2 + kt] = *(const u32x4*)(kbase + (sub * 64 + kt * 32) * SK + st * 32);
+  };
+
+  auto sub_tile = [&](int k0, int sub, bool more, auto ragged) {
+    // ---- phase 1: S^T = K Q^T, two independent accumulator chains, fragments already in registers
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[st * 2 + kt]), __builtin_bit_cast(bf16x8, qf[st]), s[kt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- fetch under the softmax: V fragments of this sub-tile, K fragments of the next one
+    u32x4 vf[4][DT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) vf[g][dt] = *(const u32x4*)(vbase + dt * 32 * ATS_VT_STRIDE + (sub * 64 + 16 * g) * 2);
+    if (more) read_k(sub + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: online softmax (lane-local row; partner lane^32 holds the other 32 keys)
+    if constexpr (decltype(ragged)::value) {
+      const int kb = k0 + sub * 64 + 4 * half;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = kb + 32 * kt + (r & 3) + 8 * (r >> 2);
+          s[kt][r] = kk < gi.k_count ? s[kt][r] : -3e38f;
+        }
+    }
+    float mx = -3e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#if defined(ATS_ABLATE) && ATS_ABLATE == 4      // no exp
+        const float e = __builtin_fmaf(s[kt][r], sc, -m_new);
+#else
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
+#endif
+        s[kt][r] = e;
+        ps += e;
+      }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    if (__any(m_new != m_run)) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    m_run = m_new;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[g][e] = (__bf16)s[g >> 1][8 * (g & 1) + e];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: O^T += V^T P^T (k-slot group g = 2 kt + st)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[g][dt]), pf[g], o[dt], 0, 0, 0);
+  };
+
+  load_stage(0);
+  for (int k0 = 0; k0 < gi.k_count; k0 += ATS_KEYS) {
+    __syncthreads();                       // the previous stage is fully consumed
+#if defined(ATS_ABLATE) && ATS_ABLATE == 3      // stage only the first 256 keys: no staging cost in the loop
+    if (k0 == 0)
+#endif
+    store_stage();
+    __syncthreads();
+#if defined(ATS_ABLATE) && ATS_ABLATE == 3
+    if (gi.k_count < 0)
+#endif
+    if (k0 + ATS_KEYS < gi.k_count) load_stage(k0 + ATS_KEYS);    // in flight during this stage's MFMAs
+#if defined(ATS_ABLATE) && ATS_ABLATE == 2      // no compute: prologue + staging + epilogue only
+    if (live && gi.k_count < 0) {
+#else
+    if (live) {
+#endif
+      const int kn = min(gi.k_count - k0, ATS_KEYS);
+      const int nfull = kn >> 6, nsub = (kn + 63) >> 6;
+      read_k(0);
+      for (int sub = 0; sub < nfull; ++sub) sub_tile(k0, sub, sub + 1 < nsub, std::false_type{});
+      if (nfull < nsub) sub_tile(k0, nfull, false, std::true_type{});
+    }
+  }
+
+  // ---- normalise and store: lane owns query qi, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half
+#if defined(ATS_ABLATE) && ATS_ABLATE == 1      // no output stores (one lane keeps the results alive)
+  if (qi < gi.q_count && l_run == -123.f) {
+#else
+  if (qi < gi.q_count) {
+#endif
+    const float inv = 1.f / l_run;
+    if (p.lse2 && half == 0) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);
+    char* op = p.O + ((gi.q_row0 + qi) * p.ldo + h * D) * 2;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * half;
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[dt][4 * q4 + e] * inv);
+        *(bf16x4*)(op + d * 2) = w;
+      }
+  }
+}
+
 // ============================================================================= generic VALU flash attention
 template <typename T>
 __global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
@@ -663,6 +908,21 @@ static int launch_mfma(const AttnParams& p, int qmax, hipStream_t st) {
   return mmd_check_launch("attn_mfma");
 }
 
+template <int D>
+static int launch_stage(const AttnParams& p, int qmax, hipStream_t st) {
+  const size_t lds = (size_t)ATS_KEYS * (D * 2 + 16) + (size_t)D * ATS_VT_STRIDE;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_stage_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_stage: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(qmax, 256), p.heads, p.nb * p.G);
+  hipLaunchKernelGGL((attn_stage_kernel<D>), grid, dim3(512), lds, st, p);
+  return mmd_check_launch("attn_stage");
+}
+
 template <typename T>
 static int launch_generic(const AttnParams& p, int qmax, hipStream_t st) {
   const size_t lds = (size_t)(64 * (p.ch + 1) * 2 + 64 * p.ch + 64 * 65 + 192) * sizeof(float);
@@ -699,7 +959,13 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 &&
                        ((uintptr_t)Q | (uintptr_t)KV) % 16 == 0 && (uintptr_t)O % 8 == 0;
-  if (dtype == MMD_BF16 && impl == 0 && aligned) {
+  // long windows at head width 64 (the ds-2 level): staged-window kernel, K/V staged once per 256 / 512 queries
+  const int k_count = win * k_per_group;
+  const bool stage_ok = dtype == MMD_BF16 && aligned && ch == 64;
+  if (impl == 3 && !stage_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 3 (staged window): needs bf16, head width 64, aligned rows");
+  if (stage_ok && (impl == 3 || (impl == 0 && k_count >= 192 && qmax >= 128)))
+    return launch_stage<64>(p, qmax, st);
+  if (dtype == MMD_BF16 && (impl == 0 || impl == 2 || impl == 3) && aligned) {
     switch (ch) {
       case 16: return launch_mfma<16>(p, qmax, st);
       case 32: return launch_mfma<32>(p, qmax, st);
@@ -716,7 +982,8 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   return launch_generic<float>(p, qmax, st);
 }
 
-// impl: 0 = auto (MFMA when dtype is bf16 and ch is supported), 1 = force generic VALU kernel
+// impl: 0 = auto (MFMA when dtype is bf16 and ch is supported; staged-window kernel for long windows at head width 64),
+// 1 = force generic VALU kernel, 2 = force the per-128-query MFMA kernel, 3 = force the staged-window kernel
 extern "C" int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off,
                             int v_off, void* O, int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch,
                             int q_per_group, int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev,

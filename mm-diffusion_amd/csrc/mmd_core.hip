@@ -1,6 +1,9 @@
 // Error plumbing, version and HIP-graph capture helpers of the C-ABI.
 #include "mmd_common.h"
 #include <string.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 static thread_local char g_err[512] = "";
 
@@ -91,5 +94,42 @@ extern "C" int mmd_event_elapsed_ms(void* a, void* b, float* ms) {
 }
 extern "C" int mmd_event_destroy(void* ev) {
   if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+  return MMD_OK;
+}
+
+// ---- debugging aid for the test suite: native backtrace on a fatal signal.  Python's faulthandler prints the Python stack of a
+// SIGSEGV inside a ctypes call but not WHICH native frame faulted (e.g. inside hipStreamEndCapture); this handler writes the native
+// frames (module + symbol/offset) to stderr and then chains to the handler that was installed before it.
+static struct sigaction g_prev_sa[3];
+static const int g_sigs[3] = {SIGSEGV, SIGBUS, SIGABRT};
+static void mmd_crash_handler(int sig, siginfo_t* info, void* uc) {
+  static const char msg[] = "\n[libmmd] fatal signal - native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  for (int i = 0; i < 3; ++i) {
+    if (g_sigs[i] != sig) continue;
+    if (g_prev_sa[i].sa_flags & SA_SIGINFO) {
+      if (g_prev_sa[i].sa_sigaction) { g_prev_sa[i].sa_sigaction(sig, info, uc); return; }
+    } else if (g_prev_sa[i].sa_handler != SIG_DFL && g_prev_sa[i].sa_handler != SIG_IGN) {
+      g_prev_sa[i].sa_handler(sig);
+      return;
+    }
+    sigaction(sig, &g_prev_sa[i], nullptr);     // default action: re-raise
+    raise(sig);
+  }
+}
+extern "C" int mmd_debug_install_crash_handler(void) {
+  void* warm[4];
+  (void)backtrace(warm, 4);                     // loads libgcc now: backtrace() must not dlopen inside the handler
+  for (int i = 0; i < 3; ++i) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = mmd_crash_handler;
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    if (sigaction(g_sigs[i], &sa, &g_prev_sa[i]) != 0) return mmd_set_error(MMD_ERR_LAUNCH, "sigaction failed");
+  }
   return MMD_OK;
 }

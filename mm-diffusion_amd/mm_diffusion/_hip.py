@@ -7,7 +7,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmd.so")
+# MMD_LIB: an ablation / experiment build of the library (tools/ only; the product never sets it)
+LIB_PATH = os.environ.get("MMD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmmd.so")
 
 F32, BF16 = 0, 1
 _lib = None
@@ -16,6 +17,7 @@ i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
 _PROTOS = {
     "mmd_version": (C.c_int, []),
     "mmd_last_error": (C.c_char_p, []),
+    "mmd_debug_install_crash_handler": (i32, []),
     "mmd_graph_begin": (i32, [vp]),
     "mmd_graph_end": (i32, [vp, C.POINTER(vp)]),
     "mmd_graph_launch": (i32, [vp, vp]),

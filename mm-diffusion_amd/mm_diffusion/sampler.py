@@ -25,9 +25,11 @@ def unwrap_unet(model):
 
 
 def default_lanes(batch):
-    """Batch lanes of a sampling step (see GraphStepper): MMD_LANES overrides; otherwise 2 when the batch splits evenly."""
+    """Batch lanes of a sampling step (see GraphStepper): 1 unless MMD_LANES says otherwise.  Measured on MI355X at batch 4
+    (BASELINE configs[1]): 1 lane 15.53 ms / step, 2 lanes 15.37, 4 lanes 20.5 - the per-level kernels already occupy every CU
+    (LDS-limited residency), so a second lane's launches queue behind them instead of filling idle CUs."""
     v = os.environ.get("MMD_LANES")
-    lanes = int(v) if v else (2 if batch >= 4 and batch % 2 == 0 else 1)
+    lanes = int(v) if v else 1
     return lanes if lanes >= 1 and batch % lanes == 0 else 1
 
 
@@ -35,11 +37,10 @@ class GraphStepper:
     """One denoising step of `batch` trajectories as one graph replay.
 
     lanes > 1 splits the batch into independent sub-batches, each with its own engine (activation buffers, video + audio launch
-    streams; packed weights are shared) and all captured into the SAME graph as parallel branches.  Every sample's trajectory is
-    independent (GroupNorm / attention never mix batch elements, tests: batch sharding is bitwise exact), so the result is
-    identical; what changes is that the many latency-bound launches of the low-resolution levels (ds4 / ds8 GEMMs, GroupNorm
-    statistics: most of the ~1100 launches of a step) of one lane run beside the other lane's work instead of leaving most of the
-    256 CUs idle.  Noise and timestep buffers stay full-batch (lanes read slices), so the RNG stream does not depend on `lanes`."""
+    streams; packed weights are shared) and its own captured graph; the lane graphs are launched on the lanes' private streams,
+    forked from and joined to the caller's stream with events.  Every sample's trajectory is independent (GroupNorm / attention
+    never mix batch elements, tests: batch sharding is bitwise exact), so the result is identical.  Noise and timestep buffers stay
+    full-batch (lanes read slices), so the RNG stream does not depend on `lanes`.  An option, not the default: see default_lanes."""
 
     def __init__(self, diffusion, unet, batch, device, clip_denoised=True, use_graph=True, update="ddpm", eta=0.0, lanes=None):
         self.diff, self.unet, self.N = diffusion, unet, int(batch)
@@ -83,7 +84,7 @@ class GraphStepper:
                 ops.record_sync(1, 0)
             self.update_plans.append(plan)
         self.update_plan = self.update_plans[0]
-        self.graph = None
+        self.graphs = None
         self.use_graph = use_graph
         # per-step scalars go up through pinned rings (H.Staged): the host runs ahead of the GPU, one reused pinned buffer would race
         self._up_t = H.Staged(self.t_idx)
@@ -91,7 +92,7 @@ class GraphStepper:
         # lane fork / join events (lane 0 rides the origin stream, lane r > 0 its engine's private `side` stream)
         import ctypes
         self._lane_ev = []
-        for _ in range(self.lanes if self.lanes > 1 else 0):
+        for _ in range(self.lanes + 1 if self.lanes > 1 else 0):
             ev = ctypes.c_void_p()
             H.call("mmd_event_create", ctypes.byref(ev))
             self._lane_ev.append(ev)
@@ -113,32 +114,48 @@ class GraphStepper:
             return {"video": self.eng.x_video.clone(), "audio": self.eng.x_audio.clone()}
         return {"video": th.cat([e.x_video for e in self.engs]), "audio": th.cat([e.x_audio for e in self.engs])}
 
-    def _launch_all(self, stream):
-        lib = H.lib()
-        if self.lanes > 1:
-            lib.mmd_event_record(self._lane_ev[0], stream)                    # fork point: before any lane's first launch
-        for r, e in enumerate(self.engs):
-            vs = stream if r == 0 else e.side.cuda_stream
-            if r:
-                lib.mmd_stream_wait_event(vs, self._lane_ev[0])
-            aux = e.aux.cuda_stream
-            ops.run_plan(e.plan_f32 if self.use_f32 else e.plan, vs, aux)
-            ops.run_plan(self.update_plans[r], vs, aux)
-            if r:
-                lib.mmd_event_record(self._lane_ev[r], vs)
-        for r in range(1, self.lanes):
-            if lib.mmd_stream_wait_event(stream, self._lane_ev[r]):
-                raise H.MMDError(f"lane join failed: {lib.mmd_last_error().decode()}")
+    def _lane_launch(self, r, stream):
+        """Enqueue lane r's U-Net plan and fused update with `stream` as its video-chain stream (its engine's aux = audio chain)."""
+        e = self.engs[r]
+        aux = e.aux.cuda_stream
+        ops.run_plan(e.plan_f32 if self.use_f32 else e.plan, stream, aux)
+        ops.run_plan(self.update_plans[r], stream, aux)
 
     def _capture(self):
-        side = self.eng.side                            # lane 0's private capture stream
-        side.wait_stream(th.cuda.current_stream(self.device))
-        self._launch_all(side.cuda_stream)              # warm-up: one-time function attributes, lazy module load
+        """One graph PER LANE, each captured with the lane's own private stream as the capture origin and its engine's aux stream
+        as the only forked stream.  (All lanes in one capture would need two non-origin streams - a lane's video and audio chains
+        - that wait on each other at every cross-attention; the HIP runtime re-parents the waiting stream on each such wait, the
+        two become each other's parent and hipStreamEndCapture recurses until the stack overflows: the SIGSEGV of
+        tools/lanes_probe.py.  Streams keep ONE role for life here: an engine's `side` is only ever an origin, its `aux` only ever
+        the origin's child.)"""
+        cur = th.cuda.current_stream(self.device)
+        for r, e in enumerate(self.engs):
+            e.side.wait_stream(cur)
+            self._lane_launch(r, e.side.cuda_stream)        # warm-up: one-time function attributes, lazy module load
         th.cuda.synchronize(self.device)
-        with H.capture(side.cuda_stream) as cap:
-            self._launch_all(side.cuda_stream)
-        self.graph = cap.exec
-        th.cuda.current_stream(self.device).wait_stream(side)
+        graphs = []
+        for r, e in enumerate(self.engs):
+            with H.capture(e.side.cuda_stream) as cap:
+                self._lane_launch(r, e.side.cuda_stream)
+            graphs.append(cap.exec)
+        self.graphs = graphs
+
+    def _fan(self, body):
+        """Run body(r, stream) for every lane: lane streams fork from the current stream and join it again (plain events)."""
+        cur = H.stream_handle()
+        if self.lanes == 1:
+            body(0, cur)
+            return
+        lib = H.lib()
+        lib.mmd_event_record(self._lane_ev[0], cur)
+        for r, e in enumerate(self.engs):
+            ls = e.side.cuda_stream
+            lib.mmd_stream_wait_event(ls, self._lane_ev[0])
+            body(r, ls)
+            lib.mmd_event_record(self._lane_ev[r + 1], ls)
+        for r in range(self.lanes):
+            if lib.mmd_stream_wait_event(cur, self._lane_ev[r + 1]):
+                raise H.MMDError(f"lane join failed: {lib.mmd_last_error().decode()}")
 
     def set_step(self, i, shifts=None, noise=None):
         """Refresh the per-step device state: timestep, shifts, noise (video first, then audio - gd:453-454)."""
@@ -163,18 +180,18 @@ class GraphStepper:
 
     def launch(self):
         if self.use_graph:
-            if self.graph is None:
+            if self.graphs is None:
                 # capture replays the step once as warm-up: keep x intact around it
                 keep = [(e.x_video.clone(), e.x_audio.clone()) for e in self.engs]
                 self._capture()
                 for e, (xv, xa) in zip(self.engs, keep):
                     e.x_video.copy_(xv)
                     e.x_audio.copy_(xa)
-            H.call("mmd_graph_launch", self.graph, H.stream_handle())
+            self._fan(lambda r, stream: H.call("mmd_graph_launch", self.graphs[r], stream))
         else:
-            for e in self.engs:
-                e.aux.wait_stream(th.cuda.current_stream(self.device))
-            self._launch_all(H.stream_handle())
+            if self.lanes == 1:
+                self.eng.aux.wait_stream(th.cuda.current_stream(self.device))
+            self._fan(self._lane_launch)
 
     def step(self, i, shifts=None, noise=None):
         self.set_step(i, shifts, noise)
@@ -184,8 +201,8 @@ class GraphStepper:
         """Retire the graph exec and the update plan's join event (destroyed by H.reap() at the next safe point, never here: this
         also runs as a finaliser from the cyclic GC)."""
         try:
-            g, self.graph = getattr(self, "graph", None), None
-            if g is not None:
+            gs, self.graphs = getattr(self, "graphs", None) or [], None
+            for g in gs:
                 H.retire("graph", g)
             for ev in H.plan_events(*(getattr(self, "update_plans", None) or [])) + list(getattr(self, "_lane_ev", [])):
                 H.retire("event", ev)

@@ -1,0 +1,207 @@
+"""The BASELINE.json configurations themselves, at full size, on the HIP path (`-m gpu`).
+
+  configs[1]  Landscape base model, batch 4, bf16, graph replay: batch rows == four batch-1 runs (bitwise), sample 0 of a 2-step run vs the
+              reference-generated full-size fixture, and the drift of a 50-step bf16 trajectory against the fp32-mode HIP path on
+              identical noise / shifts (no low-precision oracle exists upstream; the fp32-mode path is pinned to the reference at 2.5e-5).
+  configs[3]  training step, batch 8: bf16 gradients vs fp32-mode gradients, graph-captured step vs eager step.
+  configs[4]  DPM-Solver++ multistep-2, 50 network evaluations, batch 2, bf16 vs fp32 mode; one SR U-Net evaluation on the 16 frames of a
+              clip at 256 x 256.
+configs[0] is tests/test_model_gpu.py::test_full_config_two_step_matches_reference; configs[2] needs 8 GPUs (driver's SCALE run).
+
+Stated bounds (rel-L2): bitwise where the arithmetic is identical; 1e-1 for the 2-step bf16 loop vs the fp32 reference (LOOP_TOL of
+test_model_gpu.py); DRIFT_50 for bf16 vs fp32 over 50 DDPM steps; 5e-2 for bf16 vs fp32 gradients; DPM_50 for the 50-NFE solver."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import flags, gold, rel_l2, synth_sd
+
+pytestmark = pytest.mark.gpu
+
+DRIFT_50 = 0.25       # bf16 vs fp32-mode after 50 ancestral steps on identical noise (measured: see the printed value)
+DPM_50 = 0.25         # bf16 vs fp32-mode after 50 DPM-Solver++ evaluations with dynamic thresholding
+
+
+def _full(dt, **over):
+    from mm_diffusion import logger, multimodal_script_util as msu
+    logger.set_quiet(True)
+    fl = flags("full", use_fp16=(dt == torch.bfloat16), **over)
+    model, diff = msu.create_model_and_diffusion(**fl)
+    model.load_state_dict(synth_sd("full"))
+    model.cuda().eval()
+    return fl, model, diff
+
+
+def _golden_noise(g, fl):
+    """The CPU draws of the full-size 2-step fixture (B = 1): x_T video, x_T audio, then per step video noise, audio noise."""
+    torch.manual_seed(int(g["seed"]))
+    shp_v, shp_a = (1, *fl["video_size"]), (1, *fl["audio_size"])
+    xT = (torch.randn(shp_v), torch.randn(shp_a))
+    steps = [(torch.randn(shp_v), torch.randn(shp_a)) for _ in range(2)]
+    return xT, steps
+
+
+def test_config1_batch4_bf16_two_step_rows():
+    """configs[1] shapes (batch 4, bf16, graph replay, default batch lanes): row 0 reproduces the reference-generated full-size 2-step
+    fixture within LOOP_TOL, and every row equals the batch-1 run of the same sample bitwise."""
+    from mm_diffusion.sampler import GraphStepper
+    g = gold("full_psample2")
+    fl, model, diff = _full(torch.bfloat16, timestep_respacing="2")
+    (xv0, xa0), steps0 = _golden_noise(g, fl)
+    gen = torch.Generator().manual_seed(77)
+    B = 4
+    xv = torch.cat([xv0] + [torch.randn(1, *fl["video_size"], generator=gen) for _ in range(B - 1)]).cuda()
+    xa = torch.cat([xa0] + [torch.randn(1, *fl["audio_size"], generator=gen) for _ in range(B - 1)]).cuda()
+    noise = [{"video": torch.cat([nv] + [torch.randn(1, *fl["video_size"], generator=gen) for _ in range(B - 1)]).cuda(),
+              "audio": torch.cat([na] + [torch.randn(1, *fl["audio_size"], generator=gen) for _ in range(B - 1)]).cuda()} for nv, na in steps0]
+    shifts = [int(s) for s in g["shifts"]]
+    per = len(shifts) // 2
+
+    def run(rows):
+        st = GraphStepper(diff, model, len(rows), torch.device("cuda"))
+        st.load(xv[rows], xa[rows])
+        for k, i in enumerate((1, 0)):
+            st.step(i, shifts=shifts[k * per:(k + 1) * per], noise={"video": noise[k]["video"][rows], "audio": noise[k]["audio"][rows]})
+        out = st.current()
+        st.close()
+        return out
+    full = run(list(range(B)))
+    ev, ea = rel_l2(full["video"][:1].cpu(), g["video"]), rel_l2(full["audio"][:1].cpu(), g["audio"])
+    print(f"configs[1] batch-4 bf16 2-step, sample 0 vs reference fixture: rel-L2 video {ev:.3e} audio {ea:.3e}")
+    assert ev < 1e-1 and ea < 1e-1
+    for r in range(B):
+        one = run([r])
+        assert torch.equal(one["video"][0], full["video"][r]) and torch.equal(one["audio"][0], full["audio"][r]), f"row {r}"
+
+
+def test_config1_bf16_drift_over_50_steps():
+    """configs[1] precision: 50-step DDPM trajectory (batch 4, full size) in bf16 vs the fp32-mode HIP path on identical x_T, noise and
+    window shifts.  The drift bound is the stated tolerance of the bf16 configuration over a long loop."""
+    from mm_diffusion.sampler import GraphStepper
+    B, T = 4, 50
+    outs, mids = {}, {}
+    for dt in (torch.float32, torch.bfloat16):
+        fl, model, diff = _full(dt, timestep_respacing=str(T))
+        st = GraphStepper(diff, model, B, torch.device("cuda"))
+        gd = torch.Generator(device="cuda").manual_seed(123)
+        st.load(torch.randn(B, *fl["video_size"], device="cuda", generator=gd), torch.randn(B, *fl["audio_size"], device="cuda", generator=gd))
+        random.seed(123)
+        for i in range(T - 1, -1, -1):
+            nz = {"video": torch.randn(B, *fl["video_size"], device="cuda", generator=gd),
+                  "audio": torch.randn(B, *fl["audio_size"], device="cuda", generator=gd)}
+            st.step(i, noise=nz)
+            if i == T // 2:
+                mids[dt] = st.current()
+        outs[dt] = st.current()
+        st.close()
+        del model, diff, st
+    for name, d in (("after 25 steps", mids), ("final", outs)):
+        ev = rel_l2(d[torch.bfloat16]["video"].cpu(), d[torch.float32]["video"].cpu().numpy())
+        ea = rel_l2(d[torch.bfloat16]["audio"].cpu(), d[torch.float32]["audio"].cpu().numpy())
+        print(f"configs[1] bf16 vs fp32-mode, 50-step DDPM, {name}: rel-L2 video {ev:.3e} audio {ea:.3e}")
+        assert ev < DRIFT_50 and ea < DRIFT_50
+    assert torch.isfinite(outs[torch.bfloat16]["video"]).all() and torch.isfinite(outs[torch.bfloat16]["audio"]).all()
+
+
+def _train_grads(dt, x0, noise, t, shifts_seed, use_graph=False):
+    from mm_diffusion import logger, multimodal_script_util as msu
+    from mm_diffusion.optim import FlatAdamW
+    logger.set_quiet(True)
+    fl = flags("full", use_fp16=(dt == torch.bfloat16), dropout=0.0)
+    model, diff = msu.create_model_and_diffusion(**fl)
+    model.load_state_dict(synth_sd("full"))
+    model.cuda().train()
+    opt = FlatAdamW(model.parameters(), lr=0.0, pack_dtype=model.dtype)
+    random.seed(shifts_seed)
+    if use_graph:
+        from mm_diffusion.train_graph import GraphedTrainStep
+        gs = GraphedTrainStep(model, diff, opt, x0)
+        gs.step(x0, t, noise=noise)                       # warm-up + capture + first replay
+        random.seed(shifts_seed)
+        losses = gs.step(x0, t, noise=noise)
+        torch.cuda.synchronize()
+        loss = losses["loss"].detach().float().cpu()
+        gs.close()
+    else:
+        opt.zero_grad()
+        terms = diff.multimodal_training_losses(model, x0, t, noise=noise)
+        terms["loss"].mean().backward()
+        opt.fold_grads()
+        loss = terms["loss"].detach().float().cpu()
+    torch.cuda.synchronize()
+    names = [k for k, _ in model.named_parameters()]
+    grads = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+    flat = opt.grad.detach().float().cpu().clone()
+    return loss, grads, flat, names
+
+
+def test_config3_training_step_batch8_bf16_vs_fp32_and_graph_vs_eager():
+    """configs[3]: full-size multimodal_training_losses step at per-GPU batch 8 (x0 ~ U(-1, 1), t ~ U{0..999}).  bf16 gradients against
+    the fp32-mode gradients of the same step (same q_sample noise, same forward / recompute shift draws), and the graph-captured step
+    against the eager step."""
+    B = 8
+    fl = flags("full")
+    gen = torch.Generator().manual_seed(2024)
+    x0 = {"video": (torch.rand(B, *fl["video_size"], generator=gen) * 2 - 1).cuda(), "audio": (torch.rand(B, *fl["audio_size"], generator=gen) * 2 - 1).cuda()}
+    noise = {"video": torch.randn(B, *fl["video_size"], generator=gen).cuda(), "audio": torch.randn(B, *fl["audio_size"], generator=gen).cuda()}
+    t = torch.randint(0, 1000, (B,), generator=gen).cuda()
+    loss32, g32, flat32, names = _train_grads(torch.float32, x0, noise, t, 9)
+    loss16, g16, flat16, _ = _train_grads(torch.bfloat16, x0, noise, t, 9)
+    assert torch.isfinite(flat32).all() and torch.isfinite(flat16).all()
+    np.testing.assert_allclose(loss16.numpy(), loss32.numpy(), rtol=3e-2)
+    e_all = rel_l2(flat16, flat32.numpy())
+    worst = max(((rel_l2(g16[k], g32[k].numpy()), k) for k in names if g32[k].numel() >= 4096 and float(g32[k].norm()) > 0), key=lambda kv: kv[0])
+    print(f"configs[3] batch-8 training step: bf16 vs fp32-mode gradients rel-L2 {e_all:.3e} (flat), worst tensor {worst[0]:.3e} {worst[1]}")
+    assert e_all < 5e-2
+    lossg, _, flatg, _ = _train_grads(torch.bfloat16, x0, noise, t, 9, use_graph=True)
+    eg = rel_l2(flatg, flat16.numpy())
+    print(f"configs[3] graph-captured vs eager step (bf16): gradients rel-L2 {eg:.3e}")
+    assert eg < 2e-2
+    np.testing.assert_allclose(lossg.numpy(), loss16.numpy(), rtol=2e-2)
+
+
+def test_config4_dpm_solver_pp_50_evaluations_then_sr_frame_batch():
+    """configs[4]: DPM-Solver++ (predict_x0, dynamic thresholding), multistep order 2, 50 network evaluations at full size, batch 2, bf16 vs
+    fp32 mode on the same x_T / shifts; then ONE evaluation of the shipped 64 -> 256 SR U-Net on the 16 frames of a clip (16 x 3 x 256 x 256),
+    bf16 vs fp32 mode."""
+    from mm_diffusion.multimodal_dpm_solver_plus import DPM_Solver
+    B = 2
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        fl, model, diff = _full(dt)
+        gd = torch.Generator(device="cuda").manual_seed(5)
+        x_T = {"video": torch.randn(B, *fl["video_size"], device="cuda", generator=gd), "audio": torch.randn(B, *fl["audio_size"], device="cuda", generator=gd)}
+        random.seed(5)
+        solver = DPM_Solver(model=model, alphas_cumprod=torch.tensor(diff.alphas_cumprod, dtype=torch.float32), predict_x0=True, thresholding=True)
+        outs[dt] = solver.sample(x_T, steps=50, order=2, skip_type="logSNR", method="multistep")
+        assert solver.nfe == 50
+        del model, diff, solver
+    ev = rel_l2(outs[torch.bfloat16]["video"].cpu(), outs[torch.float32]["video"].cpu().numpy())
+    ea = rel_l2(outs[torch.bfloat16]["audio"].cpu(), outs[torch.float32]["audio"].cpu().numpy())
+    print(f"configs[4] DPM-Solver++ 50 NFE, bf16 vs fp32-mode: rel-L2 video {ev:.3e} audio {ea:.3e}")
+    assert torch.isfinite(outs[torch.bfloat16]["video"]).all() and torch.isfinite(outs[torch.bfloat16]["audio"]).all()
+    assert ev < DPM_50 and ea < DPM_50
+
+    from mm_diffusion import logger, script_util as su
+    from mm_diffusion.synth import synth_init_
+    logger.set_quiet(True)
+    ys = {}
+    for dt in (torch.float32, torch.bfloat16):
+        d = su.image_sr_model_and_diffusion_defaults()
+        d.update(large_size=256, small_size=64, sr_num_channels=192, sr_num_heads=4, sr_num_res_blocks=2, sr_attention_resolutions="8,16,32",
+                 sr_resblock_updown=True, sr_use_scale_shift_norm=True, sr_learn_sigma=True, use_fp16=(dt == torch.bfloat16), sr_timestep_respacing="ddim25")
+        model, sdiff = su.image_sr_create_model_and_diffusion(**d)
+        synth_init_(model)
+        model.cuda().eval()
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(16, 3, 256, 256, generator=g).cuda()
+        low = (torch.rand(16, 3, 64, 64, generator=g) * 2 - 1).cuda()
+        tt = torch.full((16,), 700, dtype=torch.int64).cuda()
+        with torch.no_grad():
+            ys[dt] = model(x, tt, low_res=low).float().cpu()
+        del model
+    e = rel_l2(ys[torch.bfloat16], ys[torch.float32].numpy())
+    print(f"configs[4] SR U-Net, one evaluation on 16 x 3 x 256 x 256: bf16 vs fp32-mode rel-L2 {e:.3e}")
+    assert ys[torch.float32].shape == (16, 6, 256, 256) and torch.isfinite(ys[torch.bfloat16]).all() and e < 3e-2

@@ -268,16 +268,66 @@ def test_cross_attention_windows(ops, dt, impl, F, HW, L, win, shift, heads, ch)
     assert rel_l2(ao.float().cpu(), aref) < tol(dt)
 
 
+@pytest.mark.parametrize("impl", [2, 3])
+@pytest.mark.parametrize("F,HW,L,win,shift,heads", [
+    (4, 1024, 1600, 1, 2, 2),      # ds-2 geometry: 1024 x 400 and 400 x 1024 windows (ragged last sub-tile, 2 / 4 key stages, wrap-around)
+    (4, 256, 400, 4, 3, 2),        # ds-4 geometry: 256 x 400 (staged, one tile per wave), 100 x 1024 (short: per-128-query kernel)
+    (2, 320, 1000, 2, 1, 1),       # 320 x 1000 / 500 x 640: ragged query tiles AND ragged key stages
+])
+def test_cross_attention_long_windows(ops, impl, F, HW, L, win, shift, heads):
+    """The long RS-MMA windows at head width 64 on both MFMA kernels (2 = per-128-query kernel, 3 = staged-window kernel; 0 picks per
+    shape), against the oracle and against each other."""
+    dt, ch = torch.bfloat16, 64
+    N, C = 2, heads * ch
+    apf = L // F
+    vq, aq = _qkv_rows(N, F * HW, C, dt, 36), _qkv_rows(N, L, C, dt, 37)
+    sh = torch.tensor([shift], dtype=torch.int32, device="cuda")
+    outs = {}
+    for im in (impl, 0):
+        vo = torch.zeros(N * F * HW, C, dtype=dt, device="cuda")
+        ao = torch.zeros(N * L, C, dtype=dt, device="cuda")
+        ops.attn(dev(vq, dt), dev(aq, dt), vo, heads, ch, N, F, F * HW, HW, L, apf, win, shift_dev=sh, impl=im)
+        ops.attn(dev(aq, dt), dev(vq, dt), ao, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh, impl=im)
+        outs[im] = (vo.float().cpu(), ao.float().cpu())
+    vref, aref = torch.zeros(N * F * HW, C), torch.zeros(N * L, C)
+    for n in range(N):
+        for i in range(F):
+            a_idx = n * L + (torch.arange(win * apf) + (i + shift) * apf) % L
+            qi = n * F * HW + torch.arange(i * HW, (i + 1) * HW)
+            vref[qi] = _ref_attn(vq, aq, heads, ch, qi, a_idx)
+            v_idx = n * F * HW + (torch.arange(win * HW) + (i + shift) * HW) % (F * HW)
+            hi = L if i == F - 1 else (i + 1) * apf
+            qa = n * L + torch.arange(i * apf, hi)
+            aref[qa] = _ref_attn(aq, vq, heads, ch, qa, v_idx)
+    for im in outs:
+        assert rel_l2(outs[im][0], vref) < tol(dt) and rel_l2(outs[im][1], aref) < tol(dt)
+    assert rel_l2(outs[impl][0], outs[0][0]) < 3e-3 and rel_l2(outs[impl][1], outs[0][1]) < 3e-3
+
+
+@pytest.mark.parametrize("T,heads", [(1024, 2), (200, 1), (520, 2)])
+def test_self_attention_staged_window(ops, T, heads):
+    """Spatial self-attention at head width 64 on the staged-window kernel (1, 2 and 3+ key stages; T = 520: ragged everything)."""
+    dt, ch = torch.bfloat16, 64
+    N, G, C = 1, 3, heads * ch
+    qkv = _qkv_rows(N * G, T, C, dt, 38)
+    ref = torch.cat([_ref_attn(qkv, qkv, heads, ch, torch.arange(s * T, (s + 1) * T), torch.arange(s * T, (s + 1) * T)) for s in range(N * G)])
+    for impl in (3, 2):
+        out = torch.zeros(N * G * T, C, dtype=dt, device="cuda")
+        ops.attn(dev(qkv, dt), dev(qkv, dt), out, heads, ch, N, G, G * T, T, G * T, T, 1, impl=impl)
+        assert rel_l2(out.float().cpu(), ref) < tol(dt)
+
+
 def test_attention_softmax_spike(ops):
     """Online-softmax rescale path: one key dominates late in the sequence (forces a big running-max jump)."""
     T, heads, ch = 300, 1, 64
     qkv = rnd(T, 3 * 64, dt=torch.bfloat16, seed=28) * 0.3
     qkv[250, 64:128] = qkv[7, :64] * 40           # key 250 (4th tile) aligned with query 7
     qkv = qkv.to(torch.bfloat16).float()
-    out = torch.zeros(T, 64, dtype=torch.bfloat16, device="cuda")
-    ops.attn(dev(qkv, torch.bfloat16), dev(qkv, torch.bfloat16), out, heads, ch, 1, 1, T, T, T, T, 1)
     ref = _ref_attn(qkv, qkv, heads, ch, torch.arange(T), torch.arange(T))
-    assert rel_l2(out.float().cpu(), ref) < 1e-2
+    for impl in (2, 3):         # per-128-query kernel, staged-window kernel (the spike sits in the second key stage)
+        out = torch.zeros(T, 64, dtype=torch.bfloat16, device="cuda")
+        ops.attn(dev(qkv, torch.bfloat16), dev(qkv, torch.bfloat16), out, heads, ch, 1, 1, T, T, T, T, 1, impl=impl)
+        assert rel_l2(out.float().cpu(), ref) < 1e-2
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -26,25 +26,40 @@ def main():
     for e in ev:
         H.call("mmd_event_create", ctypes.byref(e))
     st = H.stream_handle()
-    for name, qr, qg, kr, kg, win, heads, ch in SHAPES:
+    only = os.environ.get("ATTN_BENCH_SHAPES")
+    impls = tuple(int(v) for v in os.environ.get("ATTN_BENCH_IMPLS", "2,3").split(","))
+    for si, (name, qr, qg, kr, kg, win, heads, ch) in enumerate(SHAPES):
+        if only and str(si) not in only.split(","):
+            continue
         C = heads * ch
         g = torch.Generator(device="cuda").manual_seed(0)
         q = torch.randn(N * qr, 3 * C, device="cuda", generator=g).to(dt)
         kv = torch.randn(N * kr, 3 * C, device="cuda", generator=g).to(dt)
-        out = torch.empty(N * qr, C, device="cuda", dtype=dt)
         sh = torch.tensor([3], dtype=torch.int32, device="cuda")
         flops = 4.0 * N * qr * win * kg * C
-        for _ in range(2):
-            ops.attn(q, kv, out, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh)
-        H.call("mmd_event_record", ev[0], st)
-        n = 10
-        for _ in range(n):
-            ops.attn(q, kv, out, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh)
-        H.call("mmd_event_record", ev[1], st)
-        ms = ctypes.c_float()
-        H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
-        us = ms.value / n * 1000
-        print(f"{name:22s} {us:8.1f} us  {flops/us/1e6:6.0f} TF/s  ({flops/1e9:.1f} GF)", flush=True)
+        line = f"{name:22s} ({flops/1e9:5.1f} GF)"
+        ref = None
+        for impl in impls:             # 2 = per-128-query MFMA kernel, 3 = staged-window kernel (head width 64 only)
+            if impl == 3 and ch != 64:
+                continue
+            out = torch.zeros(N * qr, C, device="cuda", dtype=dt)
+            for _ in range(2):
+                ops.attn(q, kv, out, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=impl)
+            err = 0.0
+            if ref is None:
+                ref = out.clone()
+            else:
+                err = float((out.float() - ref.float()).norm() / ref.float().norm())
+            H.call("mmd_event_record", ev[0], st)
+            n = 10
+            for _ in range(n):
+                ops.attn(q, kv, out, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=impl)
+            H.call("mmd_event_record", ev[1], st)
+            ms = ctypes.c_float()
+            H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
+            us = ms.value / n * 1000
+            line += f" | impl{impl}: {us:7.1f} us {flops/us/1e6:5.0f} TF/s ({100*flops/us/1e6/2500:4.1f}% mfma) e={err:.1e}"
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
