@@ -68,6 +68,11 @@ int64_t mmd_gn_workspace_bytes(int dtype, int C, int S, int Tn);
 int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int inner, int64_t outer_stride,
                  int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, const float* film,
                  int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out, void* workspace, void* stream);
+/* The same fused affine from PRODUCER-side statistics: the GEMM that wrote x (mmd_conv_gemm_stats / mmd_gn_conv1x1_stats) left per
+ * (64-row record, channel) float2 (sum, sum of squares) in rec[(row / 64) * rec_ld + c]; S contiguous slices of Tn rows, Tn % 64 == 0.
+ * Replaces the statistics pass over x of GroupNorm32 (nn.py:16-33) for conv-fed norms. */
+int mmd_gn_finalize_stats(const float* rec, int64_t rec_ld, int C, int S, int Tn, const float* gamma, const float* beta,
+                          const float* film, int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out, void* stream);
 /* y = act(x*a[slice(row)] + b[slice(row)]), act: 0 none, 1 SiLU (nn.SiLU after every GroupNorm32). */
 int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn, int inner,
                  int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a, const float* b, int act,
@@ -95,6 +100,18 @@ int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const fl
 int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
                    int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                    int M, int Cout, int Cin, int tile, void* stream);
+
+/* The two GEMMs above with the GroupNorm statistics of their OUTPUT produced in the epilogue, for the norm that consumes Y next
+ * (ResBlock in_layers / out_layers norms, attention norms, the heads: unet:339-340,374-375; nn.py:16-33): per (64-row record,
+ * column) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + column] = float2.  `stats` points at
+ * the first column this launch writes (producers of a channel-concatenated tensor fill column slices of one record buffer).
+ * M % 64 == 0; not with tile 130.  mmd_gn_finalize_stats consumes the records. */
+int mmd_conv_gemm_stats(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
+                        void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
+                        float* stats, int64_t stats_ld, void* stream);
+int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
+                         int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                         int M, int Cout, int Cin, int tile, float* stats, int64_t stats_ld, void* stream);
 
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).
@@ -191,6 +208,9 @@ int mmd_lincomb_t(const float* a, const float* b, float* out, const float* ca, c
                   int N, int64_t per_sample, void* stream);
 /* out = ca a + cb b + cc c (b, c nullable): solver update combinations (multimodal_dpm_solver_plus.py:520-1100). */
 int mmd_lincomb(const float* a, float ca, const float* b, float cb, const float* c, float cc, float* out, int64_t n, void* stream);
+/* y = (dst dtype)(x * scale), fp32 <-> bf16: the bf16 payload of the data-parallel gradient all-reduce (reference: DDP reduces
+ * the fp32 / fp16 gradients it is given, multimodal_train_util.py:127-136) and its widening + 1/world scaling afterwards. */
+int mmd_cast(const void* x, int src_dtype, void* y, int dst_dtype, float scale, int64_t n, void* stream);
 /* backward of mmd_ddpm_update's sample w.r.t. x and the model output (gradient-guided sampling gd:722-817; fixed variance). */
 int mmd_ddpm_update_bwd(const float* x, const float* model_out, const float* dsample, float* dx, float* dmodel_out, const float* tables,
                         const int64_t* t, int T, int N, int64_t per_sample, int flags, void* stream);

@@ -321,6 +321,17 @@ __device__ __forceinline__ int ats_vt_col(int j) {
   return (j & ~12) | ((((q & 1) << 1) | (q >> 1)) << 2);
 }
 
+// max / sum over the two lanes (l, l ^ 32) that share a query: v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip
+// queued behind the fragment reads).  swap(x, x) leaves {lower-half values, upper-half values} in the two results for every lane.
+__device__ __forceinline__ float half_pair_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_pair_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int D>
 __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) {
   constexpr int DV = D / 8;
@@ -452,15 +463,15 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
           s[kt][r] = kk < gi.k_count ? s[kt][r] : -3e38f;
         }
     }
-    float mx = -3e38f;
+    float mxp[4] = {-3e38f, -3e38f, -3e38f, -3e38f};        // four independent chains (a single 32-deep chain is latency-bound)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int r = 0; r < 16; ++r) mxp[r & 3] = fmaxf(mxp[r & 3], s[kt][r]);
+    const float mx = half_pair_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])));
     const float m_new = fmaxf(m_run, mx * sc);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float ps = 0.f;
+    float psp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -471,9 +482,9 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
 #endif
         s[kt][r] = e;
-        ps += e;
+        psp[r & 3] += e;
       }
-    ps += __shfl_xor(ps, 32, 64);
+    const float ps = half_pair_sum((psp[0] + psp[1]) + (psp[2] + psp[3]));
     l_run = l_run * alpha + ps;
     if (__any(m_new != m_run)) {
 #pragma unroll
@@ -521,15 +532,14 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
     }
   }
 
-  // ---- normalise and store: lane owns query qi, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half
-#if defined(ATS_ABLATE) && ATS_ABLATE == 1      // no output stores (one lane keeps the results alive)
-  if (qi < gi.q_count && l_run == -123.f) {
-#else
-  if (qi < gi.q_count) {
-#endif
+  // ---- normalise, transpose through LDS (the K region, free after the last stage) and store whole 128-byte head rows: a lane
+  //      owns a query ROW, so direct stores would be 8-byte pieces at a row stride (64 lines per wave instruction - the store tail
+  //      cost 15 % of the kernel); staged, 8 lanes cover one row and a wave instruction writes 8 complete rows
+  __syncthreads();                         // every wave is past its last K / V^T read
+  {
     const float inv = 1.f / l_run;
-    if (p.lse2 && half == 0) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);
-    char* op = p.O + ((gi.q_row0 + qi) * p.ldo + h * D) * 2;
+    if (p.lse2 && half == 0 && qi < gi.q_count) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);
+    char* so = smem + (wave * 32) * SK;    // this wave's 32 rows x (D*2 + 16) bytes; written and read by this wave only
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -538,8 +548,20 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
         bf16x4 w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[dt][4 * q4 + e] * inv);
-        *(bf16x4*)(op + d * 2) = w;
+        *(bf16x4*)(so + l31 * SK + d * 2) = w;
       }
+#if defined(ATS_ABLATE) && ATS_ABLATE == 1      // no output stores
+    if (l_run == -123.f)
+#endif
+#pragma unroll
+    for (int ps = 0; ps < 32 * DV / 64; ++ps) {
+      const int idx = ps * 64 + lane;
+      const int row = idx / DV, v = idx % DV;
+      if (tq + row < gi.q_count) {
+        const u32x4 x = *(const u32x4*)(so + row * SK + v * 16);
+        *(u32x4*)(p.O + ((gi.q_row0 + tq + row) * p.ldo + h * D + v * 8) * 2) = x;
+      }
+    }
   }
 }
 

@@ -29,8 +29,57 @@ struct ConvGemmParams {
   const float* gn_a; const float* gn_b;      // [S, Cin]; contiguous slices of gn_rows rows (>= BM), Cin <= 256
   int gn_act, gn_S;
   int64_t gn_rows;
+  // optional GroupNorm statistics of the OUTPUT for its consumer (mmd_gn_finalize_stats): per (64-row record, column) the sum and
+  // sum of squares of the stored values, stats[(m / 64) * stats_ld + column] = float2; M % 64 == 0
+  float* stats; int64_t stats_ld;
   int taps[27 * 3];
 };
+
+// ---- producer-side GroupNorm statistics.  The epilogue threads (column group cg = tid % (BN/8), row phase rr = tid / (BN/8)) hold
+// per-record sums over their rows; lanes of a wave that share cg are folded with xor-shuffles, the four waves through `sP`
+// (4 x BM/64 x BN float2; aliases the fp32 staging tile, the caller has a barrier in front), and BM/64 x BN threads write one
+// float2 each.  Fixed order: deterministic.
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&sum)[BM / 64][8], float (&sq)[BM / 64][8], float* sP, int m0,
+                                               int n0, int tid) {
+  constexpr int CVN = BN / 8, NREC = BM / 64;
+  const int lane = tid & 63, wave = tid >> 6, cg = tid % CVN;
+#pragma unroll
+  for (int r = 0; r < NREC; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = CVN; o < 64; o <<= 1) {
+        sum[r][j] += __shfl_xor(sum[r][j], o, 64);
+        sq[r][j] += __shfl_xor(sq[r][j], o, 64);
+      }
+    }
+  if (lane < CVN) {
+#pragma unroll
+    for (int r = 0; r < NREC; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float* d = sP + (((wave * NREC + r) * BN) + cg * 8 + j) * 2;
+        d[0] = sum[r][j];
+        d[1] = sq[r][j];
+      }
+  }
+  __syncthreads();
+  for (int t = tid; t < NREC * BN; t += 256) {
+    const int r = t / BN, col = t % BN;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += sP[(((w * NREC + r) * BN) + col) * 2];
+      b += sP[(((w * NREC + r) * BN) + col) * 2 + 1];
+    }
+    if (n0 + col < p.Cout && m0 + r * 64 < p.M) {
+      float* d = p.stats + ((int64_t)(m0 / 64 + r) * p.stats_ld + n0 + col) * 2;
+      d[0] = a;
+      d[1] = b;
+    }
+  }
+}
 
 #define ROWB 144   // LDS bytes per staged operand row
 
@@ -94,34 +143,55 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
   __syncthreads();
   constexpr int CVN = BN / 8;          // 8-channel groups per row
   constexpr int RP = 256 / CVN;        // rows per pass
+  constexpr int NREC = BM / 64;
   const int cg = tid % CVN, rr = tid / CVN;
   const int co = n0 + cg * 8;
+  float ssum[NREC][8], ssq[NREC][8];
+#pragma unroll
+  for (int r = 0; r < NREC; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ssum[r][j] = ssq[r][j] = 0.f;
   if (co < p.Cout) {
     float bs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
-#pragma unroll 2
-    for (int ml = rr; ml < BM; ml += RP) {
-      const int m = m0 + ml;
-      if (m >= p.M) break;
-      float v[8];
-      const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + cg * 8);
-      const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + cg * 8 + 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
-      if (p.R) {
+    for (int rec = 0; rec < NREC; ++rec) {
+#pragma unroll 2
+      for (int ml = rec * 64 + rr; ml < rec * 64 + 64; ml += RP) {
+        const int m = m0 + ml;
+        if (m >= p.M) break;
+        float v[8];
+        const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + cg * 8);
+        const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + cg * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
+        if (p.R) {
+#pragma unroll
+          for (int h = 0; h < 8 / EPV; ++h) {
+            float rf[EPV];
+            Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
+          }
+        }
 #pragma unroll
         for (int h = 0; h < 8 / EPV; ++h) {
-          float rf[EPV];
-          Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
+          const u32x4 pk = Elt<T>::pack(v + h * EPV);
+          *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = pk;
+          if (p.stats) {                 // statistics of the values as STORED (what the consumer GroupNorm reads back)
+            float rf[EPV];
+            Elt<T>::unpack(pk, rf);
 #pragma unroll
-          for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
+            for (int j = 0; j < EPV; ++j) { ssum[rec][h * EPV + j] += rf[j]; ssq[rec][h * EPV + j] += rf[j] * rf[j]; }
+          }
         }
       }
-#pragma unroll
-      for (int h = 0; h < 8 / EPV; ++h)
-        *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
     }
+  }
+  if (p.stats) {                         // block-uniform
+    __syncthreads();                     // every thread is past its last sC read: the wave partials alias the staging tile
+    epilogue_stats<BM, BN>(p, ssum, ssq, sC, m0, n0, tid);
   }
 }
 
@@ -528,6 +598,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
       }
     }
   __syncthreads();
+  float ssum[2][8], ssq[2][8];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ssum[r][j] = ssq[r][j] = 0.f;
   if (e_co < p.Cout) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -549,10 +624,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
           }
         }
 #pragma unroll
-        for (int h = 0; h < 8 / EPV; ++h)
-          *(u32x4*)(p.Y + ((int64_t)m * p.ldy + e_co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
+        for (int h = 0; h < 8 / EPV; ++h) {
+          const u32x4 pk = Elt<T>::pack(v + h * EPV);
+          *(u32x4*)(p.Y + ((int64_t)m * p.ldy + e_co + h * EPV) * ES) = pk;
+          if (p.stats) {                 // statistics of the values as STORED (what the consumer GroupNorm reads back)
+            float rf[EPV];
+            Elt<T>::unpack(pk, rf);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) { ssum[ps / (NPASS / 2)][h * EPV + j] += rf[j]; ssq[ps / (NPASS / 2)][h * EPV + j] += rf[j] * rf[j]; }
+          }
+        }
       }
     }
+  }
+  if (p.stats) {                         // block-uniform
+    __syncthreads();                     // every thread is past its last sC read: the wave partials alias the staging tile
+    epilogue_stats<128, 128>(p, ssum, ssq, sC, m0, n0, tid);
   }
   GEMM_TL(3);
 #ifdef GEMM_TIMELINE
@@ -854,7 +941,8 @@ static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st)
 
 static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                           void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
-                          int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_S, int64_t gn_rows, void* stream) {
+                          int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_S, int64_t gn_rows, float* stats,
+                          int64_t stats_ld, void* stream) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_gemm: bad dtype %d", dtype);
   MMD_REQUIRE(A && W && Y && M > 0 && Cout > 0 && Cin > 0, "conv_gemm: null/empty argument");
@@ -872,6 +960,9 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
   p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = gn_act; p.gn_S = gn_S; p.gn_rows = gn_rows;
+  MMD_REQUIRE(!stats || (M % 64 == 0 && stats_ld >= Cout && tile != 130 && (uintptr_t)stats % 8 == 0),
+              "conv_gemm: output statistics need M %% 64 == 0, stats_ld >= Cout and a row-tiled main loop (not tile 130)");
+  p.stats = stats; p.stats_ld = stats_ld;
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
@@ -884,7 +975,19 @@ extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* 
                              void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
                              int tile, void* stream) {
   return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 0,
-                        0, stream);
+                        0, nullptr, 0, stream);
+}
+
+// As mmd_conv_gemm, and the epilogue also leaves the GroupNorm statistics of the output for its consumer: per (64-row record,
+// column) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + column] = float2 (stats points at the
+// first column this launch writes, so producers of a channel-concatenated tensor fill column slices of one record buffer).
+// mmd_gn_finalize_stats turns the records into the fused affine; the statistics pass over the tensor disappears.
+extern "C" int mmd_conv_gemm_stats(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
+                                   void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
+                                   int tile, float* stats, int64_t stats_ld, void* stream) {
+  MMD_REQUIRE(stats, "conv_gemm_stats: null statistics buffer");
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 0,
+                        0, stats, stats_ld, stream);
 }
 
 // 1x1 conv of GroupNorm32(+FiLM)(+SiLU)'d rows: Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R); gn_a/gn_b [S, Cin] from
@@ -895,5 +998,15 @@ extern "C" int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float
   static const int tap0[3] = {0, 0, 0};
   MMD_REQUIRE(gn_a && gn_b, "gn_conv1x1: null GroupNorm affine");
   return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, S,
-                        rows_per_slice, stream);
+                        rows_per_slice, nullptr, 0, stream);
+}
+
+// mmd_gn_conv1x1 that also emits the output statistics (see mmd_conv_gemm_stats).
+extern "C" int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
+                                    int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y,
+                                    int64_t ldy, int M, int Cout, int Cin, int tile, float* stats, int64_t stats_ld, void* stream) {
+  static const int tap0[3] = {0, 0, 0};
+  MMD_REQUIRE(gn_a && gn_b && stats, "gn_conv1x1_stats: null GroupNorm affine / statistics buffer");
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, S,
+                        rows_per_slice, stats, stats_ld, stream);
 }

@@ -932,6 +932,23 @@ extern "C" int mmd_lincomb(const float* a, float ca, const float* b, float cb, c
   return mmd_check_launch("lincomb");
 }
 
+// Gradient payload conversion of the data-parallel all-reduce (optim.FlatAdamW, grad_payload = "bf16"): y = (T_out)(x * scale).
+__global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ x, void* __restrict__ y, int src_bf16, int dst_bf16, float scale,
+                                                   int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = (src_bf16 ? Elt<__bf16>::ld(x, i) : ((const float*)x)[i]) * scale;
+    if (dst_bf16) Elt<__bf16>::st(y, i, v);
+    else ((float*)y)[i] = v;
+  }
+}
+extern "C" int mmd_cast(const void* x, int src_dtype, void* y, int dst_dtype, float scale, int64_t n, void* stream) {
+  MMD_REQUIRE(x && y && n > 0, "cast: bad argument");
+  MMD_REQUIRE((src_dtype == MMD_F32 || src_dtype == MMD_BF16) && (dst_dtype == MMD_F32 || dst_dtype == MMD_BF16), "cast: bad dtype");
+  hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, src_dtype == MMD_BF16, dst_dtype == MMD_BF16,
+                     scale, n);
+  return mmd_check_launch("cast");
+}
+
 // Backward of the sampling update through the posterior mean (gradient-guided conditional sampling, gd:722-817):
 //   sample = c1 clamp(x0) + c2 x + noise term,  x0 = cr x - crm1 eps  (or x0 = model output with flag 2)
 //   dx = dsample (c1 cr [|x0| <= 1] + c2),  dmo = dsample (-c1 crm1 [|x0| <= 1])   (fixed variance only)

@@ -357,6 +357,82 @@ extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, 
   return mmd_check_launch("gn_finalize");
 }
 
+// ---- GroupNorm finalize from PRODUCER-side statistics (mmd_conv_gemm_stats): rec[(row / 64) * rec_ld + c] = (sum, sum of squares) of
+// the stored values of 64 consecutive rows of channel c.  One block per (group, slice): the slice's Tn / 64 records x cpg channels
+// are summed in double in a fixed order (thread-strided, then a fixed tree), var = E[x^2] - mean^2 in double (no pivot: the records
+// carry plain sums; the sums themselves are exact to fp32 rounding of <= 64-term partials, so the cancellation costs
+// (1 + mean^2 / var) x 1e-7 relative - fine for conv outputs; the engine uses this path in bf16 mode only).
+__global__ __launch_bounds__(256) void gn_finalize_rec_kernel(const float* __restrict__ rec, int64_t rec_ld, int C, int S, int Tn,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ film, int64_t film_ld, float eps,
+                                                              float* __restrict__ a_out, float* __restrict__ b_out, float* __restrict__ mr_out) {
+  __shared__ double s_a[4], s_b[4];
+  __shared__ float s_mr[2];
+  const int gi = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / GN_GROUPS;
+  const int nrec = Tn / 64;
+  const float* base = rec + ((int64_t)s * nrec * rec_ld + (int64_t)gi * cpg) * 2;
+  const int total = nrec * cpg;
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < total; i += 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {          // branch-free: clamped address, masked value -> the four loads issue together
+      const int k = i + 256 * u;
+      const int kk = min(k, total - 1);
+      const int r = kk / cpg, c = kk - r * cpg;
+      const float2 v = *(const float2*)(base + ((int64_t)r * rec_ld + c) * 2);
+      const double m = k < total ? 1.0 : 0.0;
+      a[u] += m * (double)v.x;
+      b[u] += m * (double)v.y;
+    }
+  }
+  double ta = (a[0] + a[1]) + (a[2] + a[3]), tb = (b[0] + b[1]) + (b[2] + b[3]);
+  ta = wave_sum_d(ta);
+  tb = wave_sum_d(tb);
+  if ((tid & 63) == 0) { s_a[tid >> 6] = ta; s_b[tid >> 6] = tb; }
+  __syncthreads();
+  if (tid == 0) {
+    const double sa = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]), sb = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+    const double cnt = (double)Tn * (double)cpg;
+    const double mean = sa / cnt;
+    double var = sb / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mr[0] = (float)mean;
+    s_mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mr_out) {
+      mr_out[((int64_t)s * GN_GROUPS + gi) * 2] = s_mr[0];
+      mr_out[((int64_t)s * GN_GROUPS + gi) * 2 + 1] = s_mr[1];
+    }
+  }
+  __syncthreads();
+  if (tid < cpg) {
+    const int c = gi * cpg + tid;
+    float av = s_mr[1] * gamma[c];
+    float bv = beta[c] - s_mr[0] * av;
+    if (film) {
+      const float sc = 1.f + film[(int64_t)s * film_ld + c];
+      const float sh = film[(int64_t)s * film_ld + C + c];
+      av *= sc;
+      bv = bv * sc + sh;
+    }
+    a_out[(int64_t)s * C + c] = av;
+    b_out[(int64_t)s * C + c] = bv;
+  }
+}
+
+// GroupNorm32 fused affine from producer-side statistics: S contiguous slices of Tn rows (Tn % 64 == 0; slice s = records
+// [s Tn / 64, (s + 1) Tn / 64)), rec / rec_ld as written by mmd_conv_gemm_stats.  Outputs as mmd_gn_stats.
+extern "C" int mmd_gn_finalize_stats(const float* rec, int64_t rec_ld, int C, int S, int Tn, const float* gamma, const float* beta,
+                                     const float* film, int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out,
+                                     void* stream) {
+  MMD_REQUIRE(rec && gamma && beta && a_out && b_out, "gn_finalize_stats: null pointer");
+  MMD_REQUIRE(C > 0 && C % GN_GROUPS == 0 && C / GN_GROUPS <= 256 && rec_ld >= C, "gn_finalize_stats: bad channel count %d (ld %ld)", C, (long)rec_ld);
+  MMD_REQUIRE(S > 0 && Tn > 0 && Tn % 64 == 0, "gn_finalize_stats: slices must be multiples of 64 rows (S=%d Tn=%d)", S, Tn);
+  hipLaunchKernelGGL(gn_finalize_rec_kernel, dim3(GN_GROUPS, S), dim3(256), 0, (hipStream_t)stream, rec, rec_ld, C, S, Tn, gamma, beta,
+                     film, film_ld, eps, a_out, b_out, mr_out);
+  return mmd_check_launch("gn_finalize_stats");
+}
+
 extern "C" int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn,
                             int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
                             const float* b, int act, void* stream) {

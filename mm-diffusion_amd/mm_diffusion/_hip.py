@@ -38,6 +38,9 @@ _PROTOS = {
     "mmd_add_rowbias": (i32, [i32, vp, i64, i64, i32, i64, vp, i64, vp]),
     "mmd_conv_gemm": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_gn_conv1x1": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "mmd_conv_gemm_stats": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp, i64, vp]),
+    "mmd_gn_conv1x1_stats": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
+    "mmd_gn_finalize_stats": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp, vp, vp]),
     "mmd_attn_fwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, i64, i32, i64, i32, i32, vp, i32, vp]),
     "mmd_attn_small_fwd": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "mmd_resample": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
@@ -59,6 +62,7 @@ _PROTOS = {
     "mmd_ddim_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "mmd_lincomb_t": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "mmd_lincomb": (i32, [vp, f32, vp, f32, vp, f32, vp, i64, vp]),
+    "mmd_cast": (i32, [vp, i32, vp, i32, f32, i64, vp]),
     "mmd_ddpm_update_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "mmd_abs_quantile": (i32, [vp, i32, i64, f32, vp, vp]),
     "mmd_clamp_scale": (i32, [vp, vp, f32, i32, i64, vp]),

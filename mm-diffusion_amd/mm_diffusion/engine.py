@@ -12,6 +12,8 @@ Built once per (batch, dtype, device):
 Layout: video rows (n, f, h, w) x C, audio rows (n, l) x C; API-layout conversion happens only inside the
 stem (InitialBlock) and head kernels.
 """
+import os
+
 import torch
 
 from . import _hip as H
@@ -62,6 +64,9 @@ class UNetEngine:
                 raise H.MMDError(f"parameter {k} is on {v.device}: move the model to the GPU first (model.to('cuda'))")
         self._sig = self._signature()
         self.pools = [_Pool(self.device), _Pool(self.device)]   # one per launch stream (video / audio run concurrently)
+        # GroupNorm statistics from the producer GEMM's epilogue (bf16 mode; MMD_GN_EPILOGUE=0 restores the statistics pass: A/B runs)
+        self.rec_enabled = dtype == torch.bfloat16 and os.environ.get("MMD_GN_EPILOGUE", "1") != "0"
+        self._recs = {}
         H.reap()
         self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
         self.aux = self._aux.torch          # audio-chain launches
@@ -79,20 +84,59 @@ class UNetEngine:
         return self._sig != self._signature()
 
     # ------------------------------------------------------------------ helpers
-    def _alloc(self, rows, C, dtype=None):
+    def _alloc(self, rows, C, dtype=None, stats=False, unit=64):
+        """stats: the tensor is written by GEMMs only and normalised by a GroupNorm afterwards -> give it a record buffer for the
+        producers' epilogue statistics (mmd_conv_gemm_stats); unit = rows of the smallest slice a consumer norm will use."""
         dtype = dtype or self.dtype
         es = torch.empty(0, dtype=dtype).element_size()
         pool = self.pools[ops.cur_sid]
         raw = pool.get(rows * C * es)
         t = raw[: rows * C * es].view(dtype).view(rows, C)
         t._raw, t._pool = raw, pool
+        if stats and self.rec_enabled and rows % 64 == 0 and unit % 64 == 0:
+            rec = self._alloc(rows // 64, 2 * C, torch.float32)
+            self._recs[raw.untyped_storage().data_ptr()] = dict(rec=rec, view=rec.view(rows // 64, C, 2), ptr=t.data_ptr(), es=es,
+                                                                rows=rows, C=C, cover=[])
         return t
 
     def _release(self, *ts):
         for t in ts:
             if t is not None and hasattr(t, "_raw"):
+                ent = self._recs.pop(t._raw.untyped_storage().data_ptr(), None)
+                if ent is not None:
+                    self._release(ent["rec"])
                 t._pool.put(t._raw)
                 del t._raw
+
+    # ------------------------------------------------------------------ producer-side GroupNorm statistics
+    def _rec_slice(self, t):
+        """(registry entry, first column) of a tensor that lives in a buffer with a record buffer, else (None, 0)."""
+        ent = self._recs.get(t.untyped_storage().data_ptr())
+        if ent is None or t.stride(0) != ent["C"] or t.shape[0] != ent["rows"]:
+            return None, 0
+        c0 = (t.data_ptr() - ent["ptr"]) // ent["es"]
+        return (ent, c0) if 0 <= c0 and c0 + t.shape[1] <= ent["C"] else (None, 0)
+
+    def _stats_for(self, out):
+        """The record view a GEMM writing `out` should fill (None: the buffer has no record buffer)."""
+        ent, c0 = self._rec_slice(out)
+        if ent is None:
+            return None
+        ent["cover"].append((c0, c0 + out.shape[1]))
+        return ent["view"][:, c0:c0 + out.shape[1], :]
+
+    def _rec_ready(self, x, geom):
+        """The record view a GroupNorm over x can finalize from: every column of x written by a statistics-emitting GEMM, contiguous
+        slices that are multiples of 64 rows.  None -> the classic statistics pass."""
+        ent, c0 = self._rec_slice(x)
+        if ent is None or geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn % 64 or geom.S * geom.Tn != x.shape[0]:
+            return None
+        need, pos = c0 + x.shape[1], c0
+        for lo, hi in sorted(ent["cover"]):
+            if lo > pos:
+                break
+            pos = max(pos, hi)
+        return ent["view"][:, c0:need, :] if pos >= need else None
 
     def _static(self, shape, dtype):
         t = torch.zeros(shape, dtype=dtype, device=self.device)
@@ -132,15 +176,27 @@ class UNetEngine:
     def _gn(self, x, prefix, geom, act, film=None, out=None):
         """GroupNorm32(+FiLM)(+SiLU): stats -> fused affine -> apply.  Returns the normalised tensor."""
         C = x.shape[1]
-        a = self._alloc(geom.S, C, torch.float32)
-        b = self._alloc(geom.S, C, torch.float32)
-        ws = self._alloc(ops.gn_workspace_bytes(x, geom) // 8, 1, torch.float64)
-        ops.gn_stats(x, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), geom,
-                     film=film, a=a, b=b, ws=ws)
+        a, b = self._gn_affine(x, prefix, geom, film)
         y = self._alloc(x.shape[0], C) if out is None else out
         ops.gn_apply(x, a, b, geom, act=act, out=y)
-        self._release(a, b, ws)
+        self._release(a, b)
         return y
+
+    def _gn_affine(self, x, prefix, geom, film):
+        """Fused per-(slice, channel) affine of GroupNorm32(+FiLM): from the producers' epilogue statistics when x has them, else
+        by the statistics pass over x."""
+        C = x.shape[1]
+        a = self._alloc(geom.S, C, torch.float32)
+        b = self._alloc(geom.S, C, torch.float32)
+        gamma, beta = self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias")
+        rec = self._rec_ready(x, geom)
+        if rec is not None:
+            ops.gn_finalize_stats(rec, gamma, beta, geom, film=film, a=a, b=b)
+        else:
+            ws = self._alloc(ops.gn_workspace_bytes(x, geom) // 8, 1, torch.float64)
+            ops.gn_stats(x, gamma, beta, geom, film=film, a=a, b=b, ws=ws)
+            self._release(ws)
+        return a, b
 
     def _gn_pw(self, x, gn_prefix, geom, act, wkey, bkey, film=None, residual=None, out=None):
         """GroupNorm32(+FiLM)(+SiLU) -> 1x1 conv with the normalisation applied inside the GEMM loader."""
@@ -153,19 +209,15 @@ class UNetEngine:
             y = self._pw(n1, wkey, bkey, residual=residual, out=out)
             self._release(n1)
             return y
-        a = self._alloc(geom.S, C, torch.float32)
-        b = self._alloc(geom.S, C, torch.float32)
-        ws = self._alloc(ops.gn_workspace_bytes(x, geom) // 8, 1, torch.float64)
-        ops.gn_stats(x, self._f32(gn_prefix + ".GroupNorm.weight"), self._f32(gn_prefix + ".GroupNorm.bias"), geom,
-                     film=film, a=a, b=b, ws=ws)
+        a, b = self._gn_affine(x, gn_prefix, geom, film)
         y = self._alloc(x.shape[0], Cout) if out is None else out
-        ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y)
-        self._release(a, b, ws)
+        ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, stats=self._stats_for(y))
+        self._release(a, b)
         return y
 
     def _pw(self, x, wkey, bkey, residual=None, out=None):
         y = self._alloc(x.shape[0], self.params[wkey].shape[0]) if out is None else out
-        return ops.conv_gemm(x, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y)
+        return ops.conv_gemm(x, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, stats=self._stats_for(y))
 
     # ------------------------------------------------------------------ blocks
     def _self_attn(self, x, prefix, kind, Hh, out):
@@ -209,19 +261,24 @@ class UNetEngine:
         def stream(x, mod, rows_in, rows_out, out):
             vid = mod == "video"
             t0 = self._gn(x, f"{p}.{mod}_in_layers.0", Geom.per_sample(N, rows_in // N), act=True)
+            # h feeds the out_layers GroupNorm directly unless it is resampled first (up / down blocks) or shifted by the embedding
+            # (non-FiLM blocks): then its producer's epilogue statistics would describe a different tensor
+            hstats = fh == 1 and ss
             if vid:
                 t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
                                    self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,
                                    dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
                 self._release(t0)
-                h = ops.conv_gemm(t1, self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight"),
-                                  self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), **self._temporal(Hh),
-                                  out=self._alloc(rows_in, cout))
+                h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
+                ops.conv_gemm(t1, self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight"),
+                              self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), **self._temporal(Hh),
+                              out=h, stats=self._stats_for(h))
                 self._release(t1)
             else:
-                h = ops.conv_gemm(t0, self._gemm_w(f"{p}.audio_in_layers.2.audio_conv.weight"),
-                                  self._f32(f"{p}.audio_in_layers.2.audio_conv.bias"), taps=ops.taps_audio(layer["dilation"]),
-                                  dims=(L, 1, 1), out=self._alloc(rows_in, cout))
+                h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
+                ops.conv_gemm(t0, self._gemm_w(f"{p}.audio_in_layers.2.audio_conv.weight"),
+                              self._f32(f"{p}.audio_in_layers.2.audio_conv.bias"), taps=ops.taps_audio(layer["dilation"]),
+                              dims=(L, 1, 1), out=h, stats=self._stats_for(h))
                 self._release(t0)
             xs = x
             if fh != 1:        # conv at the input resolution, THEN resample both h and x (unet:441-448)
@@ -243,7 +300,9 @@ class UNetEngine:
             else:
                 sk = xs
             attn_here = layer["vattn"] if vid else layer["aattn"]
-            dest = self._alloc(rows_out, cout) if (attn_here or out is None) else out
+            # consumer of dest: the spatial-attention norm (per-frame slices), the audio-attention norm or the next block's norm (per sample)
+            dest = self._alloc(rows_out, cout, stats=True, unit=(Ho * Ho if (attn_here and vid) else rows_out // N)) \
+                if (attn_here or out is None) else out
             self._gn_pw(h, f"{p}.{mod}_out_layers.0", geom, True, f"{p}.{mod}_out_layers.3.{conv}.weight",
                         f"{p}.{mod}_out_layers.3.{conv}.bias", film=film if ss else None, residual=sk, out=dest)
             self._release(h)
@@ -255,11 +314,11 @@ class UNetEngine:
                 if vid:
                     mid = self._self_attn(dest, p + ".spatial_attention_block", "spatial", Ho, self._alloc(rows_out, cout))
                     self._release(dest)
-                    fin = out if out is not None else self._alloc(rows_out, cout)
+                    fin = out if out is not None else self._alloc(rows_out, cout, stats=True, unit=rows_out // N)
                     self._self_attn(mid, p + ".temporal_attention_block", "temporal", Ho, fin)
                     self._release(mid)
                 else:
-                    fin = out if out is not None else self._alloc(rows_out, cout)
+                    fin = out if out is not None else self._alloc(rows_out, cout, stats=True, unit=rows_out // N)
                     self._self_attn(dest, p + ".audio_attention_block", "audio", Ho, fin)
                     self._release(dest)
                 dest = fin
@@ -298,11 +357,11 @@ class UNetEngine:
         ops.record_sync(1, 0)
         self._release(vqkv, aqkv)
         ops.cur_sid = 0
-        vo = out_v if out_v is not None else self._alloc(N * F * HW, C)
+        vo = out_v if out_v is not None else self._alloc(N * F * HW, C, stats=True, unit=F * HW)
         self._pw(vatt, p + ".video_proj_out.video_conv.weight", p + ".video_proj_out.video_conv.bias", residual=v, out=vo)
         self._release(vatt)
         ops.cur_sid = 1
-        ao = out_a if out_a is not None else self._alloc(N * L, C)
+        ao = out_a if out_a is not None else self._alloc(N * L, C, stats=True, unit=L)
         self._pw(aatt, p + ".audio_proj_out.audio_conv.weight", p + ".audio_proj_out.audio_conv.bias", residual=a, out=ao)
         self._release(aatt)
         ops.cur_sid, ops.cur_tag = 0, ""
@@ -383,9 +442,9 @@ class UNetEngine:
                 if layer["kind"] == "res" and layer["down"]:
                     Ho, Lo = Hh // 2, L // 4
             ops.cur_sid = 0
-            vcat = self._alloc(N * F * Ho * Ho, chp + ich)
+            vcat = self._alloc(N * F * Ho * Ho, chp + ich, stats=True, unit=F * Ho * Ho)
             ops.cur_sid = 1
-            acat = self._alloc(N * Lo, chp + ich)
+            acat = self._alloc(N * Lo, chp + ich, stats=True, unit=Lo)
             ops.cur_sid = 0
             cat_bufs.append((vcat, acat))
             ov, oa = vcat[:, chp:], acat[:, chp:]
@@ -399,9 +458,10 @@ class UNetEngine:
                     ops.stem_conv(self.x_video, self._edge_w(p + ".video_conv.video_conv_spatial.weight"),
                                   self._f32(p + ".video_conv.video_conv_spatial.bias"), s1, N, F, self.Cv_in, Hh, Hh,
                                   ops.TAPS_SPATIAL)
-                    nv = ops.conv_gemm(s1, self._gemm_w(p + ".video_conv.video_conv_temporal.weight"),
-                                       self._f32(p + ".video_conv.video_conv_temporal.bias"), **self._temporal(Hh),
-                                       out=tv if tv is not None else self._alloc(N * F * Hh * Hh, C0))
+                    nv = tv if tv is not None else self._alloc(N * F * Hh * Hh, C0, stats=True, unit=F * Hh * Hh)
+                    ops.conv_gemm(s1, self._gemm_w(p + ".video_conv.video_conv_temporal.weight"),
+                                  self._f32(p + ".video_conv.video_conv_temporal.bias"), **self._temporal(Hh), out=nv,
+                                  stats=self._stats_for(nv))
                     self._release(s1)
                     ops.cur_sid = 1
                     na = ta if ta is not None else self._alloc(N * L, C0)

@@ -119,6 +119,20 @@ def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None, mr=
     return a, b
 
 
+def gn_finalize_stats(rec, gamma, beta, geom: Geom, film=None, a=None, b=None, mr=None):
+    """The fused GroupNorm affine from producer-side statistics (include/mmd.h: mmd_gn_finalize_stats): rec = fp32 view
+    [rows / 64, C, 2] over exactly the channels of the normalised tensor; S contiguous slices of Tn rows."""
+    C = rec.shape[1]
+    if geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn % 64 or rec.shape[0] * 64 != geom.S * geom.Tn:
+        raise H.MMDError("gn_finalize_stats: needs contiguous slices that are multiples of 64 rows")
+    a = torch.empty(geom.S, C, dtype=torch.float32, device=rec.device) if a is None else a
+    b = torch.empty(geom.S, C, dtype=torch.float32, device=rec.device) if b is None else b
+    _dispatch("mmd_gn_finalize_stats", rec.data_ptr(), rec.stride(0) // 2, C, geom.S, geom.Tn, gamma.data_ptr(), beta.data_ptr(),
+              H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), H.ptr(mr),
+              meta=(f"gn_finalize_stats[S={geom.S},Tn={geom.Tn},C={C}]", 0, rec.shape[0] * C * 8))
+    return a, b
+
+
 def gn_apply(x, a, b, geom: Geom, act=True, out=None):
     _chk2d(x)
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
@@ -215,8 +229,16 @@ def halo_tile_ok(x, taps, dims):
             and dims[2] % 16 == 0 and dims[0] * dims[1] * dims[2] == M and Cin % (128 // x.element_size()) == 0)
 
 
-def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0):
-    """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None."""
+def _stats_args(stats, M, Cout):
+    """stats: fp32 view [M / 64, Cout, 2] (a column slice of the output's record buffer) -> (pointer, row stride in float2)."""
+    if stats.dtype != torch.float32 or tuple(stats.shape) != (M // 64, Cout, 2) or M % 64 or stats.stride(1) != 2 or stats.stride(2) != 1:
+        raise H.MMDError(f"GEMM output statistics: expected an fp32 [M/64, Cout, 2] view, got {tuple(stats.shape)} strides {stats.stride()}")
+    return stats.data_ptr(), stats.stride(0) // 2
+
+
+def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None):
+    """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None.  stats (optional): record view that receives
+    the GroupNorm statistics of the output (include/mmd.h: mmd_conv_gemm_stats)."""
     _chk2d(x)
     M, Cin = x.shape
     Cout = w.shape[0]
@@ -230,13 +252,16 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, nt, arr,
             int(dims[0]), int(dims[1]), int(dims[2]))
     if tile == 0:
-        cands = (64, 128, 129) + ((130,) if HALO_CANDIDATE and halo_tile_ok(x, taps, dims) else ())
+        cands = (64, 128, 129) + ((130,) if HALO_CANDIDATE and stats is None and halo_tile_ok(x, taps, dims) else ())
         tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False, tuple(dims) if 130 in cands else None),
                           lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout, cands, out=out, scratch=(x, residual))
     flops = 2 * M * Cout * Cin * nt
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
-    _dispatch("mmd_conv_gemm", *base, tile,
-           meta=(f"conv_gemm<{'bf16' if es == 2 else 'f32'},{'128glds' if tile == 129 else ('128halo' if tile == 130 else tile)}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
+    label = f"conv_gemm<{'bf16' if es == 2 else 'f32'},{'128glds' if tile == 129 else ('128halo' if tile == 130 else tile)}>[M={M},K={Cin * nt},N={Cout}]"
+    if stats is not None:
+        _dispatch("mmd_conv_gemm_stats", *base, tile, *_stats_args(stats, M, Cout), meta=(label, flops, nbytes))
+    else:
+        _dispatch("mmd_conv_gemm", *base, tile, meta=(label, flops, nbytes))
     return out
 
 
@@ -246,7 +271,7 @@ def gn_fusable(geom: Geom, Cin, Cout):
             and (Cout + 127) // 128 <= 2)
 
 
-def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=0):
+def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=0, stats=None):
     """1x1 conv of GroupNorm'd rows with the normalisation fused into the GEMM loader (include/mmd.h: mmd_gn_conv1x1)."""
     _chk2d(x)
     M, Cin = x.shape
@@ -266,8 +291,11 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
                           lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout, candidates=(64, 128), out=out,
                           scratch=(x, residual, a, b))
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
-    _dispatch("mmd_gn_conv1x1", *base, tile,
-              meta=(f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes))
+    meta = (f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes)
+    if stats is not None:
+        _dispatch("mmd_gn_conv1x1_stats", *base, tile, *_stats_args(stats, M, Cout), meta=meta)
+    else:
+        _dispatch("mmd_gn_conv1x1", *base, tile, meta=meta)
     return out
 
 
@@ -554,3 +582,12 @@ def pack_edge_weight(w: torch.Tensor) -> torch.Tensor:
     """[Cout, Cin, *k] -> fp32 [ntaps, Cin, Cout] for the stem / head kernels."""
     Cout, Cin = w.shape[0], w.shape[1]
     return w.reshape(Cout, Cin, -1).permute(2, 1, 0).float().contiguous()
+
+
+def cast(x, out, scale=1.0):
+    """out = (out.dtype)(x * scale), fp32 <-> bf16 flat buffers (include/mmd.h: mmd_cast)."""
+    H.require_cuda(x, out)
+    if x.numel() != out.numel() or not x.is_contiguous() or not out.is_contiguous():
+        raise H.MMDError("cast: contiguous buffers of equal length expected")
+    _dispatch("mmd_cast", x.data_ptr(), H.dt_of(x), out.data_ptr(), H.dt_of(out), float(scale), x.numel())
+    return out

@@ -27,6 +27,10 @@ def _grad_slot(*params):
         g = p.grad
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not p.requires_grad:
             return None
+    for p in params:                # bucketed gradient reduction (optim.FlatAdamW.arm_overlap): this parameter's kernel comes next
+        o = getattr(p, "_mmd_opt", None)
+        if o is not None:
+            o[0]._param_done(o[1])
     return [p.grad for p in params]
 
 

@@ -109,3 +109,58 @@ def test_gloo_world2_training_collectives():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, True), (1, True, True)]
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mm-diffusion_amd"))
+    from mm_diffusion import dist_util
+    from mm_diffusion.optim import FlatAdamW
+    dist_util.setup_dist(backend="gloo")
+    shapes = [(7, 3), (5,), (16, 4), (9,), (3, 3, 3), (11,), (2, 8)]
+    res = []
+    for buckets, overlap in ((1, False), (3, False), (3, True), (7, True)):
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+        opt = FlatAdamW(params, lr=1e-3, grad_buckets=buckets)
+        assert 1 <= len(opt.buckets) <= min(buckets, len(params)) and opt.buckets[0][0] == 0 and opt.buckets[-1][1] == opt.grad.numel()
+        assert sum(b[2] for b in opt.buckets) == len(params) and all(a[1] == b[0] for a, b in zip(opt.buckets, opt.buckets[1:]))
+        assert buckets == 1 or len(opt.buckets) > 1
+        g = torch.Generator().manual_seed(100 + rank)
+        opt.grad.copy_(torch.randn(opt.grad.numel(), generator=g))
+        expect = opt.grad.clone()
+        dist.all_reduce(expect, op=dist.ReduceOp.SUM)              # the single flat all-reduce the bucketed one must equal bitwise
+        expect.div_(world)
+        if overlap:
+            opt.arm_overlap()
+            for i in reversed(range(len(params))):                 # backward order: last parameter first
+                opt._param_done(i)
+            launched_early = len(opt._inflight)
+        else:
+            launched_early = 0
+        opt.all_reduce_grads()
+        res.append((torch.equal(opt.grad, expect), launched_early == (len(opt.buckets) - 1 if overlap else 0)))
+        assert not opt._inflight and not opt._armed
+    dist.barrier()
+    q.put((rank, [r[0] for r in res], [r[1] for r in res]))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_bucketed_gradient_allreduce_equals_flat():
+    """FlatAdamW gradient buckets (1 / 3 / 7, with and without the overlap protocol driven in backward order): bitwise the result of ONE
+    all-reduce of the flat buffer; with overlap armed every bucket but the first-parameter one is in flight before all_reduce_grads()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, oks, early in res:
+        assert oks == [True, True, True, True]
+        assert early == [True] * 4            # armed: every bucket but the last-completing one (first parameters) was in flight early

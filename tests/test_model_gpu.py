@@ -148,3 +148,22 @@ def test_batch_sharding_is_exact():
         vo, ao = model(video.cuda(), audio.cuda(), t.cuda())
         parts = [model(video[i:i + 2].cuda(), audio[i:i + 2].cuda(), t[i:i + 2].cuda()) for i in (0, 2)]
     assert torch.equal(vo, torch.cat([p[0] for p in parts])) and torch.equal(ao, torch.cat([p[1] for p in parts]))
+
+
+def test_epilogue_statistics_do_not_change_the_forward(monkeypatch):
+    """bf16 plan with GroupNorm statistics taken from the producer GEMMs' epilogues (default) vs the statistics pass over every tensor
+    (MMD_GN_EPILOGUE=0): same network output up to the fp32 summation order inside the statistics."""
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MMD_GN_EPILOGUE", flag)
+        fl, model, _ = build("mid", "tiny", torch.bfloat16)
+        video, audio = inputs(fl, 2, 5)
+        model.shift_source = lambda lo, hi: min(1, hi)
+        with torch.no_grad():
+            outs[flag] = model(video.cuda(), audio.cuda(), torch.tensor([7, 800]).cuda())
+        eng = next(iter(model._engines.values()))
+        names = [e[2] for e in eng.plan if e[0] is not None]
+        assert ("mmd_gn_finalize_stats" in names) == (flag == "1")
+    ev, ea = rel_l2(outs["1"][0].cpu(), outs["0"][0].cpu().numpy()), rel_l2(outs["1"][1].cpu(), outs["0"][1].cpu().numpy())
+    print(f"epilogue statistics vs statistics pass: rel-L2 video {ev:.2e} audio {ea:.2e}")
+    assert ev < 5e-3 and ea < 5e-3

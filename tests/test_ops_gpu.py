@@ -119,6 +119,70 @@ def test_halo_tile_variant_temporal_form(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("tile", [64, 128, 129])
+@pytest.mark.parametrize("M,Cin,Cout,taps3,res", [(256, 64, 96, False, True), (1024, 128, 128, True, False), (192, 256, 264, False, False)])
+def test_gemm_epilogue_statistics(ops, dt, tile, M, Cin, Cout, taps3, res):
+    """mmd_conv_gemm_stats: per (64-row record, column) sum and sum of squares of the values AS STORED, written into a column slice of a
+    wider record buffer; the output itself is bitwise the plain kernel's."""
+    g = torch.Generator(device="cuda").manual_seed(M + Cout)
+    taps, dims = (ops.TAPS_TEMPORAL, (4, M // 4, 1)) if taps3 else (ops.TAPS_1, (1, 1, 1))
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(dt)
+    w = (torch.randn(Cout, Cin * len(taps), device="cuda", generator=g) * (Cin * len(taps)) ** -0.5).to(dt)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(M, Cout, device="cuda", generator=g).to(dt) if res else None
+    y0 = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile)
+    wide = torch.full((M // 64, Cout + 40, 2), 7.0, device="cuda")
+    y1 = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile, stats=wide[:, 24:24 + Cout, :])
+    assert torch.equal(y0, y1)
+    yf = y1.double().view(M // 64, 64, Cout)
+    ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
+    got = wide[:, 24:24 + Cout, :].double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert float((wide[:, :24] - 7).abs().max()) == 0 and float((wide[:, 24 + Cout:] - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("S,Tn,C,film", [(4, 256, 128, True), (2, 1024, 64, False), (8, 64, 512, True)])
+def test_gn_finalize_from_producer_statistics(ops, S, Tn, C, film):
+    """mmd_gn_finalize_stats (affine from the producer GEMM's records) against mmd_gn_stats (statistics pass over the tensor)."""
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(S * Tn)
+    x = (torch.randn(S * Tn, C, device="cuda", generator=g) * 1.7 + 0.6).to(dt)
+    gamma, beta = torch.randn(C, device="cuda", generator=g), torch.randn(C, device="cuda", generator=g)
+    fm = torch.randn(S, 2 * C, device="cuda", generator=g) * 0.3 if film else None
+    geom = ops.Geom.per_sample(S, Tn)
+    a0, b0 = ops.gn_stats(x, gamma, beta, geom, film=fm)
+    xf = x.float().view(S * Tn // 64, 64, C)
+    rec = torch.zeros(S * Tn // 64, C + 16, 2, device="cuda")
+    rec[:, 8:8 + C, 0], rec[:, 8:8 + C, 1] = xf.sum(1), (xf * xf).sum(1)
+    a1, b1 = ops.gn_finalize_stats(rec[:, 8:8 + C, :], gamma, beta, geom, film=fm)
+    assert rel_l2(a1.cpu(), a0.cpu().numpy()) < 1e-5 and rel_l2(b1.cpu(), b0.cpu().numpy()) < 1e-5
+
+
+def test_gn_conv1x1_statistics_feed_the_next_norm(ops):
+    """Chain as in a ResBlock tail: gn_conv1x1 (+ residual) emits the statistics of its output; the next norm's affine built from them
+    equals the one from a statistics pass over the stored output."""
+    dt = torch.bfloat16
+    S, Tn, Cin, Cout = 2, 512, 128, 128
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn(S * Tn, Cin, device="cuda", generator=g).to(dt)
+    w = (torch.randn(Cout, Cin, device="cuda", generator=g) * Cin ** -0.5).to(dt)
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(S * Tn, Cout, device="cuda", generator=g).to(dt)
+    gamma, beta = torch.randn(Cin, device="cuda", generator=g), torch.randn(Cin, device="cuda", generator=g)
+    geom = ops.Geom.per_sample(S, Tn)
+    a, b = ops.gn_stats(x, gamma, beta, geom)
+    for tile in (64, 128):
+        rec = torch.zeros(S * Tn // 64, Cout, 2, device="cuda")
+        y = ops.gn_conv1x1(x, a, b, geom, True, w, bias, residual=r, tile=tile, stats=rec)
+        y0 = ops.gn_conv1x1(x, a, b, geom, True, w, bias, residual=r, tile=tile)
+        assert torch.equal(y, y0)
+        g2, b2 = torch.randn(Cout, device="cuda", generator=g), torch.randn(Cout, device="cuda", generator=g)
+        an, bn = ops.gn_finalize_stats(rec, g2, b2, geom)
+        ar, br = ops.gn_stats(y, g2, b2, geom)
+        assert rel_l2(an.cpu(), ar.cpu().numpy()) < 1e-5 and rel_l2(bn.cpu(), br.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_strided_views(ops, dt):
     """Input, residual and output as column slices of wider buffers (free skip-concat views)."""
     M, Cin, Cout = 200, 64, 64
