@@ -150,20 +150,29 @@ def test_batch_sharding_is_exact():
     assert torch.equal(vo, torch.cat([p[0] for p in parts])) and torch.equal(ao, torch.cat([p[1] for p in parts]))
 
 
-def test_epilogue_statistics_do_not_change_the_forward(monkeypatch):
-    """bf16 plan with GroupNorm statistics taken from the producer GEMMs' epilogues (default) vs the statistics pass over every tensor
-    (MMD_GN_EPILOGUE=0): same network output up to the fp32 summation order inside the statistics."""
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_epilogue_statistics_do_not_change_the_forward(monkeypatch, dt):
+    """GroupNorm statistics taken from the producer GEMMs' epilogues vs the statistics pass over every tensor (MMD_GN_EPILOGUE=0).
+    fp32 mode (epilogue statistics forced with =2): same output to 1e-4 - the mechanism is exact up to fp32 summation order.  bf16 mode
+    (the default): the two plans round differently, so they sit a bf16 noise floor apart (each is within 3e-2 of the fp32 reference,
+    test_forward_matches_reference) - bound 3e-2."""
     outs = {}
-    for flag in ("1", "0"):
+    for flag in ("2" if dt == torch.float32 else "1", "0"):
         monkeypatch.setenv("MMD_GN_EPILOGUE", flag)
-        fl, model, _ = build("mid", "tiny", torch.bfloat16)
+        fl, model, _ = build("mid", "tiny", dt)
         video, audio = inputs(fl, 2, 5)
         model.shift_source = lambda lo, hi: min(1, hi)
         with torch.no_grad():
             outs[flag] = model(video.cuda(), audio.cuda(), torch.tensor([7, 800]).cuda())
         eng = next(iter(model._engines.values()))
         names = [e[2] for e in eng.plan if e[0] is not None]
-        assert ("mmd_gn_finalize_stats" in names) == (flag == "1")
-    ev, ea = rel_l2(outs["1"][0].cpu(), outs["0"][0].cpu().numpy()), rel_l2(outs["1"][1].cpu(), outs["0"][1].cpu().numpy())
-    print(f"epilogue statistics vs statistics pass: rel-L2 video {ev:.2e} audio {ea:.2e}")
-    assert ev < 5e-3 and ea < 5e-3
+        assert ("mmd_gn_finalize_stats" in names) == (flag != "0")
+        if flag != "0":
+            n_fin, n_pass = names.count("mmd_gn_finalize_stats"), names.count("mmd_gn_stats")
+            print(f"{dt}: {n_fin} norms finalized from epilogue statistics, {n_pass} by a statistics pass")
+            assert n_fin > n_pass
+    a, b = [v for k, v in outs.items() if k != "0"][0], outs["0"]
+    ev, ea = rel_l2(a[0].cpu(), b[0].cpu().numpy()), rel_l2(a[1].cpu(), b[1].cpu().numpy())
+    print(f"epilogue statistics vs statistics pass ({dt}): rel-L2 video {ev:.2e} audio {ea:.2e}")
+    tol = 1e-4 if dt == torch.float32 else 3e-2
+    assert ev < tol and ea < tol
