@@ -20,6 +20,8 @@ class conditioning, `use_new_attention_order` is accepted (it only changes the p
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -137,6 +139,7 @@ class ImageUnet(nn.Module):
         self.out.put(0, _Affine((ch,), "norm")), self.out.put(1, nn.Identity()), self.out.put(2, _Affine((out_channels, input_ch, 3, 3), zero=True))
         self._plan = (plan_in, plan_mid, plan_out)
         self._packed = None
+        self._graphs = {}
 
     # ------------------------------------------------------------------ reference surface
     def convert_to_fp16(self):
@@ -218,14 +221,14 @@ class ImageUnet(nn.Module):
         if updown is not None:
             Ho = Hh // 2 if updown == "down" else Hh * 2
             mode = 0 if updown == "down" else 1
-            h2 = torch.empty(N * Ho * Ho, cin, dtype=x.dtype, device=x.device)
-            x2 = torch.empty(N * Ho * Ho, cin, dtype=x.dtype, device=x.device)
+            h2 = ops.alloc(N * Ho * Ho, cin, dtype=x.dtype, device=x.device)
+            x2 = ops.alloc(N * Ho * Ho, cin, dtype=x.dtype, device=x.device)
             ops.resample(h, h2, N, Hh, Hh, 2, 2, mode)
             ops.resample(x, x2, N, Hh, Hh, 2, 2, mode)
             h, x, Hh = h2, x2, Ho
             geom = Geom.per_sample(N, Hh * Hh)
         h = ops.conv_gemm(h, w["w_in"], w["b_in"], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh))
-        emb_out = torch.empty(N, w["w_e"].shape[0], dtype=torch.float32, device=x.device)
+        emb_out = ops.alloc(N, w["w_e"].shape[0], dtype=torch.float32, device=x.device)
         ops.linear(semb, w["w_e"], w["b_e"], emb_out)
         if self.use_scale_shift_norm:
             a, b = ops.gn_stats(h, w["g2"], w["b2"], geom, film=emb_out)
@@ -244,7 +247,7 @@ class ImageUnet(nn.Module):
         a, b = ops.gn_stats(x, w["g"], w["b"], geom)
         xn = ops.gn_apply(x, a, b, geom, act=False)
         qkv = ops.conv_gemm(xn, w["w_qkv"], w["b_qkv"])
-        att = torch.empty(N * T, C, dtype=x.dtype, device=x.device)
+        att = ops.alloc(N * T, C, dtype=x.dtype, device=x.device)
         ops.attn(qkv, qkv, att, heads, C // heads, N, 1, T, T, T, T, 1)
         return ops.conv_gemm(att, w["w_proj"], w["b_proj"], residual=x)
 
@@ -264,14 +267,14 @@ class ImageUnet(nn.Module):
         mc = self.model_channels
         te = W["time_embed"]
         # time_embed MLP (fp32), then SiLU: every emb_layers Sequential starts with SiLU (image_unet.py:176-182)
-        e0 = torch.empty(N, mc, dtype=torch.float32, device=dev)
+        e0 = ops.alloc(N, mc, dtype=torch.float32, device=dev)
         ops.timestep_embedding(timesteps.contiguous(), mc, e0)
-        e1 = torch.empty(N, 4 * mc, dtype=torch.float32, device=dev)
+        e1 = ops.alloc(N, 4 * mc, dtype=torch.float32, device=dev)
         ops.linear(e0, te[0], te[1], e1)
         ops.silu(e1, None, e1)
-        emb = torch.empty(N, 4 * mc, dtype=torch.float32, device=dev)
+        emb = ops.alloc(N, 4 * mc, dtype=torch.float32, device=dev)
         ops.linear(e1, te[2], te[3], emb)
-        semb = torch.empty_like(emb)
+        semb = ops.alloc(N, 4 * mc, dtype=torch.float32, device=dev)
         ops.silu(emb, None, semb)
         plan_in, plan_mid, plan_out = self._plan
         hs = []
@@ -279,7 +282,7 @@ class ImageUnet(nn.Module):
         for layers in plan_in:
             for L in layers:
                 if L[0] == "stem":
-                    h = torch.empty(N * Hh * Hh, L[3], dtype=dt, device=dev)
+                    h = ops.alloc(N * Hh * Hh, L[3], dtype=dt, device=dev)
                     ops.stem_conv(x6.float().contiguous().view(N, 1, Cin, Hh, Hh), W[L[1]][0], W[L[1]][1], h, N, 1, Cin, Hh, Hh, ops.TAPS_SPATIAL)
                 elif L[0] == "res":
                     h, Hh = self._res(h, semb, N, Hh, L, W)
@@ -290,7 +293,7 @@ class ImageUnet(nn.Module):
             h = self._res(h, semb, N, Hh, L, W)[0] if L[0] == "res" else self._attn(h, N, Hh, L, W)
         for layers in plan_out:
             skip = hs.pop()
-            cat = torch.empty(h.shape[0], h.shape[1] + skip.shape[1], dtype=dt, device=dev)       # th.cat([h, hs.pop()], dim=1)
+            cat = ops.alloc(h.shape[0], h.shape[1] + skip.shape[1], dtype=dt, device=dev)       # th.cat([h, hs.pop()], dim=1)
             ops.copy2d(h, cat[:, :h.shape[1]])
             ops.copy2d(skip, cat[:, h.shape[1]:])
             h = cat
@@ -303,13 +306,62 @@ class ImageUnet(nn.Module):
         geom = Geom.per_sample(N, Hh * Hh)
         a, bb = ops.gn_stats(h, g, b, geom)
         h = ops.gn_apply(h, a, bb, geom, act=True)
-        out = torch.empty(N, 1, self.out_channels, Hh, Hh, dtype=torch.float32, device=dev)
+        out = ops.alloc(N, 1, self.out_channels, Hh, Hh, dtype=torch.float32, device=dev)
         ops.head_conv(h, w_out, b_out, out, N, 1, Hh, Hh, ops.TAPS_SPATIAL)
         return out.view(N, self.out_channels, Hh, Hh)
 
     def forward(self, x, timesteps, y=None):
         assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
-        return self._run(x, timesteps)
+        return self._replay((x,), timesteps, lambda xs, t: self._run(xs[0], t))
+
+    # ------------------------------------------------------------------ graph replay of the no-grad forward
+    def _replay(self, inputs, timesteps, body):
+        """Run body(static inputs, static timesteps) -> fp32 output.  Under no_grad the launch sequence is recorded ONCE per input
+        geometry into a plan (ops.recording: per-shape tile autotune, every buffer parked in a keep-list) and captured into a hipGraph;
+        every later evaluation copies the inputs into the static buffers and replays the graph: ~700 ctypes launches and as many
+        torch.empty calls per evaluation become one launch (the SR stage runs 25-1000 evaluations per clip, sample_sr.py:186-253).
+        MMD_SR_GRAPH=0 keeps the eager launches."""
+        H.require_cuda(*inputs)
+        if torch.is_grad_enabled() or os.environ.get("MMD_SR_GRAPH", "1") == "0":
+            return body(tuple(t.float().contiguous() for t in inputs), timesteps.contiguous())
+        dev = inputs[0].device
+        if self._packed is None or self._packed[0] != str(dev) or self._packed[1] != self.dtype:
+            self._pack(dev)
+            self._drop_graphs()
+        key = (tuple(tuple(t.shape) for t in inputs), timesteps.dtype, self.dtype, str(dev))
+        g = self._graphs.get(key)
+        if g is None:
+            H.reap()
+            g = dict(ins=[torch.zeros(t.shape, dtype=torch.float32, device=dev) for t in inputs],
+                     t=torch.zeros(timesteps.shape, dtype=timesteps.dtype, device=dev), plan=[], keep=[], stream=H.Stream(dev))
+            with ops.recording(g["plan"], keep=g["keep"]):
+                g["out"] = body(tuple(g["ins"]), g["t"])
+            side = g["stream"].torch
+            side.wait_stream(torch.cuda.current_stream(dev))
+            ops.run_plan(g["plan"], side.cuda_stream)                   # warm-up: one-time function attributes, lazy module load
+            torch.cuda.synchronize(dev)
+            with H.capture(side.cuda_stream) as cap:
+                ops.run_plan(g["plan"], side.cuda_stream)
+            g["exec"] = cap.exec
+            self._graphs[key] = g
+        for dst, src in zip(g["ins"], inputs):
+            dst.copy_(src)
+        g["t"].copy_(timesteps)
+        H.call("mmd_graph_launch", g["exec"], H.stream_handle())
+        return g["out"].clone()
+
+    def _drop_graphs(self):
+        for g in getattr(self, "_graphs", {}).values():
+            if g.get("exec") is not None:
+                H.retire("graph", g["exec"])
+            g["stream"].close()
+        self._graphs = {}
+
+    def __del__(self):
+        try:
+            self._drop_graphs()
+        except Exception:
+            pass
 
 
 class ImageSuperResModel(ImageUnet):
@@ -321,8 +373,12 @@ class ImageSuperResModel(ImageUnet):
     def forward(self, x, timesteps, low_res=None, **kwargs):
         if low_res is None:
             raise MMDError("ImageSuperResModel.forward needs low_res")
-        H.require_cuda(x, low_res)
-        N, C, Hh, Ww = x.shape
-        x6 = torch.empty(N, 2 * C, Hh, Ww, dtype=torch.float32, device=x.device)
-        ops.bilinear_concat(x.float().contiguous(), low_res.float().contiguous(), x6)
-        return super().forward(x6, timesteps, **kwargs)
+        assert (kwargs.get("y") is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
+
+        def body(xs, t):
+            xx, low = xs
+            N, C, Hh, Ww = xx.shape
+            x6 = ops.alloc(N, 2 * C, Hh, Ww, dtype=torch.float32, device=xx.device)
+            ops.bilinear_concat(xx, low, x6)
+            return self._run(x6, t)
+        return self._replay((x, low_res), timesteps, body)

@@ -15,20 +15,31 @@ GN_EPS = 1e-5
 # When a recorder list is installed, ops append (cfunc, args, name) instead of launching: the engine replays
 # such a plan with `cfunc(*args, stream)` (every libmmd entry point takes the stream as its LAST argument).
 _recorder = None
+_keep = None        # recording(keep=[...]): every buffer an op allocates while recording is parked here (a plan holds raw pointers)
 
 
 class recording:
-    def __init__(self, plan):
-        self.plan = plan
+    def __init__(self, plan, keep=None):
+        self.plan, self.keep = plan, keep
 
     def __enter__(self):
-        global _recorder
-        self._prev, _recorder = _recorder, self.plan
+        global _recorder, _keep
+        self._prev, _recorder = (_recorder, _keep), self.plan
+        _keep = self.keep
         return self.plan
 
     def __exit__(self, *a):
-        global _recorder
-        _recorder = self._prev
+        global _recorder, _keep
+        _recorder, _keep = self._prev
+
+
+def alloc(*shape, dtype, device):
+    """torch.empty for op outputs / workspaces.  While a plan is being recorded with a keep-list the buffer is parked there: the
+    plan replays raw pointers, so everything it touches must outlive it (image_unet's graph-replayed forward)."""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if _keep is not None and _recorder is not None:
+        _keep.append(t)
+    return t
 
 
 cur_sid = 0      # launch stream of the ops being recorded: 0 = video/main stream, 1 = audio stream
@@ -104,14 +115,14 @@ def gn_workspace_bytes(x, geom: Geom):
 
 
 def gn_workspace(x, geom: Geom):
-    return torch.empty(gn_workspace_bytes(x, geom) // 8, dtype=torch.float64, device=x.device)
+    return alloc(gn_workspace_bytes(x, geom) // 8, dtype=torch.float64, device=x.device)
 
 
 def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None, mr=None):
     _chk2d(x)
     C = x.shape[1]
-    a = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if a is None else a
-    b = torch.empty(geom.S, C, dtype=torch.float32, device=x.device) if b is None else b
+    a = alloc(geom.S, C, dtype=torch.float32, device=x.device) if a is None else a
+    b = alloc(geom.S, C, dtype=torch.float32, device=x.device) if b is None else b
     ws = gn_workspace(x, geom) if ws is None else ws
     _dispatch("mmd_gn_stats", H.dt_of(x), x.data_ptr(), x.stride(0), C, *geom.args(), gamma.data_ptr(), beta.data_ptr(),
            H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), H.ptr(mr), ws.data_ptr(),
@@ -125,8 +136,8 @@ def gn_finalize_stats(rec, gamma, beta, geom: Geom, film=None, a=None, b=None, m
     C = rec.shape[1]
     if geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn % 64 or rec.shape[0] * 64 != geom.S * geom.Tn:
         raise H.MMDError("gn_finalize_stats: needs contiguous slices that are multiples of 64 rows")
-    a = torch.empty(geom.S, C, dtype=torch.float32, device=rec.device) if a is None else a
-    b = torch.empty(geom.S, C, dtype=torch.float32, device=rec.device) if b is None else b
+    a = alloc(geom.S, C, dtype=torch.float32, device=rec.device) if a is None else a
+    b = alloc(geom.S, C, dtype=torch.float32, device=rec.device) if b is None else b
     _dispatch("mmd_gn_finalize_stats", rec.data_ptr(), rec.stride(0) // 2, C, geom.S, geom.Tn, gamma.data_ptr(), beta.data_ptr(),
               H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, a.data_ptr(), b.data_ptr(), H.ptr(mr),
               meta=(f"gn_finalize_stats[S={geom.S},Tn={geom.Tn},C={C}]", 0, rec.shape[0] * C * 8))
@@ -135,7 +146,7 @@ def gn_finalize_stats(rec, gamma, beta, geom: Geom, film=None, a=None, b=None, m
 
 def gn_apply(x, a, b, geom: Geom, act=True, out=None):
     _chk2d(x)
-    out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
+    out = alloc(x.shape, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     _dispatch("mmd_gn_apply", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
            *geom.args(), a.data_ptr(), b.data_ptr(), 1 if act else 0,
@@ -217,8 +228,13 @@ def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129), out=None, scratc
     return best
 
 
-# tile 130 (halo-tile main loop for 3x3 / temporal-k3 convs) joins the autotune candidates only on request until it has been measured
-HALO_CANDIDATE = os.environ.get("MMD_GEMM_HALO") == "1"
+# tile 130 (halo-tile main loop for 3x3 / temporal-k3 convs).  Measured on MI355X (tools/gemm_bench.py, batch 4): 3x3 ds1 128->128
+# 119.7 -> 104.9 us, 256->128 190 -> 175, ds2 256->256 91 -> 86, ds4 tie.  Its K order is chunk-major, so it is NOT bitwise equal to
+# tiles 64 / 128 / 129: a timing-based choice would let the batch-4 and the batch-1 plan of the same layer differ in the last bit
+# (tests: batch rows == batch-1 runs, bitwise).  It is therefore chosen by the LAYER GEOMETRY alone (halo_tile_pinned), never by the
+# autotuner, unless MMD_GEMM_HALO=1 asks for the old experiment (candidate everywhere it is legal) or =0 switches it off.
+_HALO_MODE = os.environ.get("MMD_GEMM_HALO", "pin")
+HALO_CANDIDATE = _HALO_MODE == "1"
 
 
 def halo_tile_ok(x, taps, dims):
@@ -236,6 +252,13 @@ def _stats_args(stats, M, Cout):
     return stats.data_ptr(), stats.stride(0) // 2
 
 
+def halo_tile_pinned(x, taps, dims):
+    """The layers that always run on tile 130: spatial 3x3 convs on frames of >= 1024 pixels (ds1 / ds2 of the base model) - a property
+    of the layer, independent of the batch size."""
+    return (_HALO_MODE == "pin" and x.dtype == torch.bfloat16 and len(taps) == 9 and dims[1] * dims[2] >= 1024
+            and halo_tile_ok(x, taps, dims))
+
+
 def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None):
     """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None.  stats (optional): record view that receives
     the GroupNorm statistics of the output (include/mmd.h: mmd_conv_gemm_stats)."""
@@ -244,13 +267,15 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     Cout = w.shape[0]
     if w.dtype != x.dtype or w.shape[1] != len(taps) * Cin or not w.is_contiguous():
         raise H.MMDError(f"conv_gemm: weight {tuple(w.shape)} {w.dtype} does not match input {tuple(x.shape)} {x.dtype} x {len(taps)} taps")
-    out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     arr, nt = H.taps_array(taps)
     es = x.element_size()
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, nt, arr,
             int(dims[0]), int(dims[1]), int(dims[2]))
+    if tile == 0 and stats is None and halo_tile_pinned(x, taps, dims):
+        tile = 130
     if tile == 0:
         cands = (64, 128, 129) + ((130,) if HALO_CANDIDATE and stats is None and halo_tile_ok(x, taps, dims) else ())
         tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False, tuple(dims) if 130 in cands else None),
@@ -278,7 +303,7 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     Cout = w.shape[0]
     if w.dtype != x.dtype or w.shape[1] != Cin or not w.is_contiguous():
         raise H.MMDError(f"gn_conv1x1: weight {tuple(w.shape)} {w.dtype} does not match input {tuple(x.shape)} {x.dtype}")
-    out = torch.empty(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     es = x.element_size()
     if not gn_fusable(geom, Cin, Cout):

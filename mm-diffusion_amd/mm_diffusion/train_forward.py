@@ -152,8 +152,8 @@ def train_forward(model, video, audio, timesteps):
         as_.append(a)
     v, a, Hh, Ll = run_layers(arch_mid, v, a, Hh, Ll)
     for layers in arch_out:
-        v = torch.cat([v, vs.pop()], dim=1)
-        a = torch.cat([a, as_.pop()], dim=1)
+        v = T.CatFn.apply(v, vs.pop())
+        a = T.CatFn.apply(a, as_.pop())
         v, a, Hh, Ll = run_layers(layers, v, a, Hh, Ll)
 
     # ---- heads: GN -> SiLU -> conv (output channels padded to 8 for the GEMM, sliced back)

@@ -225,6 +225,32 @@ class CrossAttnFn(Function):
         return dv, da, None, None, None, None, None, None, None
 
 
+class CatFn(Function):
+    """[h | skip] along the channel axis of channels-last rows (the U-Net skip concat, unet:1093-1094) with libmmd copies: forward two
+    strided row copies into one buffer, backward two strided copies out of the gradient (the inference engine has no copy at all -
+    producers write column slices of the consumer's buffer; under autograd the concat is a node of the graph)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty(a.shape[0], a.shape[1] + b.shape[1], dtype=a.dtype, device=a.device)
+        ops.copy2d(a, out[:, :a.shape[1]])
+        ops.copy2d(b, out[:, a.shape[1]:])
+        ctx.ca = a.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ca = ctx.ca
+        g = g if g.stride(1) == 1 else g.contiguous()
+        ga = torch.empty(g.shape[0], ca, dtype=g.dtype, device=g.device) if ctx.needs_input_grad[0] else None
+        gb = torch.empty(g.shape[0], g.shape[1] - ca, dtype=g.dtype, device=g.device) if ctx.needs_input_grad[1] else None
+        if ga is not None:
+            ops.copy2d(g[:, :ca], ga)
+        if gb is not None:
+            ops.copy2d(g[:, ca:], gb)
+        return ga, gb
+
+
 class ResampleFn(Function):
     """avg-pool (mode 0) / nearest upsample (mode 1) by (1, fh, fw); the backward of one is the other, rescaled."""
 

@@ -85,7 +85,6 @@ def test_direct_to_lds_variants_agree(ops, dt, res, M, Cin, Cout, taps):
         assert torch.equal(y0, ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=129))
 
 
-@pytest.mark.skipif(os.environ.get("MMD_TEST_EXPERIMENTAL") != "1", reason="tile 130 (halo-tile 3x3 main loop) is opt-in until it has been measured")
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("res", [False, True])
 @pytest.mark.parametrize("D0,H,W,Cin,Cout", [(5, 16, 32, 64, 128), (3, 8, 16, 128, 96), (2, 24, 48, 192, 256 + 8)])
@@ -103,7 +102,6 @@ def test_halo_tile_variant(ops, dt, res, D0, H, W, Cin, Cout):
     assert rel_l2(y1.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
 
 
-@pytest.mark.skipif(os.environ.get("MMD_TEST_EXPERIMENTAL") != "1", reason="tile 130 (halo-tile main loop) is opt-in until it has been measured")
 @pytest.mark.parametrize("dt", DTYPES)
 def test_halo_tile_variant_temporal_form(ops, dt):
     """The temporal k=3 conv written as D = (N, F, HW), taps (0, +-1, 0): tile 130 against the (F, HW, 1) form on tile 129."""

@@ -62,6 +62,12 @@ def main():
         if den:
             traffic["conv_gemm<bf16,128glds>"] = num / den
         traffic["_source"] = f"{os.path.basename(out)}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of conv_gemm_glds_kernel<bf16,*>, rocprofv3 --pmc passes"
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        try:                                   # the build the passes were measured on: bench.py only accepts a matching file
+            import bench
+            traffic["build_id"] = bench.build_id()
+        except Exception as e:
+            traffic["build_id"] = f"unknown ({e})"
         json.dump(traffic, open(jout, "w"), indent=1)
 
 

@@ -1,19 +1,30 @@
 #!/bin/bash
-# One gpurun that regenerates everything under profiles/ for a round: GPU test suite, smoke, the bench lines of every mode,
-# rocprofv3 kernel trace and the two PMC passes of the default bench.  usage: gpurun -- 'bash tools/round_profile.sh <tag>'
+# One gpurun that regenerates everything under profiles/ for a round AT THE CURRENT BUILD: GPU test suite, smoke, the bench lines of every
+# mode, the rocprofv3 kernel trace, the two HBM PMC passes (-> profiles/pmc_traffic.json, stamped with the build id bench.py checks), the
+# SQ PMC passes (MFMA busy / wait / stall per kernel) and the final bench line that USES the fresh pmc_traffic.json.
+# usage: gpurun -- 'bash tools/round_profile.sh <tag>'      (the LAST GPU call of a round; no csrc/ commit after it)
 set -x
-TAG=${1:-f}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
-mkdir -p $O
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/pytest.txt
+mkdir -p $O profiles
+export PYTHONFAULTHANDLER=1
+timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest_full.txt 2>&1
+tail -3 $O/pytest_full.txt > $O/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
-timeout 600 python bench.py --breakdown-out $O/breakdown.json > $O/bench_default.log 2>&1
-timeout 400 python bench.py --mode dpm --batch 2 --steps 2 --warmup 1 > $O/bench_dpm.log 2>&1
-timeout 400 python bench.py --mode sr --batch 1 --steps 1 --warmup 1 > $O/bench_sr.log 2>&1
-timeout 400 python bench.py --mode train --batch 8 --steps 5 --warmup 2 > $O/bench_train.log 2>&1
-timeout 500 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-breakdown > $O/kt.log 2>&1
-timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-breakdown > $O/pmc_fetch.log 2>&1
-timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-breakdown > $O/pmc_write.log 2>&1
-timeout 500 rocprofv3 --kernel-trace --stats -d $O/kt_train -o kt -- python bench.py --mode train --batch 8 --steps 2 --warmup 1 --no-graph > $O/kt_train.log 2>&1
-tail -3 $O/pytest.txt; tail -1 $O/smoke.log
+B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-breakdown"
+timeout 500 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B > $O/kt.log 2>&1
+timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p -f csv -- $B > $O/pmc_fetch.log 2>&1
+timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p -f csv -- $B > $O/pmc_write.log 2>&1
+timeout 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $O/pmc_sq1 -o p -f csv -- $B > $O/pmc_sq1.log 2>&1
+timeout 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA --kernel-trace -d $O/pmc_sq2 -o p -f csv -- $B > $O/pmc_sq2.log 2>&1
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write profiles/${TAG}_pmc_hbm.txt profiles/pmc_traffic.json "$B"
+python tools/pmc_sq_summary.py profiles/${TAG}_pmc_sq.txt "$B" $O/pmc_sq1 $O/pmc_sq2
+python tools/rocprof_summary.py "$(find $O/kt -name '*.db' | head -1)" profiles/${TAG}_kernel_stats_default_bench.txt > /dev/null
+timeout 600 python bench.py --breakdown-out profiles/${TAG}_bench_breakdown_hip_events.json > $O/bench_default.log 2>&1
+tail -1 $O/bench_default.log > profiles/${TAG}_bench_line.json
+timeout 400 python bench.py --mode dpm --batch 2 --steps 2 --warmup 1 > $O/bench_dpm.log 2>&1; tail -1 $O/bench_dpm.log > profiles/${TAG}_bench_line_dpm.json
+timeout 400 python bench.py --mode sr --batch 1 --steps 1 --warmup 1 > $O/bench_sr.log 2>&1; tail -1 $O/bench_sr.log > profiles/${TAG}_bench_line_sr.json
+timeout 400 python bench.py --mode train --batch 8 --steps 5 --warmup 2 > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log > profiles/${TAG}_bench_line_train.json
+cp profiles/${TAG}_* profiles/pmc_traffic.json $O/ 2>/dev/null
+tail -3 $O/pytest.txt; tail -1 $O/smoke.log; cat profiles/${TAG}_bench_line.json
