@@ -223,6 +223,9 @@ int mmd_dpm_err(const float* hi, const float* lo, const float* prev, float atol,
                 void* stream);
 /* SR model input (image_unet.py:704-715): out [N,2C,H,W] = concat(x [N,C,H,W], bilinear(low [N,C,h,w] -> H x W)), fp32. */
 int mmd_bilinear_concat(const float* x, const float* low, float* out, int N, int C, int H, int W, int h, int w, void* stream);
+/* The same tensor as channels-last rows [(n, y, x), Cpad] in `dtype` (channels 2C..Cpad zero): feeds the SR stem as an implicit GEMM. */
+int mmd_bilinear_concat_rows(int dtype, const float* x, const float* low, void* out, int N, int C, int H, int W, int h, int w, int Cpad,
+                             void* stream);
 /* Gradient of sum_n(dmse[n] mse[n] + dvb[n] vb[n]) of mmd_loss_terms w.r.t. the model output (same layout, fp32): the mean channels
  * get the mse gradient only (the vb term detaches the mean, gd:1147-1151), the variance channels the KL / decoder-NLL gradient. */
 int mmd_loss_terms_bwd(const float* x0, const float* xt, const float* model_out, const float* target, const float* tables,

@@ -544,10 +544,14 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
   }
   int rc = mmd_check_launch("conv_wgrad");
   if (rc || !db) return rc;
-  MMD_REQUIRE(Cout / epv <= 256, "conv_wgrad: Cout too wide for colsum");
   const int rpb = M >= 65536 ? 256 : 128;
-  if (dtype == MMD_BF16) hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
-  else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, st, (const char*)dY, lddy, M, Cout, db, rpb);
+  const int es = dtype == MMD_BF16 ? 2 : 4;
+  for (int c0 = 0; c0 < Cout; c0 += 256 * epv) {       // a block covers <= 256 16-byte column vectors: wide fp32 outputs (qkv 1536) go in slabs
+    const int cw = Cout - c0 < 256 * epv ? Cout - c0 : 256 * epv;
+    const char* src = (const char*)dY + (int64_t)c0 * es;
+    if (dtype == MMD_BF16) hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(cdiv(M, rpb)), dim3(256), 0, st, src, lddy, M, cw, db + c0, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, st, src, lddy, M, cw, db + c0, rpb);
+  }
   return mmd_check_launch("colsum");
 }
 

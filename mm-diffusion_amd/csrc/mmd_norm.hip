@@ -311,8 +311,12 @@ static int gn_rows_per_block(int dtype, int C, int S, int Tn) {
   const int cv = C / (dtype == MMD_BF16 ? 8 : 4);
   const int rpp = 256 / cv > 0 ? 256 / cv : 1;
   static const int cap = [] { const char* e = getenv("MMD_GN_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1280; }();
+  // R depends on the slice (Tn, C) only, never on the number of slices: the per-thread fp32 partial sums - and with them the last
+  // bit of the statistics - must not change with the batch size (a batch-4 run equals four batch-1 runs bitwise).  320 chunks per
+  // slice = one resident wave of blocks (5/CU x 256 CUs) at the 4 slices of the headline batch; MMD_GN_BLOCKS: tuning (x4).
+  (void)S;
   int R = 4 * rpp;
-  while ((int64_t)S * cdiv(Tn, R) > cap && R < 1024) R *= 2;   // ~one resident wave of blocks (5/CU x 256 CUs); MMD_GN_BLOCKS: tuning
+  while (cdiv(Tn, R) > cap / 4 && R < 1024) R *= 2;
   return R;
 }
 

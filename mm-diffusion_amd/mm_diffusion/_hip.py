@@ -68,6 +68,7 @@ _PROTOS = {
     "mmd_clamp_scale": (i32, [vp, vp, f32, i32, i64, vp]),
     "mmd_dpm_err": (i32, [vp, vp, vp, f32, f32, i32, i64, vp, vp]),
     "mmd_bilinear_concat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mmd_bilinear_concat_rows": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_pack_conv_weights": (i32, [i32, vp, i32, i32, vp]),
     "mmd_unpack_conv_grads": (i32, [vp, i32, i32, vp]),
     "mmd_loss_terms_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),

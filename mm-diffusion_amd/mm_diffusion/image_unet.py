@@ -186,7 +186,11 @@ class ImageUnet(nn.Module):
             for L in layers:
                 kind, pre = L[0], L[1]
                 if kind == "stem":
-                    W[pre] = (ops.pack_edge_weight(P[pre + ".weight"]), f32(P[pre + ".bias"]))
+                    wst = P[pre + ".weight"].float()
+                    cpad = (wst.shape[1] + 7) // 8 * 8            # GEMM form: input channels padded to a 16-byte row (SR model: 6 -> 8)
+                    wg = torch.zeros(wst.shape[0], cpad, *wst.shape[2:], device=wst.device)
+                    wg[:, :wst.shape[1]] = wst
+                    W[pre] = (ops.pack_edge_weight(P[pre + ".weight"]), f32(P[pre + ".bias"]), ops.pack_conv_weight(wg, dt), cpad)
                 elif kind == "res":
                     cin, cout = L[2], L[3]
                     W[pre] = dict(
@@ -206,6 +210,16 @@ class ImageUnet(nn.Module):
                         wq, bq = wq[perm], bq[perm]
                     W[pre] = dict(g=f32(P[pre + ".norm.weight"]), b=f32(P[pre + ".norm.bias"]), w_qkv=wq.to(dt).contiguous(), b_qkv=bq.contiguous(),
                                   w_proj=P[pre + ".proj_out.weight"].float().reshape(C, C).to(dt).contiguous(), b_proj=f32(P[pre + ".proj_out.bias"]))
+        # every ResBlock's emb_layers Linear in ONE launch over the row-concatenated weights (image_unet.py:176-182 applies them one by one)
+        offs, Ws, bs, off = {}, [], [], 0
+        for layers in plan_in + [plan_mid] + plan_out:
+            for L in layers:
+                if L[0] == "res":
+                    offs[L[1]] = (off, W[L[1]]["w_e"].shape[0])
+                    Ws.append(W[L[1]]["w_e"])
+                    bs.append(W[L[1]]["b_e"])
+                    off += W[L[1]]["w_e"].shape[0]
+        W["emb_all"] = (torch.cat(Ws).contiguous(), torch.cat(bs).contiguous(), offs, off)
         W["time_embed"] = tuple(f32(P[k]) for k in ("time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias"))
         W["out"] = (f32(P["out.0.weight"]), f32(P["out.0.bias"]), ops.pack_edge_weight(P["out.2.weight"]), f32(P["out.2.bias"]))
         self._packed = (str(device), dt, W)
@@ -228,8 +242,8 @@ class ImageUnet(nn.Module):
             h, x, Hh = h2, x2, Ho
             geom = Geom.per_sample(N, Hh * Hh)
         h = ops.conv_gemm(h, w["w_in"], w["b_in"], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh))
-        emb_out = ops.alloc(N, w["w_e"].shape[0], dtype=torch.float32, device=x.device)
-        ops.linear(semb, w["w_e"], w["b_e"], emb_out)
+        eo, en = W["emb_all"][2][pre]
+        emb_out = semb[:, eo:eo + en]            # semb = all emb_layers outputs [N, sum J], computed once per evaluation
         if self.use_scale_shift_norm:
             a, b = ops.gn_stats(h, w["g2"], w["b2"], geom, film=emb_out)
         else:
@@ -251,18 +265,20 @@ class ImageUnet(nn.Module):
         ops.attn(qkv, qkv, att, heads, C // heads, N, 1, T, T, T, T, 1)
         return ops.conv_gemm(att, w["w_proj"], w["b_proj"], residual=x)
 
-    def _run(self, x6, timesteps):
-        """x6: fp32 API-layout input [N, in_channels, H, W] (already concatenated for the SR model)."""
-        if not x6.is_cuda:
+    def _run(self, x6, timesteps, rows=None, shape=None):
+        """x6: fp32 API-layout input [N, in_channels, H, W].  SR model: x6 is None and the input arrives as channels-last rows
+        [N*H*W, Cpad] in the activation dtype (`rows`, with `shape` = (N, in_channels, H, W)) - the stem then runs as an implicit GEMM."""
+        src = x6 if rows is None else rows
+        if not src.is_cuda:
             raise MMDError("ImageUnet runs on the MI355X HIP path only (GPU tensors); there is no CPU/torch fallback")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x6.requires_grad:
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and src.requires_grad:
             raise NotImplementedError("ImageUnet: the SR model is inference-only on the HIP path")
-        dev = x6.device
+        dev = src.device
         if self._packed is None or self._packed[0] != str(dev) or self._packed[1] != self.dtype:
             self._pack(dev)
         W = self._packed[2]
         dt = self.dtype
-        N, Cin, Hh, Ww = x6.shape
+        N, Cin, Hh, Ww = x6.shape if rows is None else shape
         assert Hh == Ww, "square images only"
         mc = self.model_channels
         te = W["time_embed"]
@@ -274,14 +290,18 @@ class ImageUnet(nn.Module):
         ops.silu(e1, None, e1)
         emb = ops.alloc(N, 4 * mc, dtype=torch.float32, device=dev)
         ops.linear(e1, te[2], te[3], emb)
-        semb = ops.alloc(N, 4 * mc, dtype=torch.float32, device=dev)
-        ops.silu(emb, None, semb)
+        s1 = ops.alloc(N, 4 * mc, dtype=torch.float32, device=dev)
+        ops.silu(emb, None, s1)
+        semb = ops.alloc(N, W["emb_all"][3], dtype=torch.float32, device=dev)
+        ops.linear(s1, W["emb_all"][0], W["emb_all"][1], semb)
         plan_in, plan_mid, plan_out = self._plan
         hs = []
         h = None
         for layers in plan_in:
             for L in layers:
-                if L[0] == "stem":
+                if L[0] == "stem" and rows is not None:
+                    h = ops.conv_gemm(rows, W[L[1]][2], W[L[1]][1], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh))
+                elif L[0] == "stem":
                     h = ops.alloc(N * Hh * Hh, L[3], dtype=dt, device=dev)
                     ops.stem_conv(x6.float().contiguous().view(N, 1, Cin, Hh, Hh), W[L[1]][0], W[L[1]][1], h, N, 1, Cin, Hh, Hh, ops.TAPS_SPATIAL)
                 elif L[0] == "res":
@@ -320,9 +340,11 @@ class ImageUnet(nn.Module):
         geometry into a plan (ops.recording: per-shape tile autotune, every buffer parked in a keep-list) and captured into a hipGraph;
         every later evaluation copies the inputs into the static buffers and replays the graph: ~700 ctypes launches and as many
         torch.empty calls per evaluation become one launch (the SR stage runs 25-1000 evaluations per clip, sample_sr.py:186-253).
-        MMD_SR_GRAPH=0 keeps the eager launches."""
+        OPT-IN (MMD_SR_GRAPH=1): measured on MI355X at the shipped size (16 frames of 256 x 256, 192 channels) the evaluation is
+        GPU-bound - 46.6 ms replayed vs 46.9 ms eager - while the plan's keep-list (no liveness reuse) holds 27 GB against 5 GB of
+        eager peak; replay pays only for small frame batches, where the host launch time shows."""
         H.require_cuda(*inputs)
-        if torch.is_grad_enabled() or os.environ.get("MMD_SR_GRAPH", "1") == "0":
+        if torch.is_grad_enabled() or os.environ.get("MMD_SR_GRAPH", "0") != "1":
             return body(tuple(t.float().contiguous() for t in inputs), timesteps.contiguous())
         dev = inputs[0].device
         if self._packed is None or self._packed[0] != str(dev) or self._packed[1] != self.dtype:
@@ -378,7 +400,8 @@ class ImageSuperResModel(ImageUnet):
         def body(xs, t):
             xx, low = xs
             N, C, Hh, Ww = xx.shape
-            x6 = ops.alloc(N, 2 * C, Hh, Ww, dtype=torch.float32, device=xx.device)
-            ops.bilinear_concat(xx, low, x6)
-            return self._run(x6, t)
+            cpad = (2 * C + 7) // 8 * 8
+            rows = ops.alloc(N * Hh * Ww, cpad, dtype=self.dtype, device=xx.device)
+            ops.bilinear_concat_rows(xx, low, rows)           # [x | bilinear(low) | 0] as channels-last rows: the stem is a K = 9 * cpad GEMM
+            return self._run(None, t, rows=rows, shape=(N, 2 * C, Hh, Ww))
         return self._replay((x, low_res), timesteps, body)

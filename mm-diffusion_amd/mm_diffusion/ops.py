@@ -187,8 +187,11 @@ def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129), out=None, scratc
     variant that disagrees is a kernel bug and raises - timing alone never admits a kernel into a captured graph.  `scratch` =
     the input buffers (plan-time garbage) that are filled with N(0,1) first so the comparison sees finite, representative data."""
     default = (129 if 129 in candidates else 128) if ((M + 127) // 128) * ((Cout + 127) // 128) >= 320 else 64
+    if default not in candidates:
+        default = candidates[0]
     if not AUTOTUNE or _recorder is None:
         return default
+    key = (key, tuple(candidates))      # a shape tuned over (64, 128, 129) must not answer for a launch restricted to (128, 129)
     if key in _tile_cache:
         return _tile_cache[key]
     import ctypes
@@ -277,7 +280,10 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     if tile == 0 and stats is None and halo_tile_pinned(x, taps, dims):
         tile = 130
     if tile == 0:
-        cands = (64, 128, 129) + ((130,) if HALO_CANDIDATE and stats is None and halo_tile_ok(x, taps, dims) else ())
+        # statistics-emitting launches stay inside the 128-row tile family: the per-record sums are folded in an order that depends on
+        # the tile's thread layout (128 / 129 share it, 64 does not), and the choice must not move the last bit of the statistics
+        # when the batch size changes the autotuner's verdict
+        cands = (128, 129) if stats is not None else (64, 128, 129) + ((130,) if HALO_CANDIDATE and halo_tile_ok(x, taps, dims) else ())
         tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False, tuple(dims) if 130 in cands else None),
                           lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout, cands, out=out, scratch=(x, residual))
     flops = 2 * M * Cout * Cin * nt
@@ -313,8 +319,8 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
     if tile == 0:
         tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
-                          lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout, candidates=(64, 128), out=out,
-                          scratch=(x, residual, a, b))
+                          lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout,
+                          candidates=(128,) if stats is not None else (64, 128), out=out, scratch=(x, residual, a, b))
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
     meta = (f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes)
     if stats is not None:
@@ -443,6 +449,18 @@ def bilinear_concat(x, low, out):
     N, C, Hh, Ww = x.shape
     _dispatch("mmd_bilinear_concat", x.data_ptr(), low.data_ptr(), out.data_ptr(), N, C, Hh, Ww, low.shape[2], low.shape[3],
               meta=("bilinear_concat", 0, 4 * (x.numel() + low.numel() + out.numel())))
+    return out
+
+
+def bilinear_concat_rows(x, low, out):
+    """out [N*H*W, Cpad] (bf16 / fp32 rows) = [x | bilinear(low) | 0]: the SR model's input in the layout of the implicit-GEMM stem."""
+    H.require_cuda(x, low, out)
+    N, C, Hh, Ww = x.shape
+    _chk2d(out)
+    if out.shape[0] != N * Hh * Ww or not out.is_contiguous():
+        raise H.MMDError("bilinear_concat_rows: out must be contiguous [N*H*W, Cpad]")
+    _dispatch("mmd_bilinear_concat_rows", H.dt_of(out), x.data_ptr(), low.data_ptr(), out.data_ptr(), N, C, Hh, Ww, low.shape[2], low.shape[3],
+              out.shape[1], meta=("bilinear_concat_rows", 0, 4 * (x.numel() + low.numel()) + out.numel() * out.element_size()))
     return out
 
 

@@ -107,3 +107,17 @@ def test_sr_single_modal_dpm_solver_matches_reference(tag, px0):
     e = rel_l2(out.cpu(), g["sample"])
     print(f"{tag}: rel-L2 {e:.3e}")
     assert out.shape == noise.shape and e < 1e-4
+
+
+def test_sr_graph_replay_equals_eager(monkeypatch):
+    """MMD_SR_GRAPH=1: the recorded + captured forward (per-shape tile autotune, static buffers) equals the eager launches bitwise, on the
+    first evaluation (capture) and on replays with new inputs."""
+    g = gold("sr_tiny_forward")
+    model, _ = build(torch.bfloat16)
+    x, t, low = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda(), torch.from_numpy(g["low"]).cuda()
+    with torch.no_grad():
+        eager = [model(x, t, low_res=low), model(x * 0.5, t + 3, low_res=low)]
+        monkeypatch.setenv("MMD_SR_GRAPH", "1")
+        replay = [model(x, t, low_res=low), model(x * 0.5, t + 3, low_res=low), model(x, t, low_res=low)]
+    assert len(model._graphs) == 1
+    assert torch.equal(eager[0], replay[0]) and torch.equal(eager[1], replay[1]) and torch.equal(eager[0], replay[2])
