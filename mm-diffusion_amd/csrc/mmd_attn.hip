@@ -985,7 +985,10 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   const int k_count = win * k_per_group;
   const bool stage_ok = dtype == MMD_BF16 && aligned && ch == 64;
   if (impl == 3 && !stage_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 3 (staged window): needs bf16, head width 64, aligned rows");
-  if (stage_ok && (impl == 3 || (impl == 0 && k_count >= 192 && qmax >= 128)))
+  // auto rule from tools/attn_bench.py on MI355X (batch 4): the staged kernel wins where a group has FEW queries per staged key
+  // (audio <- video at ds2: 400 queries x 1024 keys, 63 us vs 74 us) and loses a few percent where the per-128-query kernel's three
+  // co-resident blocks per CU hide its staging (spatial 1024 x 1024: 142 vs 129 us; video <- audio 1024 x 400: 69 vs 67 us)
+  if (stage_ok && (impl == 3 || (impl == 0 && k_count >= 768 && qmax >= 128 && qmax <= 512)))
     return launch_stage<64>(p, qmax, st);
   if (dtype == MMD_BF16 && (impl == 0 || impl == 2 || impl == 3) && aligned) {
     switch (ch) {
