@@ -9,9 +9,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O profiles
 export PYTHONFAULTHANDLER=1
+if [ -z "$RP_SKIP_TESTS" ]; then      # RP_SKIP_TESTS=1: profiling passes only (the suite was just run at this build)
 timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest_full.txt 2>&1
 tail -3 $O/pytest_full.txt > $O/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+fi
 B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-breakdown"
 timeout 500 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B > $O/kt.log 2>&1
 timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p -f csv -- $B > $O/pmc_fetch.log 2>&1
@@ -26,5 +28,6 @@ tail -1 $O/bench_default.log > profiles/${TAG}_bench_line.json
 timeout 400 python bench.py --mode dpm --batch 2 --steps 2 --warmup 1 > $O/bench_dpm.log 2>&1; tail -1 $O/bench_dpm.log > profiles/${TAG}_bench_line_dpm.json
 timeout 400 python bench.py --mode sr --batch 1 --steps 1 --warmup 1 > $O/bench_sr.log 2>&1; tail -1 $O/bench_sr.log > profiles/${TAG}_bench_line_sr.json
 timeout 400 python bench.py --mode train --batch 8 --steps 5 --warmup 2 > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log > profiles/${TAG}_bench_line_train.json
-cp profiles/${TAG}_* profiles/pmc_traffic.json $O/ 2>/dev/null
-tail -3 $O/pytest.txt; tail -1 $O/smoke.log; cat profiles/${TAG}_bench_line.json
+mkdir -p $O/profiles && cp profiles/${TAG}_* profiles/pmc_traffic.json $O/profiles/ 2>/dev/null
+rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces stay on the box: only the summaries travel back
+tail -3 $O/pytest.txt 2>/dev/null; tail -1 $O/smoke.log 2>/dev/null; cat profiles/${TAG}_bench_line.json
