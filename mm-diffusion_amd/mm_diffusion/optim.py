@@ -259,5 +259,4 @@ class FlatAdamW:
         # weights on the parameters' version counters, engine.UNetEngine.stale) that every parameter changed
         bump = getattr(torch._C, "_increment_version", None)
         if bump is not None:
-            for p in self.params:
-                bump(p)
+            bump(self.params)      # ONE call on the list: handed a single tensor it iterates over it (unbind per row: 0.27 s per step)
