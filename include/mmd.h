@@ -80,6 +80,9 @@ int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, in
 /* x[m, :] += e[m / rows_per_sample, :]  (non-FiLM ResBlock h + emb_out, unet:473-477). */
 int mmd_add_rowbias(int dtype, void* x, int64_t ld, int64_t rows, int C, int64_t rows_per_sample, const float* e,
                     int64_t e_ld, void* stream);
+/* Its gradient w.r.t. e: out[s, c] += sum over the rows of sample s of dY[row, c] (S contiguous slices of Tn rows; out fp32 [S, ldo],
+ * accumulated - the caller zeroes). */
+int mmd_colsum_slices(int dtype, const void* dY, int64_t lddy, int S, int64_t Tn, int C, float* out, int64_t ldo, void* stream);
 
 /* Implicit-GEMM convolution on the matrix cores:
  *   Y[m, co] = bias[co] + sum_tap sum_ci A[src(m,tap), ci] * W[co, tap*Cin + ci] (+ R[m, co])

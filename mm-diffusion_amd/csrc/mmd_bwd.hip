@@ -555,6 +555,24 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
   return mmd_check_launch("colsum");
 }
 
+// out[s, c] += sum over the Tn rows of slice s of dY[row, c] (S contiguous slices): the gradient of a per-sample row bias - the
+// non-FiLM ResBlock's h + emb_out (unet:473-477).  `out` [S, ldo] fp32 is ACCUMULATED (caller zeroes).
+extern "C" int mmd_colsum_slices(int dtype, const void* dY, int64_t lddy, int S, int64_t Tn, int C, float* out, int64_t ldo, void* stream) {
+  const int epv = dtype == MMD_BF16 ? 8 : 4, es = dtype == MMD_BF16 ? 2 : 4;
+  MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "colsum_slices: bad dtype");
+  MMD_REQUIRE(dY && out && S > 0 && Tn > 0 && C > 0 && C % epv == 0 && lddy % epv == 0 && ((uintptr_t)dY) % 16 == 0, "colsum_slices: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = Tn >= 65536 ? 256 : 128;
+  for (int s = 0; s < S; ++s)
+    for (int c0 = 0; c0 < C; c0 += 256 * epv) {
+      const int cw = C - c0 < 256 * epv ? C - c0 : 256 * epv;
+      const char* src = (const char*)dY + ((int64_t)s * Tn * lddy + c0) * es;
+      if (dtype == MMD_BF16) hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(cdiv(Tn, rpb)), dim3(256), 0, st, src, lddy, (int)Tn, cw, out + (int64_t)s * ldo + c0, rpb);
+      else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(Tn, rpb)), dim3(256), 0, st, src, lddy, (int)Tn, cw, out + (int64_t)s * ldo + c0, rpb);
+    }
+  return mmd_check_launch("colsum_slices");
+}
+
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
 }

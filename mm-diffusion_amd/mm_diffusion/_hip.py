@@ -36,6 +36,7 @@ _PROTOS = {
     "mmd_gn_stats": (i32, [i32, vp, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, i64, f32, vp, vp, vp, vp, vp]),
     "mmd_gn_apply": (i32, [i32, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, i32, vp]),
     "mmd_add_rowbias": (i32, [i32, vp, i64, i64, i32, i64, vp, i64, vp]),
+    "mmd_colsum_slices": (i32, [i32, vp, i64, i32, i64, i32, vp, i64, vp]),
     "mmd_conv_gemm": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_gn_conv1x1": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "mmd_conv_gemm_stats": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp, i64, vp]),

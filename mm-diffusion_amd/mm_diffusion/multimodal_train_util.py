@@ -11,8 +11,10 @@ MI355X-first differences:
     broadcast (the reference: DDP with 128 MB buckets + 1046 per-tensor broadcasts)
   * `use_fp16` selects bf16 activations / conv weights with fp32 master parameters: bf16 has fp32's exponent range, so
     the reference's dynamic loss scaling (fp16_util.py:149-245) has nothing to do and `took_step` is always true
-Out of scope here (out of the hot path): wandb logging and the periodic sample-video dump (`save_video`,
-mtu:348-467 - moviepy / gif writers); `save_interval` only writes checkpoints.
+  * the periodic sample dump (`save_video`, mtu:348-467) samples from the first EMA copy WITHOUT touching the master parameters
+    (the reference loads the EMA weights into the model), gathers every rank's samples with one RCCL all-gather per stream and
+    writes a png grid of frame strips + wav files (no gif / mp4 muxer in this build)
+Out of scope here (out of the hot path): wandb logging.
 """
 import glob
 import os
@@ -145,6 +147,7 @@ class TrainLoop:
                 logger.dumpkvs()
             if self.step % self.save_interval == 0:
                 self.save()
+                self.save_video()
                 if os.environ.get("DIFFUSION_TRAINING_TEST", "") and self.step > 0:
                     return
             self.step += 1
@@ -170,7 +173,7 @@ class TrainLoop:
             return self._run_step_graph(batch)
         self.opt.zero_grad()
         loss = self.forward_backward(batch, cond)
-        self.opt.all_reduce_grads()
+        self.opt.all_reduce_grads()                           # buckets already launched under the last backward are only awaited
         self.opt.step()                                       # AdamW + every EMA copy
         self._anneal_lr()
         self.log_step()
@@ -186,6 +189,8 @@ class TrainLoop:
             t, weights = self.schedule_sampler.sample(micro["video"].shape[0], dist_util.dev())
             losses = self.diffusion.multimodal_training_losses(self.model, micro, t, model_kwargs=micro_cond)
             loss = (losses["loss"] * weights).mean()
+            if i + self.microbatch >= batch_len:              # last microbatch: gradient buckets are reduced while it is still running
+                self.opt.arm_overlap()                        # (the reference: DDP buckets + no_sync() on the earlier ones, mtu:289-319)
             loss.backward()                                   # accumulates straight into the flat gradient buffer
         if isinstance(self.schedule_sampler, LossAwareSampler):
             self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
@@ -201,6 +206,62 @@ class TrainLoop:
     def log_step(self):
         logger.logkv("step", self.step + self.resume_step)
         logger.logkv("samples", (self.step + self.resume_step + 1) * self.global_batch)
+
+    def save_video(self):
+        """Periodic sample dump (mtu:348-467): save_row^2 video+audio pairs from the first EMA copy with the configured sampler
+        (`sample_fn`: dpm_solver / dpm_solver++ adaptive-20 like the reference, ddim, or the DDPM loop), every rank's batch gathered
+        by one all-gather per stream (mtu:420-431), rank 0 writes `<sample_fn>_samples_steps<N>.png` (grid of frame strips) and one
+        wav per sample.  The master parameters are swapped out and back, never overwritten."""
+        from .common import save_audio, save_one_video
+        dev = dist_util.dev()
+        logger.log("create samples...")
+        was_training = self.model.training
+        keep = None
+        if self.opt.ema_params:                               # sample from the EMA weights, then restore the masters
+            keep = self.opt.flat.clone()
+            self.opt.flat.copy_(self.opt.ema_params[0])
+            self._params_changed()
+        self.model.eval()
+        videos, audios = [], []
+        try:
+            while len(videos) * self.batch_size * dist_util.world_size() < self.save_row ** 2:
+                shape = {"video": [self.batch_size, *self.model.video_size], "audio": [self.batch_size, *self.model.audio_size]}
+                with th.no_grad():
+                    if self.sample_fn in ("dpm_solver", "dpm_solver++"):
+                        from .multimodal_dpm_solver_plus import DPM_Solver
+                        pp = self.sample_fn == "dpm_solver++"
+                        solver = DPM_Solver(model=self.model, alphas_cumprod=th.tensor(self.diffusion.alphas_cumprod, dtype=th.float32),
+                                            predict_x0=pp, thresholding=pp)
+                        x_T = {k: th.randn(*v).to(dev) for k, v in shape.items()}
+                        sample = solver.sample(x_T, steps=20, order=2, skip_type="logSNR", method="adaptive")
+                    else:
+                        fn = self.diffusion.ddim_sample_loop if self.sample_fn == "ddim" else self.diffusion.p_sample_loop
+                        sample = fn(self.model, shape=shape, clip_denoised=True, model_kwargs={}, device=dev, progress=False)
+                videos.append(dist_util.all_gather_samples(sample["video"].float().contiguous()).cpu())
+                audios.append(dist_util.all_gather_samples(sample["audio"].float().contiguous()).cpu())
+        finally:
+            if keep is not None:
+                self.opt.flat.copy_(keep)
+                self._params_changed()
+            self.model.train(was_training)
+        videos, audios = th.cat(videos), th.cat(audios)
+        path = os.path.join(logger.get_dir(), f"{self.sample_fn}_samples_steps{self.step}.png")
+        if dist_util.rank() == 0:
+            path = save_one_video(videos, path, row=self.save_row)
+            for i, a in enumerate(audios[: self.save_row ** 2]):
+                save_audio(a.numpy(), os.path.join(logger.get_dir(), f"{self.sample_fn}_samples_steps{self.step}_{i}.wav"), self.audio_fps)
+            logger.log(f"{videos.shape[0]} has sampled -> {path}")
+        if dist.is_initialized():
+            dist.barrier()
+        return path
+
+    def _params_changed(self):
+        """The flat buffer was rewritten under the parameters: re-pack the GEMM operands and invalidate the inference engines."""
+        if self.opt.packer is not None:
+            self.opt.packer.refresh()
+        bump = getattr(th._C, "_increment_version", None)
+        if bump is not None:
+            bump(self.opt.params)
 
     def save(self):
         step = self.step + self.resume_step

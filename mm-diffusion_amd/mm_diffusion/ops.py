@@ -161,6 +161,14 @@ def add_rowbias(x, e, rows_per_sample):
     return x
 
 
+def colsum_slices(dy, out, rows_per_sample):
+    """out[s, :] += column sums of the rows of sample s of dy (include/mmd.h: mmd_colsum_slices); out fp32 [S, C], zeroed by the caller."""
+    _chk2d(dy)
+    S = dy.shape[0] // rows_per_sample
+    _dispatch("mmd_colsum_slices", H.dt_of(dy), dy.data_ptr(), dy.stride(0), S, rows_per_sample, dy.shape[1], out.data_ptr(), out.stride(0))
+    return out
+
+
 # ---- tap tables (offsets of (p0, p1, p2))
 TAPS_1 = [(0, 0, 0)]
 TAPS_SPATIAL = [(0, dh, dw) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]      # D = (1|F, H, W)

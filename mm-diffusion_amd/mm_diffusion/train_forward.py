@@ -88,9 +88,9 @@ def train_forward(model, video, audio, timesteps):
                     h = T.ResampleFn.apply(h, N, 1, Ll, 1, 4, mode)
                     xs = T.ResampleFn.apply(x, N, 1, Ll, 1, 4, mode)
             rows_out = h.shape[0]
-            if not ss:
-                raise NotImplementedError("training with use_scale_shift_norm=False is not built (every shipped config uses FiLM)")
-            h = gn(h, f"{p}.{mod}_out_layers.0", Geom.per_sample(N, rows_out // N), True, film=film)
+            if not ss:       # h + emb_out, then the plain norm (unet:473-477)
+                h = T.RowBiasFn.apply(h, film, rows_out // N)
+            h = gn(h, f"{p}.{mod}_out_layers.0", Geom.per_sample(N, rows_out // N), True, film=film if ss else None)
             if model.dropout > 0 and model.training:
                 h = T.DropoutFn.apply(h, float(model.dropout))
             conv = "video_conv" if vid else "audio_conv"

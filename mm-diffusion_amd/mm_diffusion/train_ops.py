@@ -225,6 +225,28 @@ class CrossAttnFn(Function):
         return dv, da, None, None, None, None, None, None, None
 
 
+class RowBiasFn(Function):
+    """h + emb_out broadcast over the rows of each sample: the non-FiLM ResBlock (use_scale_shift_norm=False, unet:473-477).
+    Forward mmd_copy2d + mmd_add_rowbias; backward dh = dy, d emb_out = per-sample column sums of dy (mmd_colsum_slices)."""
+
+    @staticmethod
+    def forward(ctx, h, e, rows_per_sample):
+        out = torch.empty(h.shape, dtype=h.dtype, device=h.device)
+        ops.copy2d(h, out)
+        ops.add_rowbias(out, e.detach().float().contiguous(), rows_per_sample)
+        ctx.rps, ctx.eshape = rows_per_sample, e.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        de = None
+        if ctx.needs_input_grad[1]:
+            de = torch.zeros(ctx.eshape, dtype=torch.float32, device=dy.device)
+            ops.colsum_slices(dy, de, ctx.rps)
+        return (dy if ctx.needs_input_grad[0] else None), de, None
+
+
 class CatFn(Function):
     """[h | skip] along the channel axis of channels-last rows (the U-Net skip concat, unet:1093-1094) with libmmd copies: forward two
     strided row copies into one buffer, backward two strided copies out of the gradient (the inference engine has no copy at all -

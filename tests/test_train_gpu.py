@@ -217,3 +217,32 @@ def test_graph_captured_step_matches_eager_step(dt):
     gstep.step(x0, t, noise=noise)
     assert rel_l2(opt.grad.cpu(), ref_grad.cpu().numpy()) > 1e-4
     gstep.close()
+
+
+def test_non_film_training_gradients_match_reference():
+    """use_scale_shift_norm=False (ResBlock: h + emb_out, then the plain norm, unet:473-477): loss terms and parameter gradients vs the
+    reference's .backward() (tests/golden/tiny_nofilm_train_loss.npz), including two emb_layers parameters - their gradient is the
+    per-sample column sum of the block's upstream gradient (mmd_colsum_slices)."""
+    from mm_diffusion import logger, multimodal_script_util as msu
+    from mm_diffusion.synth import synth_init_
+    logger.set_quiet(True)
+    g = gold("tiny_nofilm_train_loss")
+    fl = flags("tiny", use_scale_shift_norm=False)
+    model, diff = msu.create_model_and_diffusion(**fl)
+    synth_init_(model)
+    model.cuda().train()
+    B, seed = int(g["B"]), int(g["seed"])
+    gen = torch.Generator().manual_seed(seed)
+    x0 = {"video": (torch.rand(B, *fl["video_size"], generator=gen) * 2 - 1).cuda(), "audio": (torch.rand(B, *fl["audio_size"], generator=gen) * 2 - 1).cuda()}
+    noise = {"video": torch.randn(B, *fl["video_size"], generator=gen).cuda(), "audio": torch.randn(B, *fl["audio_size"], generator=gen).cuda()}
+    it = iter([int(s) for s in list(g["shifts_fwd"]) + list(g["shifts_bwd"])])
+    model.shift_source = lambda lo, hi: next(it)
+    terms = diff.multimodal_training_losses(model, x0, torch.from_numpy(g["t"]).cuda(), noise=noise)
+    for k in ("loss", "mse_video", "mse_audio"):
+        np.testing.assert_allclose(terms[k].detach().cpu().numpy(), g[k], rtol=5e-4)
+    terms["loss"].mean().backward()
+    params = dict(model.named_parameters())
+    for k in GRAD_KEYS + ("input_blocks.1.0.emb_layers.1.weight", "middle_blocks.0.emb_layers.1.bias"):
+        e = rel_l2(params[k].grad.cpu(), g["grad." + k])
+        print(f"non-FiLM grad {k}: rel-L2 {e:.2e}")
+        assert e < 2e-3, k

@@ -118,3 +118,32 @@ def test_graph_captured_loop_trains(tmp_path):
         loop.step += 1
     print("graph-loop losses", [round(v, 4) for v in losses])
     assert loop._gstep is not None and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("sample_fn", ["dpm_solver++", "ddim"])
+def test_periodic_sample_dump_uses_ema_and_restores_the_masters(tmp_path, sample_fn):
+    """save_video (mtu:348-467): samples come from the first EMA copy, the master parameters are back afterwards (bitwise), rank 0 writes
+    the png grid of frame strips and one wav per sample."""
+    from mm_diffusion import logger
+    _seed()
+    model, loop = _mk(tmp_path / sample_fn, sample_fn=sample_fn, save_row=2)
+    for _ in range(2):
+        loop.run_step(next(loop.data))
+        loop.step += 1
+    masters, ema0 = loop.opt.flat.clone(), loop.opt.ema_params[0].clone()
+    assert not torch.equal(masters, ema0)
+    train_diff = loop.diffusion
+    if sample_fn == "ddim":                                   # keep the DDIM loop short: sample on a 4-step respacing
+        from mm_diffusion import multimodal_script_util as msu
+        loop.diffusion = msu.create_gaussian_diffusion(steps=1000, timestep_respacing="ddim4")
+    path = loop.save_video()
+    loop.diffusion = train_diff
+    assert torch.equal(loop.opt.flat, masters) and torch.equal(loop.opt.ema_params[0], ema0)
+    assert os.path.exists(path) and path.endswith(".png")
+    wavs = [f for f in os.listdir(logger.get_dir()) if f.endswith(".wav")]
+    assert len(wavs) == 4
+    from PIL import Image
+    im = Image.open(path)
+    assert im.size == (8 * 16, 4 * 16)                        # 4 clips (rows) x 8 frames of 16 x 16
+    loop.run_step(next(loop.data))                            # training goes on from the master parameters
+    assert torch.isfinite(loop.opt.flat).all()

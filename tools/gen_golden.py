@@ -244,7 +244,7 @@ def gen_psample(name, B, seed, respacing, **over):
 
 
 def gen_train_loss(name, B, seed, **over):
-    f = flags(name, **over)
+    f = flags(name, **{k: v for k, v in over.items() if not k.startswith("_")})
     model, diff = msu.create_model_and_diffusion(**f)
     synth_init(model).train()  # dropout p=0 -> deterministic
     g = th.Generator().manual_seed(seed)
@@ -265,7 +265,9 @@ def gen_train_loss(name, B, seed, **over):
               "middle_blocks.1.v_qkv.weight", "video_out.2.video_conv.bias", "audio_out.2.audio_conv.weight"):
         p = dict(model.named_parameters())[k]
         grads["grad." + k] = p.grad
-    tag = name + ("_ls" if over.get("learn_sigma") else "")
+    for k in over.get("_extra_grads", ()):
+        grads["grad." + k] = dict(model.named_parameters())[k].grad
+    tag = name + ("_ls" if over.get("learn_sigma") else "") + ("_nofilm" if over.get("use_scale_shift_norm") is False else "")
     save(f"{tag}_train_loss", seed=seed, B=B, t=t, shifts_fwd=np.asarray(rec.draws[:nfwd]),
          shifts_bwd=np.asarray(rec2.draws),
          **{k: v for k, v in losses.items()}, **grads)
@@ -415,6 +417,9 @@ ALL = {
     "dpm_adaptive3": lambda: gen_dpm("tiny_dpm_adaptive3", 66, False, False, order=3, method="adaptive", atol=0.05, rtol=0.1),
     "tiny_train_loss": lambda: gen_train_loss("tiny", 2, 31),
     "tiny_ls_train_loss": lambda: gen_train_loss("tiny", 2, 32, learn_sigma=True),
+    # non-FiLM ResBlocks (use_scale_shift_norm=False, unet:473-477): h + emb_out, then the plain norm
+    "tiny_nofilm_train_loss": lambda: gen_train_loss("tiny", 2, 33, use_scale_shift_norm=False,
+                                                     _extra_grads=("input_blocks.1.0.emb_layers.1.weight", "middle_blocks.0.emb_layers.1.bias")),
 }
 
 if __name__ == "__main__":

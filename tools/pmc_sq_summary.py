@@ -46,7 +46,10 @@ def main():
                 f.write("    ratios: " + "  ".join(f"{lab}={c[n] / wc:.3f}" for lab, n in (("wait", "SQ_WAIT_ANY"), ("stall", "SQ_WAIT_INST_ANY"), ("issue", "SQ_ACTIVE_INST_ANY"),
                                                                                         ("valu", "SQ_ACTIVE_INST_VALU"), ("lds_stall", "SQ_WAIT_INST_LDS"), ("lds", "SQ_ACTIVE_INST_LDS")) if n in c) + "\n")
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"]:
-                f.write(f"    SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f}\n")
+                r = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]
+                # SQ_BUSY_CYCLES sums the 32 shader engines (kernel duration x 32), SQ_VALU_MFMA_BUSY_CYCLES the 1024 SIMDs: 32 SIMDs per SE
+                f.write(f"    SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES = {r:.3f}  ->  MFMA pipe busy {100 * r / 32:.1f} % of SIMD-cycles "
+                        f"(kernel duration ~ {c['SQ_BUSY_CYCLES'] / 32:.0f} cycles)\n")
 
 
 if __name__ == "__main__":
