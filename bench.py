@@ -192,6 +192,7 @@ def train_bench(args, world, rank, device):
             return gstep.step(x0, t)["loss"].mean()
         opt.zero_grad()
         loss = diff.multimodal_training_losses(model, x0, t)["loss"].mean()
+        opt.arm_overlap()             # world > 1: gradient buckets are all-reduced on a side stream while the backward is still running
         loss.backward()
         opt.all_reduce_grads()
         opt.step()
