@@ -226,7 +226,7 @@ class ImageUnet(nn.Module):
         return W
 
     # ------------------------------------------------------------------ forward
-    def _res(self, x, semb, N, Hh, L, W):
+    def _res(self, x, semb, N, Hh, L, W, out=None):
         _, pre, cin, cout, updown = L
         w = W[pre]
         geom = Geom.per_sample(N, Hh * Hh)
@@ -251,9 +251,9 @@ class ImageUnet(nn.Module):
             a, b = ops.gn_stats(h, w["g2"], w["b2"], geom)
         h = ops.gn_apply(h, a, b, geom, act=True)
         skip = x if w["w_skip"] is None else ops.conv_gemm(x, w["w_skip"], w["b_skip"])
-        return ops.conv_gemm(h, w["w_out"], w["b_out"], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh), residual=skip), Hh
+        return ops.conv_gemm(h, w["w_out"], w["b_out"], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh), residual=skip, out=out), Hh
 
-    def _attn(self, x, N, Hh, L, W):
+    def _attn(self, x, N, Hh, L, W, out=None):
         _, pre, C, heads = L
         w = W[pre]
         T = Hh * Hh
@@ -263,7 +263,7 @@ class ImageUnet(nn.Module):
         qkv = ops.conv_gemm(xn, w["w_qkv"], w["b_qkv"])
         att = ops.alloc(N * T, C, dtype=x.dtype, device=x.device)
         ops.attn(qkv, qkv, att, heads, C // heads, N, 1, T, T, T, T, 1)
-        return ops.conv_gemm(att, w["w_proj"], w["b_proj"], residual=x)
+        return ops.conv_gemm(att, w["w_proj"], w["b_proj"], residual=x, out=out)
 
     def _run(self, x6, timesteps, rows=None, shape=None):
         """x6: fp32 API-layout input [N, in_channels, H, W].  SR model: x6 is None and the input arrives as channels-last rows
@@ -295,33 +295,50 @@ class ImageUnet(nn.Module):
         semb = ops.alloc(N, W["emb_all"][3], dtype=torch.float32, device=dev)
         ops.linear(s1, W["emb_all"][0], W["emb_all"][1], semb)
         plan_in, plan_mid, plan_out = self._plan
-        hs = []
-        h = None
+        # skip concats without copies (th.cat([h, hs.pop()], dim=1), image_unet.py:689-692): output block k reads ONE buffer
+        # [decoder h | skip]; input block nin-1-k writes its output straight into the right-hand column slice, the layer in front of
+        # output block k into the left-hand slice (the multimodal engine does the same)
+        nin = len(plan_in)
+        chans_in, Hin, ch, Hc = [], [], None, Hh
         for layers in plan_in:
             for L in layers:
+                if L[0] in ("stem", "res"):
+                    ch = L[3]
+                if L[0] == "res" and L[4] == "down":
+                    Hc //= 2
+            chans_in.append(ch)
+            Hin.append(Hc)
+        ch_dec = [plan_out[k][0][2] - chans_in[nin - 1 - k] for k in range(nin)]
+        cats = [None] * nin
+        h = None
+        for i, layers in enumerate(plan_in):
+            k = nin - 1 - i
+            cats[i] = ops.alloc(N * Hin[i] * Hin[i], ch_dec[k] + chans_in[i], dtype=dt, device=dev)
+            dst = cats[i][:, ch_dec[k]:]
+            for j, L in enumerate(layers):
+                o = dst if j == len(layers) - 1 else None
                 if L[0] == "stem" and rows is not None:
-                    h = ops.conv_gemm(rows, W[L[1]][2], W[L[1]][1], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh))
+                    h = ops.conv_gemm(rows, W[L[1]][2], W[L[1]][1], taps=ops.TAPS_SPATIAL, dims=(N, Hh, Hh), out=o)
                 elif L[0] == "stem":
                     h = ops.alloc(N * Hh * Hh, L[3], dtype=dt, device=dev)
                     ops.stem_conv(x6.float().contiguous().view(N, 1, Cin, Hh, Hh), W[L[1]][0], W[L[1]][1], h, N, 1, Cin, Hh, Hh, ops.TAPS_SPATIAL)
+                    if o is not None:
+                        h = ops.copy2d(h, o)
                 elif L[0] == "res":
-                    h, Hh = self._res(h, semb, N, Hh, L, W)
+                    h, Hh = self._res(h, semb, N, Hh, L, W, out=o)
                 else:
-                    h = self._attn(h, N, Hh, L, W)
-            hs.append(h)
-        for L in plan_mid:
-            h = self._res(h, semb, N, Hh, L, W)[0] if L[0] == "res" else self._attn(h, N, Hh, L, W)
-        for layers in plan_out:
-            skip = hs.pop()
-            cat = ops.alloc(h.shape[0], h.shape[1] + skip.shape[1], dtype=dt, device=dev)       # th.cat([h, hs.pop()], dim=1)
-            ops.copy2d(h, cat[:, :h.shape[1]])
-            ops.copy2d(skip, cat[:, h.shape[1]:])
-            h = cat
-            for L in layers:
+                    h = self._attn(h, N, Hh, L, W, out=o)
+        for j, L in enumerate(plan_mid):
+            o = cats[nin - 1][:, :ch_dec[0]] if j == len(plan_mid) - 1 else None
+            h = self._res(h, semb, N, Hh, L, W, out=o)[0] if L[0] == "res" else self._attn(h, N, Hh, L, W, out=o)
+        for k, layers in enumerate(plan_out):
+            h = cats[nin - 1 - k]
+            for j, L in enumerate(layers):
+                o = cats[nin - 2 - k][:, :ch_dec[k + 1]] if (j == len(layers) - 1 and k + 1 < nin) else None
                 if L[0] == "res":
-                    h, Hh = self._res(h, semb, N, Hh, L, W)
+                    h, Hh = self._res(h, semb, N, Hh, L, W, out=o)
                 else:
-                    h = self._attn(h, N, Hh, L, W)
+                    h = self._attn(h, N, Hh, L, W, out=o)
         g, b, w_out, b_out = W["out"]
         geom = Geom.per_sample(N, Hh * Hh)
         a, bb = ops.gn_stats(h, g, b, geom)
