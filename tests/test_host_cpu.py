@@ -193,3 +193,62 @@ def test_halo_tile_block_flow_model():
     assert m.check(1, 8, 32, 128, 136, m.sp) < 1e-10
     assert m.check(1, 16, 16, 64, 64, [(0, -1, 0), (0, 0, 0), (0, 1, 0)]) < 1e-10
     assert m.check(1, 8, 16, 64, 8, [(0, 0, 0)]) < 1e-10
+
+
+def test_halo_tile_is_pinned_by_layer_geometry_only():
+    """Tile 130 is chosen for spatial 3x3 convs on frames of >= 1024 pixels whatever the batch (ops.halo_tile_pinned): the choice may
+    never depend on the batch size, or a batch-4 plan and a batch-1 plan would differ in the last bit."""
+    import torch
+    from mm_diffusion import ops
+    for n in (1, 2, 4, 8):
+        x = torch.zeros(n * 16 * 32 * 32, 256, dtype=torch.bfloat16)
+        assert ops.halo_tile_pinned(x, ops.TAPS_SPATIAL, (n * 16, 32, 32))                     # ds2 frames: 1024 pixels
+        x = torch.zeros(n * 16 * 16 * 16, 384, dtype=torch.bfloat16)
+        assert not ops.halo_tile_pinned(x, ops.TAPS_SPATIAL, (n * 16, 16, 16))                 # ds4 frames: 256 pixels
+    x = torch.zeros(16 * 64 * 64, 128, dtype=torch.bfloat16)
+    assert not ops.halo_tile_pinned(x, ops.TAPS_TEMPORAL, (16, 4096, 1))                      # temporal k=3: not a 9-tap conv
+    assert not ops.halo_tile_pinned(x.float(), ops.TAPS_SPATIAL, (16, 64, 64))                # fp32 mode keeps the bitwise-equal tiles
+    assert not ops.halo_tile_pinned(torch.zeros(16 * 64 * 64, 8, dtype=torch.bfloat16), ops.TAPS_SPATIAL, (16, 64, 64))   # Cin below one K step
+
+
+def test_default_lanes_and_bucket_partition():
+    import torch
+    from mm_diffusion.optim import FlatAdamW
+    from mm_diffusion.sampler import default_lanes
+    assert default_lanes(4) == 1 and default_lanes(1) == 1
+    g = torch.Generator().manual_seed(0)
+    for nb in (1, 2, 4, 9):
+        sizes = [int(v) for v in torch.randint(1, 5000, (23,), generator=g)]
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in sizes]
+        opt = FlatAdamW(params, lr=1e-3, grad_buckets=nb)
+        assert 1 <= len(opt.buckets) <= nb and opt.buckets[0][0] == 0 and opt.buckets[-1][1] == sum(sizes)
+        assert all(a[1] == b[0] for a, b in zip(opt.buckets, opt.buckets[1:])) and sum(b[2] for b in opt.buckets) == len(params)
+        assert opt.bucket_of == sorted(opt.bucket_of) and len(set(opt.bucket_of)) == len(opt.buckets)
+        off = 0
+        for i, p in enumerate(params):                        # every parameter lies inside the bucket it is assigned to
+            lo, hi, _ = opt.buckets[opt.bucket_of[i]]
+            assert lo <= off and off + p.numel() <= hi
+            off += p.numel()
+
+
+def test_recording_keep_list_parks_op_allocations():
+    """ops.recording(plan, keep=[...]): buffers an op allocates while recording must outlive the plan (it replays raw pointers)."""
+    import torch
+    from mm_diffusion import ops
+    keep = []
+    with ops.recording([], keep=keep):
+        t = ops.alloc(3, 4, dtype=torch.float32, device="cpu")
+    assert len(keep) == 1 and keep[0] is t
+    u = ops.alloc(2, dtype=torch.float32, device="cpu")
+    assert len(keep) == 1 and u.shape == (2,)
+
+
+def test_retired_handles_are_only_destroyed_by_reap():
+    from mm_diffusion import _hip
+    n0 = len(_hip._retired)
+    _hip.retire("event", None)
+    _hip.retire("graph", 0)
+    assert len(_hip._retired) == n0                            # null handles are ignored
+    _hip.retire("event", 1234)
+    assert _hip._retired[-1] == ("event", 1234)
+    _hip._retired.pop()
