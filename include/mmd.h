@@ -91,7 +91,9 @@ int mmd_colsum_slices(int dtype, const void* dY, int64_t lddy, int S, int64_t Tn
  * VideoConv '3d' k=1, AudioConv k=3 dilated (D=(L,1,1), taps (+-d,0,0)) and k=1, and every qkv/proj 1x1 conv
  * (unet:83-131,272,275,378,401,605-610).  W is [Cout][ntaps*Cin] in `dtype`; bias fp32 (nullable);
  * R (nullable) residual in `dtype`.  taps is a HOST pointer.  tile: 0 auto, 64 or 128 (register-staged
- * main loop) or 129 (128x128 tile, direct-to-LDS global_load_lds main loop); all variants are bitwise identical. */
+ * main loop), 129 (128x128 tile, direct-to-LDS global_load_lds main loop), 131 (bf16 1x1 convs with Cin 128 / 256 / 384:
+ * row strips stationary in registers, weights streamed through LDS); these variants are bitwise identical.  130 = halo-tile
+ * main loop for spatial 3x3 convs (chunk-major K order: equal to rounding). */
 int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
                   void* stream);
@@ -99,7 +101,9 @@ int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const fl
 /* 1x1 conv whose input GroupNorm32(+FiLM)(+SiLU) is applied on the way into LDS (no normalised tensor in HBM):
  *   Y = act(A * gn_a[s(m)] + gn_b[s(m)]) W^T + bias (+ R),  s(m) = m / rows_per_slice  (S contiguous slices, S*rows == M,
  *   rows_per_slice >= 128, Cin <= 256).  gn_a / gn_b [S, Cin] come from mmd_gn_stats.  Replaces the ResBlock tail
- *   norm -> SiLU -> out conv -> + skip (unet:373-388,457-483). */
+ *   norm -> SiLU -> out conv -> + skip (unet:373-388,457-483).  tile 131 (bf16): the normalisation is applied once per row
+ *   strip in registers, so wide outputs (the qkv convs of the attention blocks, unet:272,605-606) fuse too; it needs
+ *   rows_per_slice >= 256 (Cin 128 / 256) or >= 128 (Cin 384). */
 int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
                    int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                    int M, int Cout, int Cin, int tile, void* stream);
@@ -108,7 +112,9 @@ int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, con
  * (ResBlock in_layers / out_layers norms, attention norms, the heads: unet:339-340,374-375; nn.py:16-33): per (64-row record,
  * column) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + column] = float2.  `stats` points at
  * the first column this launch writes (producers of a channel-concatenated tensor fill column slices of one record buffer).
- * M % 64 == 0; not with tile 130.  mmd_gn_finalize_stats consumes the records. */
+ * M % 64 == 0; not with tile 130, with tile 131 only for Cin <= 256.  The order in which a record's 64 rows are folded belongs
+ * to the kernel family (tiles 128 / 129 share one, 131 has its own): a layer must be given the same family at every batch size
+ * if its results are to be batch-invariant to the last bit.  mmd_gn_finalize_stats consumes the records. */
 int mmd_conv_gemm_stats(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                         void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
                         float* stats, int64_t stats_ld, void* stream);

@@ -871,6 +871,320 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   GEMM_TL(3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-strip main loop for 1x1 convolutions (tile code 131, bf16, Cin = 128 / 256 / 384).
+// The tiled main loops above are latency-bound on the 1x1 convs: K is 2-6 K steps, one K step is in flight per block, and every
+// output tile pays prologue + 2-6 dependent L2 round trips + epilogue (qkv conv 256 -> 768 at ds2: 65 us against ~20 us of HBM
+// time).  Here the ACTIVATIONS are stationary: a wave loads its 32*RF rows ONCE, straight from global memory into MFMA B-operand
+// fragments (16 bytes per lane per 16-channel k-step; all loads of the strip in flight together), applies GroupNorm(+FiLM)(+SiLU)
+// once in registers (the tiled GN loader redoes it for every column tile, which is why wide convs could not fuse it), and then
+// walks the output channels in chunks of CC: the chunk's weights [CC][Cin] stream through a two-stage LDS ring by
+// global_load_lds (same 128-byte-row, XOR-swizzled image as the direct-to-LDS loop, one plane per 64 channels), are shared by
+// the four waves and come from L2.  The epilogue never touches LDS: v_permlane32_swap pairs the two half-waves' 4-channel groups
+// into 8 consecutive channels per lane (16-byte stores / residual loads), and the stores of a chunk's last sub-tile are issued
+// after the chunk's barrier so that the wait for the weight DMA does not sit on their acknowledgements.
+// K order and epilogue order equal the tiled loops': Y is bitwise identical to tiles 64 / 128 / 129.  The output statistics
+// (RF = 2: a wave owns whole 64-row records) are folded in this kernel's own fixed order (rows f = 0, 1 of a lane, then a
+// recursive-halving butterfly over the 32 lanes of a half-wave), so launches that emit statistics are chosen by layer geometry,
+// never by timing (ops.strip_tile_pinned).
+// Grid = row strips x nsplit column ranges (nsplit fills the chip when M is small; results do not depend on it).
+__device__ __forceinline__ float halfwave_sum16(const float (&u)[16], int l31) {
+  // sum of u[i] over the 32 lanes of a half-wave for all sixteen i at once: each xor step halves what a lane carries; the lane
+  // ends with the total of u[l31 >> 1] (the xor-1 step completes it in both lanes of a pair)
+  float a8[8], a4[4], a2[2];
+  {
+    const bool hi = (l31 & 16) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float keep = hi ? u[8 + i] : u[i], send = hi ? u[i] : u[8 + i];
+      a8[i] = keep + __shfl_xor(send, 16, 64);
+    }
+  }
+  {
+    const bool hi = (l31 & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float keep = hi ? a8[4 + i] : a8[i], send = hi ? a8[i] : a8[4 + i];
+      a4[i] = keep + __shfl_xor(send, 8, 64);
+    }
+  }
+  {
+    const bool hi = (l31 & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float keep = hi ? a4[2 + i] : a4[i], send = hi ? a4[i] : a4[2 + i];
+      a2[i] = keep + __shfl_xor(send, 4, 64);
+    }
+  }
+  const bool hi = (l31 & 2) != 0;
+  const float keep = hi ? a2[1] : a2[0], send = hi ? a2[0] : a2[1];
+  float a1 = keep + __shfl_xor(send, 2, 64);
+  a1 += __shfl_xor(a1, 1, 64);
+  return a1;
+}
+
+template <int KS, int RF, int CC, int GNM>   // GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
+                                             // normalisation in one kernel spill ~100 registers around the branch)
+__global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
+  constexpr int K = 64 * KS;                 // input channels
+  constexpr int NCG = 4 * KS;                // 16-channel k-steps (one MFMA each)
+  constexpr int BR = 128 * RF;               // rows per block: 4 waves x RF fragments of 32 rows
+  constexpr int NA = CC / 32;                // 32-channel output sub-tiles per chunk
+  constexpr int GP = CC / 32;                // weight DMA instructions per wave per 64-channel plane (CC / 8 row groups over 4 waves)
+  constexpr int PLANE_B = CC * 128, STAGE_B = KS * PLANE_B;
+  constexpr bool DEFER = KS > 2;             // K = 128 has 1-4 chunks per block and needs the 16 registers for a third wave per SIMD
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;                           // [2 stages][KS planes][CC rows][128 B], 16-byte chunks XOR-swizzled by (row >> 1) & 7
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // the nsplit blocks of one row strip get consecutive ids inside one XCD's contiguous range: they share the strip's rows in that L2
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int sp = wgid % nsplit, mt = wgid / nsplit;
+  const int Cs = p.Cout / nsplit, cbase = sp * Cs, nchunk = Cs / CC;
+  const int m0 = mt * BR;
+  float* sBias = (float*)(smem + 2 * STAGE_B);          // [Cs] bias of this block's column range
+  float* sGN = sBias + ((Cs + 3) & ~3);                 // [2 slices][a | b][K] fused GroupNorm affine
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int lrow = lane >> 3, pc = lane & 7;
+  const char* w_ptr[GP];
+#pragma unroll
+  for (int ih = 0; ih < GP; ++ih) {
+    const int row = 8 * (ih * 4 + wave) + lrow;          // row of the chunk this lane fetches 16 bytes of
+    const int logical = pc ^ ((row >> 1) & 7);
+    w_ptr[ih] = p.W + ((int64_t)(cbase + row) * K + logical * 8) * 2;
+  }
+  auto issue = [&](int stage, int ci) {
+    const int64_t off = (int64_t)ci * CC * K * 2;
+#pragma unroll
+    for (int pl = 0; pl < KS; ++pl)
+#pragma unroll
+      for (int ih = 0; ih < GP; ++ih)
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr[ih] + off + pl * 128),
+                                         (lptr_t)(sW + stage * STAGE_B + pl * PLANE_B + (ih * 4 + wave) * 1024), 16, 0, 0);
+  };
+
+  issue(0, 0);
+  // the strip's activations: fragment f, k-step cg = 8 channels [16 cg + 8 half, +8) of row l31 - the B operand of the MFMA
+  int rowc[RF];
+  bool rok[RF];
+  u32x4 xa[RF][NCG];
+#pragma unroll
+  for (int f = 0; f < RF; ++f) {
+    const int row = m0 + wave * (32 * RF) + f * 32 + l31;   // m0 + BR may pass M by less than one block: no overflow (M < 2^31 - 256)
+    rok[f] = row < p.M;
+    rowc[f] = rok[f] ? row : p.M - 1;                    // tail rows read a valid row and are never stored
+    const char* ap = p.A + ((int64_t)rowc[f] * p.lda + half * 8) * 2;
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) xa[f][cg] = *(const u32x4*)(ap + cg * 32);
+  }
+  // bias of the column range and the GroupNorm affine rows of the (at most two) slices of the strip -> LDS.  All global loads
+  // first (branch-free: clamped indices, the zero page when there is no bias), then the LDS writes: one round trip for everything
+  constexpr bool gn = GNM != 0;
+  float bias_v[8];                                       // Cs <= 2048
+  {
+    const float* bsrc = p.bias ? p.bias + cbase : (const float*)g_zero_page;
+    const int bmul = p.bias ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias_v[i] = bsrc[min(tid + 256 * i, Cs - 1) * bmul];
+  }
+  int gsel[RF];
+#pragma unroll
+  for (int f = 0; f < RF; ++f) gsel[f] = 0;
+  float tv[KS];                                          // entry i = tid + 256 e of [2 slices][a | b][K]
+  if (gn) {
+    const int gnr = (int)p.gn_rows;                      // < 2^31: gn_S * gn_rows == M
+    const int s0 = m0 / gnr;                             // gn_rows >= BR: the strip touches at most two slices
+#pragma unroll
+    for (int e = 0; e < KS; ++e) {
+      const int i = tid + 256 * e;
+      const int sl = i / (2 * K), ab = (i / K) & 1, c = i % K;
+      const int sidx = min(s0 + sl, p.gn_S - 1);
+      tv[e] = (ab ? p.gn_b : p.gn_a)[(int64_t)sidx * K + c];
+    }
+#pragma unroll
+    for (int f = 0; f < RF; ++f) gsel[f] = min(rowc[f] / gnr - s0, 1) * 2 * K;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (tid + 256 * i < Cs) sBias[tid + 256 * i] = bias_v[i];
+  if (gn) {
+#pragma unroll
+    for (int e = 0; e < KS; ++e) sGN[tid + 256 * e] = tv[e];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                       // chunk 0 landed; bias / affine tables visible
+  if (gn) {
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        float x[8];
+        Elt<__bf16>::unpack(xa[f][cg], x);
+        const float* ap = sGN + gsel[f] + cg * 16 + half * 8;
+        const float* bp = ap + K;
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          const f32x4 av = *(const f32x4*)(ap + e), bv = *(const f32x4*)(bp + e);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float y = x[e + k] * av[k] + bv[k];
+            x[e + k] = GNM == 2 ? silu_f(y) : y;
+          }
+        }
+        u32x4 y = Elt<__bf16>::pack(x);
+        // pin the result here: otherwise the arithmetic is sunk to its first use (the MFMA loop) while all 8 KS table reads stay up
+        // front, and the kernel spills hundreds of registers
+        asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));
+        xa[f][cg] = y;
+      }
+  }
+
+  const int xsw = (l31 >> 1) & 7;
+  const bool wave_ok = (int64_t)m0 + wave * (32 * RF) < p.M;      // wave-uniform: statistics records are whole waves (RF = 2)
+  const int64_t rec = ((int64_t)m0 + wave * (32 * RF)) / 64;
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int st = ci & 1;
+    if (ci + 1 < nchunk) issue(st ^ 1, ci + 1);         // next chunk's weights land under this chunk's MFMAs
+    u32x4 outv[RF][2];                                  // the LAST sub-tile's stores wait until after the barrier (see above)
+    float srec[2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int cb = ci * CC + a * 32;                   // first column of the sub-tile inside this block's range
+      u32x4 rres[RF][2];
+      if (p.R) {
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+#pragma unroll
+          for (int j2 = 0; j2 < 2; ++j2)
+            rres[f][j2] = *(const u32x4*)(p.R + ((int64_t)rowc[f] * p.ldr + cbase + cb + 16 * j2 + 8 * half) * 2);
+      }
+      f32x16 acc[RF];
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+      const char* bW = sW + st * STAGE_B + (a * 32 + l31) * 128;
+#pragma unroll
+      for (int pl = 0; pl < KS; ++pl)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const u32x4 fw = *(const u32x4*)(bW + pl * PLANE_B + (((2 * c + half) ^ xsw) * 16));
+#pragma unroll
+          for (int f = 0; f < RF; ++f) Mma<__bf16>::run(fw, xa[f][4 * pl + c], acc[f]);
+        }
+      // acc[f][4 q + j] = channel 8 q + 4 half + j of row l31.  Pair q = 2 j2 (vdst) with q = 2 j2 + 1 (src): afterwards this lane
+      // holds the 8 consecutive channels 16 j2 + 8 half .. + 8 of its row
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        const int col = cbase + cb + 16 * j2 + 8 * half;
+        const f32x4 b0 = *(const f32x4*)(sBias + cb + 16 * j2 + 8 * half), b1 = *(const f32x4*)(sBias + cb + 16 * j2 + 8 * half + 4);
+        float u[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u[i] = 0.f;
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][8 * j2 + j]), __float_as_uint(acc[f][8 * j2 + 4 + j]),
+                                                             false, false);
+            v[j] = __uint_as_float(sw[0]);
+            v[4 + j] = __uint_as_float(sw[1]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+          if (p.R) {
+            float rf[8];
+            Elt<__bf16>::unpack(rres[f][j2], rf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rf[j];
+          }
+          const u32x4 pk = Elt<__bf16>::pack(v);
+          if (DEFER && a == NA - 1) outv[f][j2] = pk;
+          else if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = pk;
+          if (p.stats) {                                 // statistics of the values as STORED
+            float rf[8];
+            Elt<__bf16>::unpack(pk, rf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { u[2 * j] += rf[j]; u[2 * j + 1] += rf[j] * rf[j]; }
+          }
+        }
+        if (p.stats) {                                   // block-uniform
+          const float tot = halfwave_sum16(u, l31);      // float (l31 >> 1) of the 8 channels' (sum, sum of squares) records
+          if (DEFER && a == NA - 1) srec[j2] = tot;
+          else if (wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = tot;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                     // next chunk landed; every wave is past its reads of this stage
+#pragma unroll
+    for (int j2 = 0; DEFER && j2 < 2; ++j2) {
+      const int col = cbase + ci * CC + (NA - 1) * 32 + 16 * j2 + 8 * half;
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+        if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = outv[f][j2];
+      if (p.stats && wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2];
+    }
+  }
+}
+
+template <int KS, int RF, int CC, int GNM>
+static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int BR = 128 * RF, STAGE_B = KS * CC * 128;
+  const int rowblocks = cdiv(p.M, BR), nch = p.Cout / CC;
+  // column split: the smallest divisor of the chunk count that gives the chip >= ~1.75 blocks per CU (the strip's rows are then
+  // loaded nsplit times, from L2 after the first); results do not depend on it
+  int nsplit = 1;
+  for (int d = 1; d <= nch && d <= 16; ++d)
+    if (nch % d == 0) {
+      nsplit = d;
+      if ((int64_t)rowblocks * d >= 448) break;
+    }
+  const int Cs = p.Cout / nsplit;
+  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0);
+  const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4;
+  if (lds > lds_max) return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): %d output channels per block", Cs);
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_strip_kernel<KS, RF, CC, GNM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv1x1_strip: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv1x1_strip_kernel<KS, RF, CC, GNM>), dim3(rowblocks * nsplit), dim3(256), lds, st, p, nsplit);
+  return mmd_check_launch("conv1x1_strip");
+}
+
+template <int KS, int RF, int CC>
+static int launch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
+  if (!p.gn_a) return launch_conv1x1_strip_mode<KS, RF, CC, 0>(p, st);
+  return p.gn_act ? launch_conv1x1_strip_mode<KS, RF, CC, 2>(p, st) : launch_conv1x1_strip_mode<KS, RF, CC, 1>(p, st);
+}
+
+// tile 131: bf16 1x1 convs with Cin = 128 / 256 (two row fragments per wave, output statistics supported) or 384 (one fragment)
+static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
+  const int rf = p.Cin <= 256 ? 2 : 1, cc = p.Cin <= 256 ? 64 : 32;
+  if (p.ntaps != 1 || p.taps[0] || p.taps[1] || p.taps[2] || (p.Cin != 128 && p.Cin != 256 && p.Cin != 384) || p.Cout % cc != 0 ||
+      (p.gn_a && p.gn_rows < 128 * rf) || (p.stats && rf != 2))
+    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): needs a 1x1 conv with Cin 128 / 256 / 384, Cout %% %d == 0, GroupNorm "
+                         "slices of >= %d rows, output statistics only with Cin <= 256 (got Cin=%d Cout=%d)", cc, 128 * rf, p.Cin, p.Cout);
+  if (p.Cin == 128) return launch_conv1x1_strip<2, 2, 64>(p, st);
+  if (p.Cin == 256) return launch_conv1x1_strip<4, 2, 64>(p, st);
+  return launch_conv1x1_strip<6, 1, 32>(p, st);
+}
+
 template <typename T>
 static int launch_conv_gemm_halo(const ConvGemmParams& p, hipStream_t st) {
   bool taps_ok = p.ntaps <= 9;
@@ -952,7 +1266,7 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   MMD_REQUIRE(lda % epv == 0 && ldy % epv == 0 && (!R || ldr % epv == 0), "conv_gemm: row strides must be 16-byte multiples");
   MMD_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)R) % 16 == 0, "conv_gemm: pointers must be 16-byte aligned");
   MMD_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "conv_gemm: bad position dims");
-  MMD_REQUIRE(!gn_a || (gn_b && ntaps == 1 && gn_S > 0 && gn_rows >= 128 && Cin <= 256 && (int64_t)gn_S * gn_rows == M),
+  MMD_REQUIRE(!gn_a || (gn_b && ntaps == 1 && gn_S > 0 && gn_rows >= 128 && (Cin <= 256 || tile == 131) && (int64_t)gn_S * gn_rows == M),
               "gn_conv1x1: needs contiguous slices of >= 128 rows covering M and Cin <= 256 (got S=%d rows=%ld Cin=%d M=%d)",
               gn_S, (long)gn_rows, Cin, M);
   ConvGemmParams p;
@@ -966,8 +1280,9 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
-  MMD_REQUIRE(tile == 64 || tile == 128 || ((tile == 129 || tile == 130) && !gn_a),
-              "conv_gemm: tile must be 0, 64, 128, 129 (128 direct-to-LDS) or 130 (halo-tile 3x3, experimental)");
+  MMD_REQUIRE(tile == 64 || tile == 128 || ((tile == 129 || tile == 130) && !gn_a) || (tile == 131 && dtype == MMD_BF16),
+              "conv_gemm: tile must be 0, 64, 128, 129 (128 direct-to-LDS), 130 (halo-tile 3x3) or 131 (row strip, bf16 1x1 convs)");
+  if (tile == 131) return dispatch_conv1x1_strip(p, st);
   return dtype == MMD_BF16 ? dispatch_conv_gemm<__bf16>(p, tile, st) : dispatch_conv_gemm<float>(p, tile, st);
 }
 

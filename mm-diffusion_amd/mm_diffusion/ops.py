@@ -270,6 +270,39 @@ def halo_tile_pinned(x, taps, dims):
             and halo_tile_ok(x, taps, dims))
 
 
+# tile 131 (row-strip main loop for bf16 1x1 convs, mmd_gemm.hip: activations stationary in registers, GroupNorm applied once per
+# strip, the weights streamed through LDS).  Its output is bitwise equal to tiles 64 / 128 / 129, its output STATISTICS are folded in
+# its own order, so - like tile 130 - it is chosen by the layer's channel geometry alone, never by timing: a layer runs the same
+# kernel at every batch size.  MMD_GEMM_STRIP=0 switches it off (A/B), =1x1 / =gn restrict it to plain / GroupNorm-fused launches.
+_STRIP_MODE = os.environ.get("MMD_GEMM_STRIP", "0")      # not the default until its first GPU run has passed: "pin" switches it on
+
+
+def strip_tile_ok(x, Cout, taps=TAPS_1, stats=None, geom=None):
+    """Launches conv_gemm tile 131 accepts: bf16 1x1 conv, Cin 128 / 256 (two row fragments per wave, 64-channel chunks, output
+    statistics allowed) or 384 (one fragment, 32-channel chunks, no statistics); fused GroupNorm needs contiguous slices of at
+    least one block of rows (256 / 128)."""
+    M, Cin = x.shape
+    if x.dtype != torch.bfloat16 or len(taps) != 1 or tuple(taps[0]) != (0, 0, 0) or Cin not in (128, 256, 384):
+        return False
+    rf = 2 if Cin <= 256 else 1
+    if Cout % (32 * rf) or (stats is not None and (rf != 2 or M % 64)):
+        return False
+    if geom is not None and not (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 * rf
+                                 and geom.S * geom.Tn == M):
+        return False
+    return True
+
+
+def strip_tile_pinned(x, Cout, taps=TAPS_1, stats=None, geom=None):
+    if _STRIP_MODE == "0" or (_STRIP_MODE == "1x1" and geom is not None) or (_STRIP_MODE == "gn" and geom is None):
+        return False
+    return strip_tile_ok(x, Cout, taps, stats, geom)
+
+
+def _tile_name(tile):
+    return {129: "128glds", 130: "128halo", 131: "strip"}.get(tile, tile)
+
+
 def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None):
     """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None.  stats (optional): record view that receives
     the GroupNorm statistics of the output (include/mmd.h: mmd_conv_gemm_stats)."""
@@ -287,6 +320,8 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
             int(dims[0]), int(dims[1]), int(dims[2]))
     if tile == 0 and stats is None and halo_tile_pinned(x, taps, dims):
         tile = 130
+    if tile == 0 and strip_tile_pinned(x, Cout, taps, stats):
+        tile = 131
     if tile == 0:
         # statistics-emitting launches stay inside the 128-row tile family: the per-record sums are folded in an order that depends on
         # the tile's thread layout (128 / 129 share it, 64 does not), and the choice must not move the last bit of the statistics
@@ -296,7 +331,7 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
                           lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout, cands, out=out, scratch=(x, residual))
     flops = 2 * M * Cout * Cin * nt
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
-    label = f"conv_gemm<{'bf16' if es == 2 else 'f32'},{'128glds' if tile == 129 else ('128halo' if tile == 130 else tile)}>[M={M},K={Cin * nt},N={Cout}]"
+    label = f"conv_gemm<{'bf16' if es == 2 else 'f32'},{_tile_name(tile)}>[M={M},K={Cin * nt},N={Cout}]"
     if stats is not None:
         _dispatch("mmd_conv_gemm_stats", *base, tile, *_stats_args(stats, M, Cout), meta=(label, flops, nbytes))
     else:
@@ -304,8 +339,11 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     return out
 
 
-def gn_fusable(geom: Geom, Cin, Cout):
-    """Whether GroupNorm can ride in the 1x1 GEMM loader: contiguous slices of >= 128 rows, narrow K and N."""
+def gn_fusable(geom: Geom, Cin, Cout, x=None):
+    """Whether GroupNorm can ride in the 1x1 GEMM: in the tiled loader (contiguous slices of >= 128 rows, narrow K and N: every
+    column tile redoes the normalisation) or, given the input x, in the row-strip kernel (normalises once per strip: any N)."""
+    if x is not None and strip_tile_pinned(x, Cout, geom=geom):
+        return True
     return (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
             and (Cout + 127) // 128 <= 2)
 
@@ -320,17 +358,19 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     es = x.element_size()
-    if not gn_fusable(geom, Cin, Cout):
+    if not (gn_fusable(geom, Cin, Cout, x) or (tile == 131 and strip_tile_ok(x, Cout, stats=stats, geom=geom))):
         raise H.MMDError("gn_conv1x1: needs contiguous slices of >= 128 rows, Cin <= 256 (use gn_apply + conv_gemm otherwise)")
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
             w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
+    if tile == 0 and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
+        tile = 131
     if tile == 0:
         tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
                           lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout,
                           candidates=(128,) if stats is not None else (64, 128), out=out, scratch=(x, residual, a, b))
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
-    meta = (f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{tile}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes)
+    meta = (f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{_tile_name(tile)}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes)
     if stats is not None:
         _dispatch("mmd_gn_conv1x1_stats", *base, tile, *_stats_args(stats, M, Cout), meta=meta)
     else:

@@ -211,6 +211,52 @@ def test_halo_tile_is_pinned_by_layer_geometry_only():
     assert not ops.halo_tile_pinned(torch.zeros(16 * 64 * 64, 8, dtype=torch.bfloat16), ops.TAPS_SPATIAL, (16, 64, 64))   # Cin below one K step
 
 
+def test_strip_kernel_lane_model():
+    """Lane-level numpy model of conv_gemm tile 131 (tools/strip_model.py: weight DMA image + swizzle, fragment reads, the
+    activation fragments loaded straight from global memory, GroupNorm slice selection, v_permlane32_swap epilogue, recursive-halving
+    statistics, column split and XCD remap, ragged last strip): every output element is written exactly once and equals
+    X W^T + bias (+ R) to bf16 rounding; the records equal the sums over the stored values."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("strip_model", os.path.join(os.path.dirname(__file__), "..", "tools", "strip_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for (M, K, Cout, res, gn, st) in [(512, 128, 128, True, (256, True), True),        # two strips x two column ranges, statistics
+                                      (320, 256, 192, False, None, False),             # ragged second strip, three column ranges
+                                      (384, 384, 96, False, (128, False), False),      # one row fragment per wave, 32-channel chunks
+                                      (800, 128, 64, True, (400, True), True)]:        # a strip that straddles two GroupNorm slices
+        Y, ref, stats, sref, touched, nsplit = m.run(M, K, Cout, residual=res, gn=gn, want_stats=st and M % 64 == 0)
+        assert (touched == 1).all() and not np.isnan(Y).any()
+        assert np.abs(Y - ref).max() / np.abs(ref).max() < 4e-3
+        if st and M % 64 == 0:
+            assert np.abs(stats - sref).max() / np.abs(sref).max() < 1e-6
+    # the column split only fills the chip: it never splits below one chunk and always divides the chunk count
+    for M, Cout, BR, CC in [(65536, 768, 256, 64), (16384, 1152, 128, 32), (262144, 128, 256, 64), (1600, 256, 256, 64), (64, 64, 256, 64)]:
+        n = m.pick_nsplit(M, Cout, BR, CC)
+        assert (Cout // CC) % n == 0 and 1 <= n <= 16
+
+
+def test_strip_tile_is_pinned_by_layer_geometry_only(monkeypatch):
+    """Tile 131 is chosen from dtype, taps and channel counts (and, when GroupNorm is fused, the slice length) - never from M or a
+    timing: its statistics are folded in its own order, so a layer must run it at every batch size or at none."""
+    import torch
+    from mm_diffusion import ops
+    monkeypatch.setattr(ops, "_STRIP_MODE", "pin")
+    for n in (1, 2, 4, 8):
+        x = torch.zeros(n * 16 * 1024, 256, dtype=torch.bfloat16)
+        assert ops.strip_tile_pinned(x, 768) and ops.strip_tile_pinned(x, 256, stats=torch.zeros(n * 256, 256, 2))
+        assert ops.strip_tile_pinned(x, 768, geom=ops.Geom.spatial(n, 16, 1024))
+        assert ops.gn_fusable(ops.Geom.spatial(n, 16, 1024), 256, 768, x) and not ops.gn_fusable(ops.Geom.spatial(n, 16, 1024), 256, 768)
+        assert not ops.strip_tile_pinned(x, 768, geom=ops.Geom.temporal(n, 16, 1024))          # strided slices: gn_apply + plain strip GEMM
+        x3 = torch.zeros(n * 16 * 256, 384, dtype=torch.bfloat16)
+        assert ops.strip_tile_pinned(x3, 1152) and not ops.strip_tile_pinned(x3, 384, stats=torch.zeros(n * 64, 384, 2))
+    x = torch.zeros(4096, 256, dtype=torch.bfloat16)
+    assert not ops.strip_tile_pinned(x.float(), 256)                                           # fp32 mode keeps the exact-fp32 tiles
+    assert not ops.strip_tile_pinned(x, 256, taps=ops.TAPS_TEMPORAL)
+    assert not ops.strip_tile_pinned(torch.zeros(4096, 512, dtype=torch.bfloat16), 512)
+    assert not ops.strip_tile_pinned(x, 96 + 8)                                                # Cout not a multiple of the 64-channel chunk
+
+
 def test_default_lanes_and_bucket_partition():
     import torch
     from mm_diffusion.optim import FlatAdamW
