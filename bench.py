@@ -456,7 +456,10 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json is from build {pt.get('build_id')}, this is {build_id()}: not used"
         except Exception:
             pass
-        res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        bound, unit = "mfma", "TFLOP/s"
+        if a["flops"] == 0:        # an elementwise kernel dominates: price it against HBM
+            bound, unit, ach, peak = "hbm", "GB/s", a["bytes"] / (a["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS
+        res["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                            "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": a["calls"], "avg_launch_ms": a["ms"] / max(a["calls"], 1),
                            "algorithmic_gflop_per_launch": a["flops"] / max(a["calls"], 1) / 1e9,
                            "algorithmic_MB_per_launch": a["bytes"] / max(a["calls"], 1) / 1e6,

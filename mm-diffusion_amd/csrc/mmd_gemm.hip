@@ -87,6 +87,7 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
 // STATIC number of global loads per K step, so the compiler can keep the newer register stage in flight with a counted
 // s_waitcnt vmcnt(N) (a load under a divergent branch forces vmcnt(0) and serialises the pipeline).
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) uint32_t g_zero_row[32] = {};      // 128 bytes: one K plane of a padding row (strip kernel)
 
 #ifdef GEMM_TIMELINE
 // Debug builds (tools/gemm_timeline.py, -DGEMM_TIMELINE): thread 0 of every direct-to-LDS GEMM block stamps s_memrealtime
@@ -933,6 +934,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
   constexpr int GP = CC / 32;                // weight DMA instructions per wave per 64-channel plane (CC / 8 row groups over 4 waves)
   constexpr int PLANE_B = CC * 128, STAGE_B = KS * PLANE_B;
   constexpr bool DEFER = KS > 2;             // K = 128 has 1-4 chunks per block and needs the 16 registers for a third wave per SIMD
+  static_assert(RF == 2 || (CC == 32 && KS > 2), "one row fragment per wave: one sub-tile per chunk, deferred epilogue");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;                           // [2 stages][KS planes][CC rows][128 B], 16-byte chunks XOR-swizzled by (row >> 1) & 7
 
@@ -953,6 +955,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
   const int m0 = mt * BR;
   float* sBias = (float*)(smem + 2 * STAGE_B);          // [Cs] bias of this block's column range
   float* sGN = sBias + ((Cs + 3) & ~3);                 // [2 slices][a | b][K] fused GroupNorm affine
+  float* sRec = sGN + (GNM != 0 ? 4 * K : 0);           // RF = 1: [2 chunk parities][4 waves][NA * 2][32] half-record statistics
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -984,9 +987,26 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
     const int row = m0 + wave * (32 * RF) + f * 32 + l31;   // m0 + BR may pass M by less than one block: no overflow (M < 2^31 - 256)
     rok[f] = row < p.M;
     rowc[f] = rok[f] ? row : p.M - 1;                    // tail rows read a valid row and are never stored
-    const char* ap = p.A + ((int64_t)rowc[f] * p.lda + half * 8) * 2;
+    if (p.ntaps == 1) {                                  // block-uniform
+      const char* ap = p.A + ((int64_t)rowc[f] * p.lda + half * 8) * 2;
 #pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) xa[f][cg] = *(const u32x4*)(ap + cg * 32);
+      for (int cg = 0; cg < NCG; ++cg) xa[f][cg] = *(const u32x4*)(ap + cg * 32);
+    } else {
+      // several taps (temporal / audio k=3 at 128 channels): K index = tap * Cin + ci, Cin a multiple of 64, so a 64-channel plane
+      // lies inside one tap; its source row is the row shifted by the tap, or the zero row outside (D0, D1, D2)
+      const int D12 = p.D1 * p.D2;
+      const int q2 = rowc[f] % p.D2, q1 = (rowc[f] / p.D2) % p.D1, q0 = (rowc[f] / D12) % p.D0;
+#pragma unroll
+      for (int pl = 0; pl < KS; ++pl) {
+        const int tap = (64 * pl) / p.Cin, ci0 = 64 * pl - tap * p.Cin;
+        const int o0 = p.taps[3 * tap], o1 = p.taps[3 * tap + 1], o2 = p.taps[3 * tap + 2];
+        const bool ok = (unsigned)(q0 + o0) < (unsigned)p.D0 && (unsigned)(q1 + o1) < (unsigned)p.D1 && (unsigned)(q2 + o2) < (unsigned)p.D2;
+        const int64_t src = (int64_t)rowc[f] + (int64_t)o0 * D12 + o1 * p.D2 + o2;
+        const char* ap = ok ? p.A + (src * p.lda + ci0 + half * 8) * 2 : (const char*)g_zero_row + half * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xa[f][4 * pl + c] = *(const u32x4*)(ap + c * 32);
+      }
+    }
   }
   // bias of the column range and the GroupNorm affine rows of the (at most two) slices of the strip -> LDS.  All global loads
   // first (branch-free: clamped indices, the zero page when there is no bias), then the LDS writes: one round trip for everything
@@ -1122,7 +1142,13 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
         }
         if (p.stats) {                                   // block-uniform
           const float tot = halfwave_sum16(u, l31);      // float (l31 >> 1) of the 8 channels' (sum, sum of squares) records
-          if (DEFER && a == NA - 1) srec[j2] = tot;
+          if (RF == 1) {
+            // a wave holds HALF a record (32 rows): park the partial for the even wave of the pair, which adds (own + partner) after
+            // the chunk's barrier; the buffer alternates with the chunk parity, so a wave that runs ahead into the next chunk cannot
+            // overwrite what its partner has not read yet
+            if ((l31 & 1) == 0) sRec[(((ci & 1) * 4 + wave) * (NA * 2) + a * 2 + j2) * 32 + half * 16 + (l31 >> 1)] = tot;
+            srec[j2] = tot;                              // RF = 1 has one sub-tile per chunk (CC = 32)
+          } else if (DEFER && a == NA - 1) srec[j2] = tot;
           else if (wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = tot;
         }
       }
@@ -1135,7 +1161,12 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
 #pragma unroll
       for (int f = 0; f < RF; ++f)
         if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = outv[f][j2];
-      if (p.stats && wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2];
+      if (RF == 1) {
+        if (p.stats && wave_ok && (wave & 1) == 0 && (l31 & 1) == 0) {
+          const float other = sRec[(((ci & 1) * 4 + wave + 1) * (NA * 2) + (NA - 1) * 2 + j2) * 32 + half * 16 + (l31 >> 1)];
+          p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2] + other;
+        }
+      } else if (p.stats && wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2];
     }
   }
 }
@@ -1146,15 +1177,21 @@ static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
   const int rowblocks = cdiv(p.M, BR), nch = p.Cout / CC;
   // column split: the smallest divisor of the chunk count that gives the chip >= ~1.75 blocks per CU (the strip's rows are then
   // loaded nsplit times, from L2 after the first); results do not depend on it
+  static const int want_blocks = [] {                     // tuning switch (read once): MMD_STRIP_BLOCKS, default 448
+    const char* e = getenv("MMD_STRIP_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 448;
+  }();
   int nsplit = 1;
   for (int d = 1; d <= nch && d <= 16; ++d)
     if (nch % d == 0) {
       nsplit = d;
-      if ((int64_t)rowblocks * d >= 448) break;
+      if ((int64_t)rowblocks * d >= want_blocks) break;
     }
   const int Cs = p.Cout / nsplit;
-  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0);
-  const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4;
+  constexpr size_t REC_B = RF == 1 ? 2 * 4 * (CC / 32) * 2 * 32 * sizeof(float) : 0;
+  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0) + REC_B;
+  const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4 + REC_B;
   if (lds > lds_max) return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): %d output channels per block", Cs);
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
@@ -1173,16 +1210,19 @@ static int launch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
   return p.gn_act ? launch_conv1x1_strip_mode<KS, RF, CC, 2>(p, st) : launch_conv1x1_strip_mode<KS, RF, CC, 1>(p, st);
 }
 
-// tile 131: bf16 1x1 convs with Cin = 128 / 256 (two row fragments per wave, output statistics supported) or 384 (one fragment)
+// tile 131: bf16 convs whose whole K = ntaps * Cin is 128 / 256 (two row fragments per wave) or 384 / 512 (one fragment): the 1x1
+// convs at 128-512 channels and the k=3 temporal / audio convs at 128 channels.  Cin % 64 == 0; fused GroupNorm only with one tap
 static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
-  const int rf = p.Cin <= 256 ? 2 : 1, cc = p.Cin <= 256 ? 64 : 32;
-  if (p.ntaps != 1 || p.taps[0] || p.taps[1] || p.taps[2] || (p.Cin != 128 && p.Cin != 256 && p.Cin != 384) || p.Cout % cc != 0 ||
-      (p.gn_a && p.gn_rows < 128 * rf) || (p.stats && rf != 2))
-    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): needs a 1x1 conv with Cin 128 / 256 / 384, Cout %% %d == 0, GroupNorm "
-                         "slices of >= %d rows, output statistics only with Cin <= 256 (got Cin=%d Cout=%d)", cc, 128 * rf, p.Cin, p.Cout);
-  if (p.Cin == 128) return launch_conv1x1_strip<2, 2, 64>(p, st);
-  if (p.Cin == 256) return launch_conv1x1_strip<4, 2, 64>(p, st);
-  return launch_conv1x1_strip<6, 1, 32>(p, st);
+  const int K = p.Cin * p.ntaps;
+  const int rf = K <= 256 ? 2 : 1, cc = K <= 256 ? 64 : 32;
+  if ((K != 128 && K != 256 && K != 384 && K != 512) || p.Cin % 64 != 0 || p.Cout % cc != 0 || (p.gn_a && (p.ntaps != 1 || p.gn_rows < 128 * rf)) ||
+      (p.ntaps == 1 && (p.taps[0] || p.taps[1] || p.taps[2])))
+    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): needs ntaps * Cin in {128, 256, 384, 512}, Cin %% 64 == 0, Cout %% %d == 0, "
+                         "fused GroupNorm only for 1x1 convs with slices of >= %d rows (got Cin=%d ntaps=%d Cout=%d)", cc, 128 * rf, p.Cin, p.ntaps, p.Cout);
+  if (K == 128) return launch_conv1x1_strip<2, 2, 64>(p, st);
+  if (K == 256) return launch_conv1x1_strip<4, 2, 64>(p, st);
+  if (K == 384) return launch_conv1x1_strip<6, 1, 32>(p, st);
+  return launch_conv1x1_strip<8, 1, 32>(p, st);
 }
 
 template <typename T>

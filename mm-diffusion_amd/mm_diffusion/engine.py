@@ -205,7 +205,8 @@ class UNetEngine:
         """GroupNorm32(+FiLM)(+SiLU) -> 1x1 conv with the normalisation applied inside the GEMM loader."""
         C = x.shape[1]
         Cout = self.params[wkey].shape[0]
-        if not ops.gn_fusable(geom, C, Cout, x):
+        will_emit = True if (out is not None and self._rec_slice(out)[0] is not None) else None    # the launch below fills out's records
+        if not ops.gn_fusable(geom, C, Cout, x, will_emit):
             # wide outputs (qkv, deep levels) outside the row-strip kernel's shapes: every column tile would redo the normalisation
             # in its loader (measured 2x slower than materialising once), so normalise once and run the plain GEMM
             n1 = self._gn(x, gn_prefix, geom, act, film=film)

@@ -270,33 +270,40 @@ def halo_tile_pinned(x, taps, dims):
             and halo_tile_ok(x, taps, dims))
 
 
-# tile 131 (row-strip main loop for bf16 1x1 convs, mmd_gemm.hip: activations stationary in registers, GroupNorm applied once per
-# strip, the weights streamed through LDS).  Its output is bitwise equal to tiles 64 / 128 / 129, its output STATISTICS are folded in
-# its own order, so - like tile 130 - it is chosen by the layer's channel geometry alone, never by timing: a layer runs the same
-# kernel at every batch size.  MMD_GEMM_STRIP=0 switches it off (A/B), =1x1 / =gn restrict it to plain / GroupNorm-fused launches.
-_STRIP_MODE = os.environ.get("MMD_GEMM_STRIP", "0")      # not the default until its first GPU run has passed: "pin" switches it on
+# tile 131 (row-strip main loop, mmd_gemm.hip: a wave's rows stationary in registers as MFMA operands, GroupNorm applied once per
+# strip, the weights streamed through LDS) for the bf16 convs whose whole K = ntaps * Cin is 128 ... 512: the 1x1 convs at 128-512
+# channels and the k=3 temporal / audio convs at 128 channels.  Its output is bitwise equal to tiles 64 / 128 / 129, its output
+# STATISTICS are folded in its own order, so - like tile 130 - it is chosen by the layer's channel geometry alone, never by timing:
+# a layer runs the same kernel at every batch size.  MMD_GEMM_STRIP=0 switches it off (A/B); =base restricts it to the first
+# validated subset (1x1 convs, Cin 128 / 256 / 384, statistics only up to 256 channels).
+_STRIP_MODE = os.environ.get("MMD_GEMM_STRIP", "pin")
 
 
-def strip_tile_ok(x, Cout, taps=TAPS_1, stats=None, geom=None):
-    """Launches conv_gemm tile 131 accepts: bf16 1x1 conv, Cin 128 / 256 (two row fragments per wave, 64-channel chunks, output
-    statistics allowed) or 384 (one fragment, 32-channel chunks, no statistics); fused GroupNorm needs contiguous slices of at
-    least one block of rows (256 / 128)."""
+def strip_tile_ok(x, Cout, taps=TAPS_1, stats=None, geom=None, base=False):
+    """Launches conv_gemm tile 131 accepts: bf16, K = ntaps * Cin in {128, 256} (two row fragments per wave, 64-channel chunks) or
+    {384, 512} (one fragment, 32-channel chunks), Cin a multiple of 64; output statistics need M % 64 == 0; fused GroupNorm (1x1 convs
+    only) needs contiguous slices of at least one block of rows (256 / 128)."""
     M, Cin = x.shape
-    if x.dtype != torch.bfloat16 or len(taps) != 1 or tuple(taps[0]) != (0, 0, 0) or Cin not in (128, 256, 384):
+    K = len(taps) * Cin
+    if x.dtype != torch.bfloat16 or K not in (128, 256, 384, 512) or Cin % 64:
         return False
-    rf = 2 if Cin <= 256 else 1
-    if Cout % (32 * rf) or (stats is not None and (rf != 2 or M % 64)):
+    if len(taps) == 1 and tuple(taps[0]) != (0, 0, 0):
         return False
-    if geom is not None and not (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 * rf
-                                 and geom.S * geom.Tn == M):
+    rf = 2 if K <= 256 else 1
+    if Cout % (32 * rf) or (stats is not None and M % 64):
+        return False
+    if base and (len(taps) != 1 or K == 512 or (stats is not None and rf != 2)):
+        return False
+    if geom is not None and not (len(taps) == 1 and geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn
+                                 and geom.Tn >= 128 * rf and geom.S * geom.Tn == M):
         return False
     return True
 
 
 def strip_tile_pinned(x, Cout, taps=TAPS_1, stats=None, geom=None):
-    if _STRIP_MODE == "0" or (_STRIP_MODE == "1x1" and geom is not None) or (_STRIP_MODE == "gn" and geom is None):
+    if _STRIP_MODE == "0":
         return False
-    return strip_tile_ok(x, Cout, taps, stats, geom)
+    return strip_tile_ok(x, Cout, taps, stats, geom, base=_STRIP_MODE == "base")
 
 
 def _tile_name(tile):
@@ -339,10 +346,11 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     return out
 
 
-def gn_fusable(geom: Geom, Cin, Cout, x=None):
+def gn_fusable(geom: Geom, Cin, Cout, x=None, stats=None):
     """Whether GroupNorm can ride in the 1x1 GEMM: in the tiled loader (contiguous slices of >= 128 rows, narrow K and N: every
-    column tile redoes the normalisation) or, given the input x, in the row-strip kernel (normalises once per strip: any N)."""
-    if x is not None and strip_tile_pinned(x, Cout, geom=geom):
+    column tile redoes the normalisation) or, given the input x (and whether the launch will emit output statistics), in the
+    row-strip kernel (normalises once per strip: any N)."""
+    if x is not None and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
         return True
     return (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
             and (Cout + 127) // 128 <= 2)
@@ -358,7 +366,7 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     es = x.element_size()
-    if not (gn_fusable(geom, Cin, Cout, x) or (tile == 131 and strip_tile_ok(x, Cout, stats=stats, geom=geom))):
+    if not (gn_fusable(geom, Cin, Cout, x, stats) or (tile == 131 and strip_tile_ok(x, Cout, stats=stats, geom=geom))):
         raise H.MMDError("gn_conv1x1: needs contiguous slices of >= 128 rows, Cin <= 256 (use gn_apply + conv_gemm otherwise)")
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
             w.data_ptr(), H.ptr(bias), H.ptr(residual),

@@ -230,6 +230,15 @@ def test_strip_kernel_lane_model():
         assert np.abs(Y - ref).max() / np.abs(ref).max() < 4e-3
         if st and M % 64 == 0:
             assert np.abs(stats - sref).max() / np.abs(sref).max() < 1e-6
+    # one row fragment per wave with statistics (the even wave of a pair adds its partner's half-record after the chunk's barrier),
+    # K = 512, and the k=3 convs at 128 channels (a 64-channel plane of the fragment = the row shifted by the tap, or the zero row)
+    for (M, K, Cout, res, taps, dims) in [(384, 384, 96, False, None, (1, 1, 1)), (256, 512, 96, True, None, (1, 1, 1)),
+                                          (512, 384, 64, True, [(-1, 0, 0), (0, 0, 0), (1, 0, 0)], (4, 128, 1)),
+                                          (640, 384, 32, False, [(-4, 0, 0), (0, 0, 0), (4, 0, 0)], (320, 1, 1))]:
+        Y, ref, stats, sref, touched, nsplit = m.run(M, K, Cout, residual=res, want_stats=True, taps=taps, dims=dims)
+        assert (touched == 1).all() and not np.isnan(Y).any() and not np.isnan(stats).any()
+        assert np.abs(Y - ref).max() / np.abs(ref).max() < 4e-3
+        assert np.abs(stats - sref).max() / np.abs(sref).max() < 1e-6
     # the column split only fills the chip: it never splits below one chunk and always divides the chunk count
     for M, Cout, BR, CC in [(65536, 768, 256, 64), (16384, 1152, 128, 32), (262144, 128, 256, 64), (1600, 256, 256, 64), (64, 64, 256, 64)]:
         n = m.pick_nsplit(M, Cout, BR, CC)
@@ -249,11 +258,17 @@ def test_strip_tile_is_pinned_by_layer_geometry_only(monkeypatch):
         assert ops.gn_fusable(ops.Geom.spatial(n, 16, 1024), 256, 768, x) and not ops.gn_fusable(ops.Geom.spatial(n, 16, 1024), 256, 768)
         assert not ops.strip_tile_pinned(x, 768, geom=ops.Geom.temporal(n, 16, 1024))          # strided slices: gn_apply + plain strip GEMM
         x3 = torch.zeros(n * 16 * 256, 384, dtype=torch.bfloat16)
-        assert ops.strip_tile_pinned(x3, 1152) and not ops.strip_tile_pinned(x3, 384, stats=torch.zeros(n * 64, 384, 2))
+        assert ops.strip_tile_pinned(x3, 1152) and ops.strip_tile_pinned(x3, 384, stats=torch.zeros(n * 64, 384, 2))
+        g3 = ops.Geom.per_sample(n, 16 * 256)
+        assert ops.gn_fusable(g3, 384, 1152, x3) and ops.gn_fusable(g3, 384, 384, x3, True)
+        assert not ops.strip_tile_ok(x3, 384, stats=True, base=True) and not ops.gn_fusable(ops.Geom.per_sample(n * 64, 64), 384, 384, x3, True)
+        x1 = torch.zeros(n * 16 * 4096, 128, dtype=torch.bfloat16)
+        assert ops.strip_tile_pinned(x1, 128, taps=ops.TAPS_TEMPORAL, stats=True) and ops.strip_tile_pinned(x1[: n * 25600], 128, taps=ops.taps_audio(16))
     x = torch.zeros(4096, 256, dtype=torch.bfloat16)
     assert not ops.strip_tile_pinned(x.float(), 256)                                           # fp32 mode keeps the exact-fp32 tiles
-    assert not ops.strip_tile_pinned(x, 256, taps=ops.TAPS_TEMPORAL)
-    assert not ops.strip_tile_pinned(torch.zeros(4096, 512, dtype=torch.bfloat16), 512)
+    assert not ops.strip_tile_pinned(x, 256, taps=ops.TAPS_TEMPORAL)                           # K = 768
+    assert ops.strip_tile_pinned(torch.zeros(4096, 512, dtype=torch.bfloat16), 512)
+    assert not ops.strip_tile_pinned(torch.zeros(4096, 640, dtype=torch.bfloat16), 512)
     assert not ops.strip_tile_pinned(x, 96 + 8)                                                # Cout not a multiple of the 64-channel chunk
 
 

@@ -9,9 +9,11 @@ import torch
 
 from helpers import rel_l2
 
-import os
+from mm_diffusion import ops as _ops
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("MMD_GEMM_STRIP", "0") == "0", reason="tile 131 is opt-in until validated on the GPU")]
+# MMD_GEMM_STRIP (ops._STRIP_MODE): "0" = tile 131 off, "base" = 1x1 convs at 128 / 256 / 384 channels (statistics up to 256), "pin" = all
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(_ops._STRIP_MODE == "0", reason="tile 131 switched off")]
+full = pytest.mark.skipif(_ops._STRIP_MODE != "pin", reason="k=3 convs, K = 512 and one-fragment statistics need MMD_GEMM_STRIP=pin")
 BF = torch.bfloat16
 
 
@@ -39,6 +41,8 @@ def _operands(M, Cin, Cout, res, seed):
     (100, 128, 64, True),                # fewer rows than one wave pair
     (4096 + 32, 384, 96, True),          # ragged tail at 32-row granularity, three 32-channel chunks
     (25600, 256, 256, False),
+    pytest.param(4096, 512, 1536, False, marks=full),            # ds8 qkv: K = 512, sixteen column ranges per strip
+    pytest.param(4096 + 64, 512, 512, True, marks=full),
 ])
 def test_strip_output_is_bitwise_the_tiled_output(ops, M, Cin, Cout, res):
     x, w, b, r, _ = _operands(M, Cin, Cout, res, M + Cin + Cout)
@@ -50,6 +54,38 @@ def test_strip_output_is_bitwise_the_tiled_output(ops, M, Cin, Cout, res):
         assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
     y2 = ops.conv_gemm(x, w, None, residual=r, tile=131)            # no bias: the zero page
     assert torch.equal(y2, ops.conv_gemm(x, w, None, residual=r, tile=129))
+
+
+@full
+@pytest.mark.parametrize("N,F,HW,Cout,res,form", [(2, 16, 256, 128, False, "temporal"), (1, 5, 96, 64, True, "temporal"), (3, 1, 800, 128, True, "audio4"),
+                                                  (2, 16, 64, 256, False, "temporal_d1")])
+def test_strip_k3_convs_at_128_channels(ops, N, F, HW, Cout, res, form):
+    """The k=3 temporal conv (D = (F, HW, 1), taps (+-1, 0, 0); also in the (N, F, HW) form) and the dilated audio conv (D = (L, 1, 1),
+    taps (+-d, 0, 0)) at 128 channels: K = 384 is one strip; a 64-channel plane of the activation fragment comes from the row shifted
+    by its tap, or from the zero row outside the clip.  Bitwise the tiled kernels' output, statistics to fp32 rounding."""
+    Cin = 128
+    if form == "temporal":
+        M, taps, dims = N * F * HW, ops.TAPS_TEMPORAL, (F, HW, 1)
+    elif form == "temporal_d1":
+        M, taps, dims = N * F * HW, ops.TAPS_TEMPORAL_D1, (N, F, HW)
+    else:
+        M, taps, dims = N * HW, ops.taps_audio(4), (HW, 1, 1)
+    g = torch.Generator(device="cuda").manual_seed(M + Cout)
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(BF)
+    w = (torch.randn(Cout, 3 * Cin, device="cuda", generator=g) * (3 * Cin) ** -0.5).to(BF)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(M, Cout, device="cuda", generator=g).to(BF) if res else None
+    y0 = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=129)
+    y1 = torch.full_like(y0, float("nan"))
+    ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=131, out=y1)
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    if M % 64 == 0:
+        rec = torch.full((M // 64, Cout, 2), 7.0, device="cuda")
+        y2 = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=131, stats=rec)
+        assert torch.equal(y0, y2)
+        yf = y2.double().view(M // 64, 64, Cout)
+        ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
+        assert float((rec.double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
 def test_strip_strided_views(ops):
@@ -110,7 +146,9 @@ def test_strip_fused_groupnorm(ops, S, Tn, Cin, Cout, act, res):
     assert e_ref < 6e-3 and e_unf < 4e-3
 
 
-@pytest.mark.parametrize("M,Cin,Cout,res,gn", [(4096, 128, 128, True, True), (2048 + 64, 256, 320, False, False), (8192, 256, 256, True, True)])
+@pytest.mark.parametrize("M,Cin,Cout,res,gn", [(4096, 128, 128, True, True), (2048 + 64, 256, 320, False, False), (8192, 256, 256, True, True),
+                                               pytest.param(16384, 384, 384, True, False, marks=full), pytest.param(4096 + 128, 512, 512, True, False, marks=full),
+                                               pytest.param(2048, 384, 96, False, True, marks=full)])
 def test_strip_output_statistics(ops, M, Cin, Cout, res, gn):
     """Per (64-row record, column) sum / sum of squares of the values as stored, written into a column slice of a wider record buffer;
     emitting them does not change the output."""
@@ -158,11 +196,15 @@ def test_strip_rows_do_not_depend_on_the_batch(ops):
     assert torch.equal(z4[:Tn], z1) and torch.equal(r4[:Tn // 64], r1)
 
 
+@full
 def test_strip_is_pinned_by_layer_geometry(ops):
     x = torch.zeros(512, 256, device="cuda", dtype=BF)
     assert ops.strip_tile_pinned(x, 768) and ops.strip_tile_pinned(x, 256, stats=torch.zeros(8, 256, 2))
     assert not ops.strip_tile_pinned(x.float(), 768)                               # fp32 mode keeps the exact-fp32 tiles
-    assert not ops.strip_tile_pinned(torch.zeros(512, 512, device="cuda", dtype=BF), 512)
+    assert ops.strip_tile_pinned(torch.zeros(512, 512, device="cuda", dtype=BF), 512)
+    assert not ops.strip_tile_pinned(torch.zeros(512, 640, device="cuda", dtype=BF), 512)
     x3 = torch.zeros(512, 384, device="cuda", dtype=BF)
-    assert ops.strip_tile_pinned(x3, 1152) and not ops.strip_tile_pinned(x3, 384, stats=torch.zeros(8, 384, 2))
+    assert ops.strip_tile_pinned(x3, 1152) and ops.strip_tile_pinned(x3, 384, stats=torch.zeros(8, 384, 2))
+    x1 = torch.zeros(512, 128, device="cuda", dtype=BF)
+    assert ops.strip_tile_pinned(x1, 128, taps=ops.TAPS_TEMPORAL) and not ops.strip_tile_pinned(x, 256, taps=ops.TAPS_TEMPORAL)   # K = 768
     assert not ops.strip_tile_pinned(x, 768, geom=ops.Geom.per_sample(4, 128))    # slices shorter than a strip: gn_apply + GEMM

@@ -29,6 +29,27 @@ def load(d, counter):
     return tot, cnt
 
 
+def label_of(kernel_name):
+    """rocprofv3 kernel name -> the label bench.py's breakdown uses for the same launches (bf16 instances only).  rocprofv3 reports
+    some instances mangled (_Z16conv_gemm_kernelIDF16bLi128ELi128ELb0EE...) and demangles __bf16 as `bool _Accum` in others."""
+    import re
+    k = kernel_name
+    fp32 = "<float" in k or re.search(r"kernelIf", k) is not None
+    m = re.search(r"conv1x1_strip_kernel(?:<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)|ILi\d+ELi\d+ELi\d+ELi(\d+)E)", k)
+    if m:
+        return "conv_gemm<bf16,strip>" if (m.group(1) or m.group(2)) == "0" else "gn_conv1x1<bf16,strip>"
+    if fp32:
+        return None
+    if "conv_gemm_glds_kernel" in k:
+        return "conv_gemm<bf16,128glds>"
+    if "conv_gemm_halo_kernel" in k:
+        return "conv_gemm<bf16,128halo>"
+    m = re.search(r"conv_gemm_kernelIDF16bLi(\d+)ELi\d+ELb([01])E", k) or re.search(r"conv_gemm_kernel<[^,]+,\s*(\d+),\s*\d+,\s*(true|false|1|0)", k)
+    if m:
+        return ("gn_conv1x1" if m.group(2) in ("true", "1") else "conv_gemm") + f"<bf16,{m.group(1)}>"
+    return None
+
+
 def main():
     fd, wd, out = sys.argv[1:4]
     jout = sys.argv[4] if len(sys.argv) > 4 else None
@@ -49,19 +70,17 @@ def main():
         for _, n, f, w, k in rows[:24]:
             fo.write(f"{n:7d} {f:15.1f} {2 * f * 1024 / 1e6:17.2f} {w:15.1f} {w * 1024 / 1e6:14.2f}  {k[:110]}\n")
     if jout:
-        traffic = {}
+        # launch-weighted mean per bench.py label (kernel family), so whichever family dominates the step finds its traffic here
+        traffic, acc = {}, collections.defaultdict(lambda: [0.0, 0.0])
         for _, n, f, w, k in rows:
-            if "conv_gemm_glds_kernel" in k:
-                traffic["conv_gemm<bf16,128glds>"] = traffic.get("conv_gemm<bf16,128glds>", 0.0) + 0.0
-        # launch-weighted mean over the template instances of the dominant kernel family
-        num = den = 0.0
-        for _, n, f, w, k in rows:
-            if "conv_gemm_glds_kernel" in k:
-                num += n * (2 * f + w) * 1024
-                den += n
-        if den:
-            traffic["conv_gemm<bf16,128glds>"] = num / den
-        traffic["_source"] = f"{os.path.basename(out)}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of conv_gemm_glds_kernel<bf16,*>, rocprofv3 --pmc passes"
+            lab = label_of(k)
+            if lab:
+                acc[lab][0] += n * (2 * f + w) * 1024
+                acc[lab][1] += n
+        for lab, (num, den) in acc.items():
+            if den:
+                traffic[lab] = num / den
+        traffic["_source"] = f"{os.path.basename(out)}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, launch-weighted over the template instances of a kernel family, rocprofv3 --pmc passes"
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         try:                                   # the build the passes were measured on: bench.py only accepts a matching file
             import bench

@@ -52,18 +52,31 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32)
 
 
-def run(M, K, Cout, bias=True, residual=False, gn=None, want_stats=False, seed=0):
-    """Whole launch on random bf16-representable data.  Returns (Y model, Y reference, stats model, stats reference, touched)."""
+def run(M, K, Cout, bias=True, residual=False, gn=None, want_stats=False, seed=0, taps=None, dims=(1, 1, 1)):
+    """Whole launch on random bf16-representable data.  K = ntaps * Cin; taps = [(o0, o1, o2)] over dims (D0, D1, D2), zero padded.
+    Returns (Y model, Y reference, stats model, stats reference, touched, nsplit)."""
     rng = np.random.default_rng(seed)
     KS = K // 64
     RF, CC = (2, 64) if K <= 256 else (1, 32)
     BR = 128 * RF
-    A = bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    taps = taps or [(0, 0, 0)]
+    Cin = K // len(taps)
+    A = bf16_round(rng.standard_normal((M, Cin)).astype(np.float32))
     W = bf16_round((rng.standard_normal((Cout, K)) / np.sqrt(K)).astype(np.float32))
     b = rng.standard_normal(Cout).astype(np.float32) if bias else None
     R = bf16_round(rng.standard_normal((M, Cout)).astype(np.float32)) if residual else None
     g = None
     X = A
+    if len(taps) > 1:                                            # im2row reference: X[m] = [A[src(m, tap)] or 0 for tap in taps]
+        D0, D1, D2 = dims
+        m = np.arange(M)
+        q2, q1, q0 = m % D2, (m // D2) % D1, (m // (D1 * D2)) % D0
+        cols = []
+        for (o0, o1, o2) in taps:
+            ok = (q0 + o0 >= 0) & (q0 + o0 < D0) & (q1 + o1 >= 0) & (q1 + o1 < D1) & (q2 + o2 >= 0) & (q2 + o2 < D2)
+            src = np.clip(m + o0 * D1 * D2 + o1 * D2 + o2, 0, M - 1)
+            cols.append(np.where(ok[:, None], A[src], 0.0))
+        X = np.concatenate(cols, axis=1).astype(np.float32)
     if gn is not None:
         rows, act = gn
         S = M // rows
@@ -81,7 +94,7 @@ def run(M, K, Cout, bias=True, residual=False, gn=None, want_stats=False, seed=0
     touched = np.zeros((M, Cout), np.int32)
     stats = np.full((M // 64 if M % 64 == 0 else 1, Cout, 2), np.nan, np.float32)
     for bid in range(nwg):
-        _run_block_chunks(bid, nwg, nsplit, KS, RF, CC, A, W, b, R, M, Cout, g, want_stats, Y, stats, touched)
+        _run_block_chunks(bid, nwg, nsplit, KS, RF, CC, A, W, b, R, M, Cout, g, want_stats, Y, stats, touched, taps, dims)
     ref = X.astype(np.float64) @ W.astype(np.float64).T
     if b is not None:
         ref = ref + b
@@ -94,7 +107,7 @@ def run(M, K, Cout, bias=True, residual=False, gn=None, want_stats=False, seed=0
     return Y, ref, stats, sref, touched, nsplit
 
 
-def _run_block_chunks(bid, nwg, nsplit, KS, RF, CC, A, W, bias, R, M, Cout, gn, want_stats, Y, stats, touched):
+def _run_block_chunks(bid, nwg, nsplit, KS, RF, CC, A, W, bias, R, M, Cout, gn, want_stats, Y, stats, touched, taps=((0, 0, 0),), dims=(1, 1, 1)):
     """One workgroup.  A [M, K], W [Cout, K] (bf16-representable values), gn = (a [S, K], b [S, K], rows per slice, act).  The
     two-stage ring is modelled faithfully: chunk ci is computed from stage ci & 1 after chunk ci + 1 has been issued into the other
     stage (an LDS image that was never written reads back NaN)."""
@@ -125,8 +138,23 @@ def _run_block_chunks(bid, nwg, nsplit, KS, RF, CC, A, W, bias, R, M, Cout, gn, 
         rows = [m0 + wave * 32 * RF + f * 32 + l31 for f in range(RF)]
         rok = [r < M for r in rows]
         rowc = [np.where(ok, r, M - 1) for r, ok in zip(rows, rok)]
-        xa = [[A[rowc[f][:, None], (16 * cg + 8 * half)[:, None] + np.arange(8)[None, :]].astype(np.float32) for cg in range(NCG)]
-              for f in range(RF)]
+        if len(taps) == 1:
+            xa = [[A[rowc[f][:, None], (16 * cg + 8 * half)[:, None] + np.arange(8)[None, :]].astype(np.float32) for cg in range(NCG)]
+                  for f in range(RF)]
+        else:                                                    # a 64-channel plane lies inside one tap: shifted row or the zero row
+            Cin, (D0, D1, D2) = A.shape[1], dims
+            xa = [[None] * NCG for _ in range(RF)]
+            for f in range(RF):
+                q2, q1, q0 = rowc[f] % D2, (rowc[f] // D2) % D1, (rowc[f] // (D1 * D2)) % D0
+                for pl in range(KS):
+                    tap = (64 * pl) // Cin
+                    ci0 = 64 * pl - tap * Cin
+                    o0, o1, o2 = taps[tap]
+                    ok = (q0 + o0 >= 0) & (q0 + o0 < D0) & (q1 + o1 >= 0) & (q1 + o1 < D1) & (q2 + o2 >= 0) & (q2 + o2 < D2)
+                    src = np.where(ok, rowc[f] + o0 * D1 * D2 + o1 * D2 + o2, 0)
+                    for c in range(4):
+                        ch = (ci0 + 16 * c + 8 * half)[:, None] + np.arange(8)[None, :]
+                        xa[f][4 * pl + c] = np.where(ok[:, None], A[src[:, None], ch], 0.0).astype(np.float32)
         if gn is not None:
             ga, gb, gnr, act = gn
             s0, S = m0 // gnr, ga.shape[0]
@@ -145,10 +173,12 @@ def _run_block_chunks(bid, nwg, nsplit, KS, RF, CC, A, W, bias, R, M, Cout, gn, 
         waves.append((rows, rok, rowc, xa))
     issue(0, 0)
     xsw = (l31 >> 1) & 7
+    sRec = np.full((2, 4, NA * 2, 32), np.nan, np.float32)     # RF = 1: half-record partials, double-buffered by chunk parity
     for ci in range(nchunk):
         st = ci & 1
         if ci + 1 < nchunk:
             issue(st ^ 1, ci + 1)
+        own = {}
         for wave in range(4):
             rows, rok, rowc, xa = waves[wave]
             wave_ok = m0 + wave * 32 * RF < M
@@ -194,15 +224,32 @@ def _run_block_chunks(bid, nwg, nsplit, KS, RF, CC, A, W, bias, R, M, Cout, gn, 
                         u[:, 1::2] += pk * pk
                     if want_stats:
                         tot = halfwave_sum16(u)
-                        for ln in range(64):
-                            if wave_ok and (l31[ln] & 1) == 0:
-                                stats.reshape(-1)[(rec * Cout + col[ln]) * 2 + (l31[ln] >> 1)] = tot[ln]
+                        if RF == 1:
+                            for ln in range(64):
+                                if (l31[ln] & 1) == 0:
+                                    sRec[ci & 1, wave, a * 2 + j2, half[ln] * 16 + (l31[ln] >> 1)] = tot[ln]
+                            own[(wave, j2)] = (tot, col, rec, wave_ok)
+                        else:
+                            for ln in range(64):
+                                if wave_ok and (l31[ln] & 1) == 0:
+                                    stats.reshape(-1)[(rec * Cout + col[ln]) * 2 + (l31[ln] >> 1)] = tot[ln]
+        # after the chunk's barrier: the even wave of a pair adds its partner's half-record and stores
+        if want_stats and RF == 1:
+            for (wave, j2), (tot, col, rec, wave_ok) in own.items():
+                if wave_ok and wave % 2 == 0:
+                    for ln in range(64):
+                        if (l31[ln] & 1) == 0:
+                            other = sRec[ci & 1, wave + 1, (NA - 1) * 2 + j2, half[ln] * 16 + (l31[ln] >> 1)]
+                            stats.reshape(-1)[(rec * Cout + col[ln]) * 2 + (l31[ln] >> 1)] = np.float32(tot[ln] + other)
 
 
 if __name__ == "__main__":
-    for (M, K, Cout, res, gn, st) in [(512, 128, 128, True, (256, True), True), (320, 256, 192, False, None, False),
-                                      (384, 384, 96, False, (128, False), False)]:
-        Y, ref, stats, sref, touched, nsplit = run(M, K, Cout, residual=res, gn=gn, want_stats=st)
+    for (M, K, Cout, res, gn, st, taps, dims) in [(512, 128, 128, True, (256, True), True, None, (1, 1, 1)),
+                                                  (320, 256, 192, False, None, False, None, (1, 1, 1)),
+                                                  (384, 384, 96, False, (128, False), True, None, (1, 1, 1)),
+                                                  (512, 384, 64, True, None, True, [(-1, 0, 0), (0, 0, 0), (1, 0, 0)], (4, 128, 1)),
+                                                  (256, 512, 96, False, None, True, None, (1, 1, 1))]:
+        Y, ref, stats, sref, touched, nsplit = run(M, K, Cout, residual=res, gn=gn, want_stats=st, taps=taps, dims=dims)
         err = np.abs(Y - ref).max() / np.abs(ref).max()
         print(f"M={M} K={K} N={Cout} nsplit={nsplit}: every element written once: {bool((touched == 1).all())}, max rel err {err:.2e}"
               + (f", stats max rel err {np.abs(stats - sref).max() / np.abs(sref).max():.2e}" if st else ""))

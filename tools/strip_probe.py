@@ -31,6 +31,12 @@ SHAPES = [
     ("a ds2 qkv", 25600, 256, 768, (4, False), False, False),
     ("a ds2 res out conv + skip", 25600, 256, 256, (4, True), True, True),
     ("a ds4 qkv", 6400, 384, 1152, (4, False), False, False),
+    ("v ds4 proj_out + x (stats)", 16384, 384, 384, None, True, True),
+    ("v ds8 qkv", 4096, 512, 1536, (4, False), False, False),
+    ("v ds8 proj_out + x (stats)", 4096, 512, 512, None, True, True),
+    ("v ds1 temporal k3 (stats)", 262144, 128, 128, "temporal", False, True),
+    ("v ds1 temporal k3", 262144, 128, 128, "temporal", False, False),
+    ("a ds1 conv k3 d=4 (stats)", 102400, 128, 128, "audio", False, True),
 ]
 
 
@@ -67,17 +73,24 @@ def main():
         y_new = torch.full((M, Cout), float("nan"), device="cuda", dtype=BF)
         rec_old = torch.zeros(M // 64, Cout, 2, device="cuda") if st else None
         rec_new = torch.zeros(M // 64, Cout, 2, device="cuda") if st else None
-        if gn is None:
-            t_old = 128 if st else 129                       # statistics launches are pinned to the 128-row family; time both
+        if gn is None or isinstance(gn, str):
+            taps, dims = ops.TAPS_1, (1, 1, 1)
+            if gn == "temporal":                             # D = (F, HW, 1), 16 frames
+                taps, dims = ops.TAPS_TEMPORAL, (16, M // (4 * 16), 1)
+            elif gn == "audio":
+                taps, dims = ops.taps_audio(4), (M // 4, 1, 1)
+            if len(taps) > 1:
+                w = (torch.randn(Cout, Cin * len(taps), device="cuda", generator=g) * (Cin * len(taps)) ** -0.5).to(BF)
+
             def old():
-                ops.conv_gemm(x, w, b, residual=r, tile=t_old, out=y_old, stats=rec_old)
+                ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=129, out=y_old, stats=rec_old)
 
             def new():
-                ops.conv_gemm(x, w, b, residual=r, tile=131, out=y_new, stats=rec_new)
-            how = f"tile {t_old}"
+                ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=131, out=y_new, stats=rec_new)
+            how = "tile 129"                                 # the autotuner's choice among the 128-row family at these sizes
             if st:
-                us129 = timed(lambda: ops.conv_gemm(x, w, b, residual=r, tile=129, out=y_old, stats=rec_old))
-                how += f" (129: {us129:.1f} us)"
+                us128 = timed(lambda: ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=128, out=y_old, stats=rec_old))
+                how += f" (128: {us128:.1f} us)"
         else:
             S, act = gn
             geom = ops.Geom.per_sample(S, M // S)
@@ -106,11 +119,12 @@ def main():
             yf = y_new.double().view(M // 64, 64, Cout)
             ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
             serr = f" stats-err {float((rec_new.double() - ref).abs().max() / ref.abs().max()):.1e}"
+        kk = Cin * (3 if isinstance(gn, str) else 1)
         nbytes = 2 * (M * Cin + M * Cout * (2 if res else 1))
         tot_old += us_old
         tot_new += us_new
         print(f"{name:28s} M={M:6d} {Cin:3d}->{Cout:4d} | {how:34s} {us_old:7.1f} us | strip {us_new:7.1f} us "
-              f"({nbytes / us_new / 1e6:5.2f} TB/s, {2.0 * M * Cin * Cout / us_new / 1e6:5.0f} TF/s) | x{us_old / us_new:4.2f} | "
+              f"({nbytes / us_new / 1e6:5.2f} TB/s, {2.0 * M * kk * Cout / us_new / 1e6:5.0f} TF/s) | x{us_old / us_new:4.2f} | "
               f"bitwise={same} rel-L2 {err:.1e}{serr}", flush=True)
     print(f"sum: old {tot_old:.0f} us, strip {tot_new:.0f} us")
 
