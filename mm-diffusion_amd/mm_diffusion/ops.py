@@ -346,12 +346,32 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     return out
 
 
-def gn_fusable(geom: Geom, Cin, Cout, x=None, stats=None):
+def strip_column_split(M, K, Cout):
+    """The column split conv_gemm tile 131 launches with (mmd_gemm.hip: launch_conv1x1_strip_mode): the smallest divisor of the chunk
+    count that gives the chip >= 448 blocks, at most 16."""
+    rf, cc = (2, 64) if K <= 256 else (1, 32)
+    rowblocks, nch, n = -(-M // (128 * rf)), Cout // cc, 1
+    for d in range(1, min(nch, 16) + 1):
+        if nch % d == 0:
+            n = d
+            if rowblocks * d >= 448:
+                break
+    return n
+
+
+def gn_fusable(geom: Geom, Cin, Cout, x=None, stats=None, act=False):
     """Whether GroupNorm can ride in the 1x1 GEMM: in the tiled loader (contiguous slices of >= 128 rows, narrow K and N: every
     column tile redoes the normalisation) or, given the input x (and whether the launch will emit output statistics), in the
-    row-strip kernel (normalises once per strip: any N)."""
-    if x is not None and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
-        return True
+    row-strip kernel (normalises once per strip: any N).
+
+    A layer whose GEMM runs on the strip kernel never goes back to the tiled loader (its statistics are folded in another order);
+    what may depend on M is only whether the normalisation is FUSED: every block of a strip's column split redoes it, and with SiLU
+    that is ~12 VALU instructions per element, so when few rows force a deep split (M = 4096 at 512 channels: 16 ranges, 34 us fused
+    against 5 + 17 us) gn_apply + the plain strip GEMM is the faster of two bitwise-equal paths (tests/test_strip_gpu.py)."""
+    if x is not None and strip_tile_pinned(x, Cout, stats=stats):
+        if not strip_tile_pinned(x, Cout, stats=stats, geom=geom):
+            return False                                   # slices the strip cannot fuse: gn_apply + strip GEMM
+        return not (act and strip_column_split(x.shape[0], Cin, Cout) > 2)
     return (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
             and (Cout + 127) // 128 <= 2)
 
@@ -366,13 +386,13 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     es = x.element_size()
-    if not (gn_fusable(geom, Cin, Cout, x, stats) or (tile == 131 and strip_tile_ok(x, Cout, stats=stats, geom=geom))):
+    if not (gn_fusable(geom, Cin, Cout, x, stats, act) or (tile == 131 and strip_tile_ok(x, Cout, stats=stats, geom=geom))):
         raise H.MMDError("gn_conv1x1: needs contiguous slices of >= 128 rows, Cin <= 256 (use gn_apply + conv_gemm otherwise)")
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
             w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
     if tile == 0 and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
-        tile = 131
+        tile = 131                                         # (callers that follow gn_fusable only get here when the fusion pays)
     if tile == 0:
         tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
                           lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout,
