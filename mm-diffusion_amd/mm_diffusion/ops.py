@@ -386,13 +386,19 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     es = x.element_size()
-    if not (gn_fusable(geom, Cin, Cout, x, stats, act) or (tile == 131 and strip_tile_ok(x, Cout, stats=stats, geom=geom))):
+    # capability, not preference: an explicit tile is checked against what THAT main loop can do (gn_fusable is the caller's cost rule)
+    tiled_ok = (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
+                and (Cout + 127) // 128 <= 2)
+    strip_ok = strip_tile_ok(x, Cout, stats=stats, geom=geom)
+    if not ((tile == 131 and strip_ok) or (tile in (64, 128) and tiled_ok) or (tile == 0 and (tiled_ok or strip_ok))):
         raise H.MMDError("gn_conv1x1: needs contiguous slices of >= 128 rows, Cin <= 256 (use gn_apply + conv_gemm otherwise)")
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
             w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
     if tile == 0 and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
         tile = 131                                         # (callers that follow gn_fusable only get here when the fusion pays)
+    if tile == 0 and not tiled_ok:
+        raise H.MMDError("gn_conv1x1: the row-strip kernel is switched off (MMD_GEMM_STRIP) and the tiled loader cannot take this launch")
     if tile == 0:
         tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
                           lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout,
