@@ -924,9 +924,14 @@ __device__ __forceinline__ float halfwave_sum16(const float (&u)[16], int l31) {
   return a1;
 }
 
+#ifdef STRIP_JOINT
+#define STRIP_WAVES_K128 2                   // four chains need 64 accumulator registers: two waves per SIMD
+#else
+#define STRIP_WAVES_K128 3
+#endif
 template <int KS, int RF, int CC, int GNM>   // GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
                                              // normalisation in one kernel spill ~100 registers around the branch)
-__global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
+__global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
   constexpr int K = 64 * KS;                 // input channels
   constexpr int NCG = 4 * KS;                // 16-channel k-steps (one MFMA each)
   constexpr int BR = 128 * RF;               // rows per block: 4 waves x RF fragments of 32 rows
@@ -1084,6 +1089,35 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
 #endif
     u32x4 outv[RF][2];                                  // the LAST sub-tile's stores wait until after the barrier (see above)
     float srec[2];
+#ifdef STRIP_JOINT
+    // experiment (-DSTRIP_JOINT, K = 128 only): the MFMAs of BOTH 32-channel sub-tiles of a chunk issued together = four independent
+    // accumulator chains per wave instead of two (the SQ counters show ~50 % issue stalls), the epilogues after them
+    constexpr bool JOINT = KS == 2 && NA == 2;
+    f32x16 jacc[JOINT ? NA : 1][RF];
+    if (JOINT) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) jacc[JOINT ? a : 0][f][r] = 0.f;
+#pragma unroll
+      for (int pl = 0; pl < KS; ++pl)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          u32x4 fw2[NA];
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            fw2[a] = *(const u32x4*)(sW + st * STAGE_B + (a * 32 + l31) * 128 + pl * PLANE_B + (((2 * c + half) ^ xsw) * 16));
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int f = 0; f < RF; ++f) Mma<__bf16>::run(fw2[a], xa[f][4 * pl + c], jacc[JOINT ? a : 0][f]);
+        }
+    }
+#else
+    constexpr bool JOINT = false;
+#endif
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
       const int cb = ci * CC + a * 32;                   // first column of the sub-tile inside this block's range
@@ -1100,9 +1134,15 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
       for (int f = 0; f < RF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+#ifdef STRIP_JOINT
+      if (JOINT) {
+#pragma unroll
+        for (int f = 0; f < RF; ++f) acc[f] = jacc[JOINT ? a : 0][f];
+      }
+#endif
       const char* bW = sW + st * STAGE_B + (a * 32 + l31) * 128;
 #pragma unroll
-      for (int pl = 0; pl < KS; ++pl)
+      for (int pl = 0; pl < (JOINT ? 0 : KS); ++pl)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #if defined(STRIP_ABLATE) && STRIP_ABLATE == 1      // ablation builds (tools/strip_ablate.sh): no weight fragment reads, no MFMAs

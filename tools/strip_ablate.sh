@@ -10,3 +10,8 @@ for n in 1 2 3 4; do
   echo "## STRIP_ABLATE=$n"
   MMD_LIB=mm-diffusion_amd/lib/variants/libmmd_strip_abl$n.so timeout 200 python tools/strip_probe.py
 done
+# a real candidate, not an ablation: both 32-channel sub-tiles of a chunk in flight (four MFMA chains per wave) for K = 128; results must
+# stay bitwise equal (the probe's equality column), only the K = 128 rows can move
+bash tools/build_variant.sh strip_joint mmd_gemm.hip "-DSTRIP_JOINT" > /dev/null
+echo "## STRIP_JOINT"
+MMD_LIB=mm-diffusion_amd/lib/variants/libmmd_strip_joint.so timeout 200 python tools/strip_probe.py
