@@ -81,6 +81,7 @@ __device__ __forceinline__ int64_t key_row(const GroupInfo& gi, int kk) {
 }
 
 // ============================================================================= MFMA flash attention (bf16)
+__device__ __attribute__((aligned(16))) uint32_t g_attn_zero[4] = {0, 0, 0, 0};   // (-DATTN_BRANCHFREE_KV) what a key past the window reads
 #define SVT_STRIDE 136   // bytes per V^T row (64 keys * 2 B + 8): (stride/8) odd -> conflict-free ds_read_b64
 
 // launch bound 2 waves/SIMD (<= 256 registers): keeps the S / O accumulators in the unified VGPR file - with the default
@@ -149,6 +150,23 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       const int id = tid + 256 * i;
+#ifdef ATTN_BRANCHFREE_KV
+      // experiment (-DATTN_BRANCHFREE_KV): keys past the window read a zero page instead of sitting under a branch - hipcc turns the
+      // predicated form below into s_and_saveexec / s_cbranch pairs around every load (4 per tile and thread)
+      {
+        const int j = id / DV, v = id % DV;
+        const bool ok = id < 64 * DV && kt0 + j < gi.k_count;
+        const char* src = ok ? p.KV + (key_row(gi, ok ? kt0 + j : 0) * p.ldkv + p.k_off + h * D + v * 8) * 2 : (const char*)g_attn_zero;
+        rk[i] = *(const u32x4*)src;
+      }
+      {
+        const int j = (id & 31) + 32 * ((id >> 6) & 1);
+        const int v = 2 * (id >> 7) + ((id >> 5) & 1);
+        const bool ok = id < 64 * DV && kt0 + j < gi.k_count;
+        const char* src = ok ? p.KV + (key_row(gi, ok ? kt0 + j : 0) * p.ldkv + p.v_off + h * D + v * 8) * 2 : (const char*)g_attn_zero;
+        rv[i] = *(const u32x4*)src;
+      }
+#else
       // K: row-major, DV lanes per key row (coalesced)
       {
         const int j = id / DV, v = id % DV;
@@ -166,6 +184,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
           x = *(const u32x4*)(p.KV + (key_row(gi, kt0 + j) * p.ldkv + p.v_off + h * D + v * 8) * 2);
         rv[i] = x;
       }
+#endif
     }
   };
   auto store_kv = [&]() {
@@ -249,6 +268,18 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
       for (int r = 0; r < 16; ++r) {
 #if defined(ATTN_ABLATE) && ATTN_ABLATE == 1
         const float e = s[kt][r] * sc - m_new;
+#elif defined(ATTN_PKFMA)
+        // experiment (-DATTN_PKFMA): the exp2 argument two lanes-worth at a time (v_pk_fma_f32): same fma, half the issue slots
+        float e;
+        if ((r & 1) == 0) {
+          typedef __attribute__((ext_vector_type(2))) float f32x2;
+          const f32x2 a2 = {s[kt][r], s[kt][r + 1]}, sc2 = {sc, sc}, m2 = {-m_new, -m_new};
+          const f32x2 e2 = __builtin_elementwise_fma(a2, sc2, m2);
+          s[kt][r + 1] = e2[1];
+          e = __builtin_amdgcn_exp2f(e2[0]);
+        } else {
+          e = __builtin_amdgcn_exp2f(s[kt][r]);
+        }
 #else
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
 #endif
