@@ -290,7 +290,7 @@ def strip_tile_ok(x, Cout, taps=TAPS_1, stats=None, geom=None, base=False):
     if len(taps) == 1 and tuple(taps[0]) != (0, 0, 0):
         return False
     rf = 2 if K <= 256 else 1
-    if Cout % (32 * rf) or (stats is not None and M % 64):
+    if Cout % (32 * rf) or Cout > 2048 or (stats is not None and M % 64):      # <= 2048 output channels per block (its LDS bias table)
         return False
     if base and (len(taps) != 1 or K == 512 or (stats is not None and rf != 2)):
         return False
