@@ -81,6 +81,7 @@ __device__ __forceinline__ int64_t key_row(const GroupInfo& gi, int kk) {
 }
 
 // ============================================================================= MFMA flash attention (bf16)
+__device__ __attribute__((aligned(16))) uint32_t g_attn_zero[4] = {0, 0, 0, 0};   // (-DATTN_BRANCHFREE_KV) what a key past the window reads
 #define SVT_STRIDE 136   // bytes per V^T row (64 keys * 2 B + 8): (stride/8) odd -> conflict-free ds_read_b64
 
 // launch bound 2 waves/SIMD (<= 256 registers): keeps the S / O accumulators in the unified VGPR file - with the default
@@ -130,6 +131,17 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
+#ifdef ATTN_ROWSUM_MFMA
+  // experiment (-DATTN_ROWSUM_MFMA): the softmax denominator on the matrix cores.  The kernel class is VALU-bound at head width 64
+  // (15.6 VALU instructions per MFMA, MFMA pipe 22 % busy), and the row sum is 32 adds + a cross-half shuffle
+  // + the l_run update per tile.  One more accumulator tile whose A operand is all ones gives every row = sum_k P[k][q] over BOTH
+  // half-waves' keys (4 MFMAs per tile, no LDS read); only register 0 is ever read or rescaled.  The sum then runs over the
+  // bf16-rounded P that also feeds the numerator.
+  f32x16 osum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+  const u32x4 ones_bf16 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#endif
 
   u32x4 rk[NK], rv[NK];
   const int ntiles = (gi.k_count + 63) >> 6;
@@ -138,6 +150,23 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       const int id = tid + 256 * i;
+#ifdef ATTN_BRANCHFREE_KV
+      // experiment (-DATTN_BRANCHFREE_KV): keys past the window read a zero page instead of sitting under a branch - hipcc turns the
+      // predicated form below into s_and_saveexec / s_cbranch pairs around every load (4 per tile and thread)
+      {
+        const int j = id / DV, v = id % DV;
+        const bool ok = id < 64 * DV && kt0 + j < gi.k_count;
+        const char* src = ok ? p.KV + (key_row(gi, ok ? kt0 + j : 0) * p.ldkv + p.k_off + h * D + v * 8) * 2 : (const char*)g_attn_zero;
+        rk[i] = *(const u32x4*)src;
+      }
+      {
+        const int j = (id & 31) + 32 * ((id >> 6) & 1);
+        const int v = 2 * (id >> 7) + ((id >> 5) & 1);
+        const bool ok = id < 64 * DV && kt0 + j < gi.k_count;
+        const char* src = ok ? p.KV + (key_row(gi, ok ? kt0 + j : 0) * p.ldkv + p.v_off + h * D + v * 8) * 2 : (const char*)g_attn_zero;
+        rv[i] = *(const u32x4*)src;
+      }
+#else
       // K: row-major, DV lanes per key row (coalesced)
       {
         const int j = id / DV, v = id % DV;
@@ -155,6 +184,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
           x = *(const u32x4*)(p.KV + (key_row(gi, kt0 + j) * p.ldkv + p.v_off + h * D + v * 8) * 2);
         rv[i] = x;
       }
+#endif
     }
   };
   auto store_kv = [&]() {
@@ -238,19 +268,38 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
       for (int r = 0; r < 16; ++r) {
 #if defined(ATTN_ABLATE) && ATTN_ABLATE == 1
         const float e = s[kt][r] * sc - m_new;
+#elif defined(ATTN_PKFMA)
+        // experiment (-DATTN_PKFMA): the exp2 argument two lanes-worth at a time (v_pk_fma_f32): same fma, half the issue slots
+        float e;
+        if ((r & 1) == 0) {
+          typedef __attribute__((ext_vector_type(2))) float f32x2;
+          const f32x2 a2 = {s[kt][r], s[kt][r + 1]}, sc2 = {sc, sc}, m2 = {-m_new, -m_new};
+          const f32x2 e2 = __builtin_elementwise_fma(a2, sc2, m2);
+          s[kt][r + 1] = e2[1];
+          e = __builtin_amdgcn_exp2f(e2[0]);
+        } else {
+          e = __builtin_amdgcn_exp2f(s[kt][r]);
+        }
 #else
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
 #endif
         s[kt][r] = e;
+#ifndef ATTN_ROWSUM_MFMA
         ps += e;
+#endif
       }
+#ifndef ATTN_ROWSUM_MFMA
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
+#endif
     if (__any(m_new != m_run)) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#ifdef ATTN_ROWSUM_MFMA
+      osum[0] *= alpha;
+#endif
     }
     m_run = m_new;
     // ---- O^T += V^T P^T : P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
@@ -261,6 +310,9 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * st + j];
+#ifdef ATTN_ROWSUM_MFMA
+        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones_bf16), pf, osum, 0, 0, 0);
+#endif
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const char* vb = sVt + (dt * 32 + l31) * SVT_STRIDE + (32 * kt + 16 * st + 4 * half) * 2;
@@ -279,6 +331,9 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
   for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
   // ---- normalise and store: lane owns query qi, d = 32*dt + (r&3) + 8*(r>>2) + 4*half
+#ifdef ATTN_ROWSUM_MFMA
+  l_run = osum[0];
+#endif
   if (qok) {
     const float inv = 1.f / l_run;
     if (p.lse2 && half == 0) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);   // v_log_f32 = log2

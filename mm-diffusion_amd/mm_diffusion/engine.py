@@ -206,9 +206,10 @@ class UNetEngine:
         C = x.shape[1]
         Cout = self.params[wkey].shape[0]
         will_emit = True if (out is not None and self._rec_slice(out)[0] is not None) else None    # the launch below fills out's records
-        if not ops.gn_fusable(geom, C, Cout, x, will_emit):
+        if not ops.gn_fusable(geom, C, Cout, x, will_emit, act):
             # wide outputs (qkv, deep levels) outside the row-strip kernel's shapes: every column tile would redo the normalisation
-            # in its loader (measured 2x slower than materialising once), so normalise once and run the plain GEMM
+            # in its loader (measured 2x slower than materialising once), so normalise once and run the plain GEMM; likewise a strip
+            # GEMM whose few rows force a deep column split (ops.gn_fusable)
             n1 = self._gn(x, gn_prefix, geom, act, film=film)
             y = self._pw(n1, wkey, bkey, residual=residual, out=out)
             self._release(n1)

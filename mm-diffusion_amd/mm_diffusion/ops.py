@@ -290,7 +290,7 @@ def strip_tile_ok(x, Cout, taps=TAPS_1, stats=None, geom=None, base=False):
     if len(taps) == 1 and tuple(taps[0]) != (0, 0, 0):
         return False
     rf = 2 if K <= 256 else 1
-    if Cout % (32 * rf) or (stats is not None and M % 64):
+    if Cout % (32 * rf) or Cout > 2048 or (stats is not None and M % 64):      # <= 2048 output channels per block (its LDS bias table)
         return False
     if base and (len(taps) != 1 or K == 512 or (stats is not None and rf != 2)):
         return False
@@ -346,12 +346,32 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     return out
 
 
-def gn_fusable(geom: Geom, Cin, Cout, x=None, stats=None):
+def strip_column_split(M, K, Cout):
+    """The column split conv_gemm tile 131 launches with (mmd_gemm.hip: launch_conv1x1_strip_mode): the smallest divisor of the chunk
+    count that gives the chip >= 448 blocks, at most 16."""
+    rf, cc = (2, 64) if K <= 256 else (1, 32)
+    rowblocks, nch, n = -(-M // (128 * rf)), Cout // cc, 1
+    for d in range(1, min(nch, 16) + 1):
+        if nch % d == 0:
+            n = d
+            if rowblocks * d >= 448:
+                break
+    return n
+
+
+def gn_fusable(geom: Geom, Cin, Cout, x=None, stats=None, act=False):
     """Whether GroupNorm can ride in the 1x1 GEMM: in the tiled loader (contiguous slices of >= 128 rows, narrow K and N: every
     column tile redoes the normalisation) or, given the input x (and whether the launch will emit output statistics), in the
-    row-strip kernel (normalises once per strip: any N)."""
-    if x is not None and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
-        return True
+    row-strip kernel (normalises once per strip: any N).
+
+    A layer whose GEMM runs on the strip kernel never goes back to the tiled loader (its statistics are folded in another order);
+    what may depend on M is only whether the normalisation is FUSED: every block of a strip's column split redoes it, and with SiLU
+    that is ~12 VALU instructions per element, so when few rows force a deep split (M = 4096 at 512 channels: 16 ranges, 34 us fused
+    against 5 + 17 us) gn_apply + the plain strip GEMM is the faster of two bitwise-equal paths (tests/test_strip_gpu.py)."""
+    if x is not None and strip_tile_pinned(x, Cout, stats=stats):
+        if not strip_tile_pinned(x, Cout, stats=stats, geom=geom):
+            return False                                   # slices the strip cannot fuse: gn_apply + strip GEMM
+        return not (act and strip_column_split(x.shape[0], Cin, Cout) > 2)
     return (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
             and (Cout + 127) // 128 <= 2)
 
@@ -366,13 +386,19 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
     es = x.element_size()
-    if not (gn_fusable(geom, Cin, Cout, x, stats) or (tile == 131 and strip_tile_ok(x, Cout, stats=stats, geom=geom))):
+    # capability, not preference: an explicit tile is checked against what THAT main loop can do (gn_fusable is the caller's cost rule)
+    tiled_ok = (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
+                and (Cout + 127) // 128 <= 2)
+    strip_ok = strip_tile_ok(x, Cout, stats=stats, geom=geom)
+    if not ((tile == 131 and strip_ok) or (tile in (64, 128) and tiled_ok) or (tile == 0 and (tiled_ok or strip_ok))):
         raise H.MMDError("gn_conv1x1: needs contiguous slices of >= 128 rows, Cin <= 256 (use gn_apply + conv_gemm otherwise)")
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
             w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
     if tile == 0 and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
-        tile = 131
+        tile = 131                                         # (callers that follow gn_fusable only get here when the fusion pays)
+    if tile == 0 and not tiled_ok:
+        raise H.MMDError("gn_conv1x1: the row-strip kernel is switched off (MMD_GEMM_STRIP) and the tiled loader cannot take this launch")
     if tile == 0:
         tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
                           lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout,

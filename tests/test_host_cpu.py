@@ -264,6 +264,12 @@ def test_strip_tile_is_pinned_by_layer_geometry_only(monkeypatch):
         assert not ops.strip_tile_ok(x3, 384, stats=True, base=True) and not ops.gn_fusable(ops.Geom.per_sample(n * 64, 64), 384, 384, x3, True)
         x1 = torch.zeros(n * 16 * 4096, 128, dtype=torch.bfloat16)
         assert ops.strip_tile_pinned(x1, 128, taps=ops.TAPS_TEMPORAL, stats=True) and ops.strip_tile_pinned(x1[: n * 25600], 128, taps=ops.taps_audio(16))
+    # fusing GroupNorm + SiLU into the strip is a speed choice between two bitwise-equal paths: not when few rows force a deep column split
+    big, small = torch.zeros(262144, 128, dtype=torch.bfloat16), torch.zeros(4096, 512, dtype=torch.bfloat16)
+    assert ops.gn_fusable(ops.Geom.per_sample(4, 65536), 128, 128, big, True, True) and ops.strip_column_split(262144, 128, 128) == 1
+    assert not ops.gn_fusable(ops.Geom.per_sample(4, 1024), 512, 512, small, True, True) and ops.strip_column_split(4096, 512, 512) == 16
+    assert ops.gn_fusable(ops.Geom.per_sample(4, 1024), 512, 1536, small, None, False)         # no SiLU (qkv norms): always fused
+    assert not ops.gn_fusable(ops.Geom.per_sample(4, 6400), 256, 256, torch.zeros(25600, 256, dtype=torch.bfloat16), True, True)
     x = torch.zeros(4096, 256, dtype=torch.bfloat16)
     assert not ops.strip_tile_pinned(x.float(), 256)                                           # fp32 mode keeps the exact-fp32 tiles
     assert not ops.strip_tile_pinned(x, 256, taps=ops.TAPS_TEMPORAL)                           # K = 768

@@ -125,6 +125,8 @@ def test_strip_fused_groupnorm(ops, S, Tn, Cin, Cout, act, res):
     xn = ops.gn_apply(x, ga, gb, geom, act=act)
     y_unfused = ops.conv_gemm(xn, w, b, residual=r, tile=129)
     e_unf = rel_l2(y.float().cpu(), y_unfused.float().cpu().numpy())
+    # same expressions, same rounding point: fusing is a pure speed choice (ops.gn_fusable makes it per launch size)
+    assert torch.equal(y.view(torch.int16), y_unfused.view(torch.int16))
     # (b) the tiled fused loader where it applies (same expressions in the loader)
     msg = ""
     if Cin <= 256 and Cout <= 256:

@@ -50,6 +50,14 @@ def main():
                 ref = out.clone()
             else:
                 err = float((out.float() - ref.float()).norm() / ref.float().norm())
+            # variant builds (MMD_LIB): ATTN_BENCH_SAVE=dir stores the outputs of this build, ATTN_BENCH_CMP=dir compares with them
+            if os.environ.get("ATTN_BENCH_SAVE"):
+                os.makedirs(os.environ["ATTN_BENCH_SAVE"], exist_ok=True)
+                torch.save(out.cpu(), os.path.join(os.environ["ATTN_BENCH_SAVE"], f"s{si}_i{impl}.pt"))
+            vs = ""
+            if os.environ.get("ATTN_BENCH_CMP"):
+                base = torch.load(os.path.join(os.environ["ATTN_BENCH_CMP"], f"s{si}_i{impl}.pt")).cuda().float()
+                vs = f" vs-product {float((out.float() - base).norm() / base.norm()):.1e}"
             H.call("mmd_event_record", ev[0], st)
             n = 10
             for _ in range(n):
@@ -58,7 +66,7 @@ def main():
             ms = ctypes.c_float()
             H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
             us = ms.value / n * 1000
-            line += f" | impl{impl}: {us:7.1f} us {flops/us/1e6:5.0f} TF/s ({100*flops/us/1e6/2500:4.1f}% mfma) e={err:.1e}"
+            line += f" | impl{impl}: {us:7.1f} us {flops/us/1e6:5.0f} TF/s ({100*flops/us/1e6/2500:4.1f}% mfma) e={err:.1e}{vs}"
         print(line, flush=True)
 
 
