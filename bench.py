@@ -221,7 +221,7 @@ def train_bench(args, world, rank, device):
         print(json.dumps({
             "metric": "training steps/sec (multimodal_training_losses fwd+bwd+AdamW, video+audio pairs)", "value": args.steps * B * world / elapsed,
             "unit": "pair-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "ranks_seen": args.ranks_seen,
             "config": {"workload": f"BASELINE configs[3]: base model training step, per-GPU batch {B}, dropout 0.1, flat-buffer gradient all-reduce, "
                                    f"{'eager' if gstep is None else 'graph-captured forward+backward'}",
                        "global_batch": B * world, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9},
@@ -280,7 +280,7 @@ def dpm_bench(args, world, rank, device):
         print(json.dumps({
             "metric": "denoising steps/sec (video+audio pair), DPM-Solver++ multistep-2, 50 NFE", "value": evals * B * world / elapsed,
             "unit": "pair-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * elapsed / evals,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "ranks_seen": args.ranks_seen,
             "config": {"workload": f"BASELINE configs[4] (base-model half): DPM-Solver++ 50 NFE, per-GPU batch {B}; one timed step = one full "
                                    f"{NFE}-evaluation sample() call", "global_batch": B * world, "seconds_per_sample_batch": elapsed / args.steps,
                        "finite": bool(torch.isfinite(out["video"]).all())}}))
@@ -335,13 +335,38 @@ def sr_bench(args, world, rank, device):
         print(json.dumps({
             "metric": "SR denoising steps/sec (256x256 frames), DDIM-25", "value": evals * B * Fr * world / elapsed, "unit": "frame-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * elapsed / evals, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "ranks_seen": args.ranks_seen,
             "config": {"workload": f"BASELINE configs[4] (SR half): ImageSuperResModel 64->256, {B} clip(s) x 16 frames per GPU, DDIM-25; one timed step "
                                    "= one full 25-evaluation ddim_sample_loop", "global_batch": B * world, "seconds_per_clip_batch": elapsed / args.steps,
                        "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "finite": bool(torch.isfinite(out).all())}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command line as N ranks of one node through
+    torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous on a free port; the reference's launch model is
+    `mpiexec -n N python ...`, ssh_scripts/multimodal_sample_sr.sh:16-28).  Rank 0's JSON line is this process's stdout.
+    With fewer visible GPUs than ranks the ranks share devices over gloo (RCCL refuses duplicate devices): a functional
+    smoke run of the multi-rank path, flagged in the JSON line (`backend`)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.is_available() and torch.cuda.device_count() < n:
+        env.setdefault("MMD_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
 
 
 def main():
@@ -359,15 +384,34 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="batch lanes of the sampling step (0 = the sampler's default; sampler.GraphStepper)")
     ap.add_argument("--breakdown-out", default="")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the ranks up, all-reduce a one per rank and print {n_gpus, ranks_seen, backend}: the self-launch / rendezvous "
+                         "path without any GPU work (CPU test of `python bench.py --gpus N`)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)          # plain `python bench.py --gpus N`: spawn the N ranks ourselves
     import torch.distributed as dist
     from mm_diffusion import dist_util
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         dist_util.setup_dist()
     rank = dist_util.rank()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    ranks_seen = 1
+    if world > 1:          # the collective backend really spans `world` ranks: all-reduce of ones (goes into the JSON line)
+        ones = torch.ones(1, device=dist_util.dev() if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+    args.ranks_seen, args.backend = ranks_seen, (dist.get_backend() if world > 1 else None)
+    if args.launch_check:
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": ranks_seen, "backend": args.backend}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
     device = dist_util.dev()
@@ -433,7 +477,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: Landscape base model (133.68M params), DDPM p_sample, "
                                f"timestep_respacing={args.respacing}, per-GPU batch {args.batch}, 16x3x64x64 video + 1x25600 audio",
                    "global_batch": global_batch, "batch_steps_per_s": steps_per_s, "parallelism": f"batch-sharded x{world}, no in-loop collective",
-                   "weights": "key-seeded synthetic (mm_diffusion.synth)", "graph_replay": True, "batch_lanes": stepper.lanes, "finite": finite, "terminal_all_gather_ms": gather_ms},
+                   "weights": "key-seeded synthetic (mm_diffusion.synth)", "graph_replay": True, "batch_lanes": stepper.lanes, "finite": finite, "terminal_all_gather_ms": gather_ms,
+                   "ranks_seen": args.ranks_seen, "backend": args.backend},
         "model_tflops": steps_per_s * args.batch * MODEL_FLOPS_PER_PAIR / 1e12,
     }
     if rank == 0 and not args.no_breakdown:
@@ -456,10 +501,15 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json is from build {pt.get('build_id')}, this is {build_id()}: not used"
         except Exception:
             pass
+        # which roof binds the dominant kernel: its arithmetic intensity against the ridge (MFMA peak / HBM peak = 312 flop/B in bf16)
+        ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        ai = a["flops"] / max(a["bytes"], 1)
         bound, unit = "mfma", "TFLOP/s"
-        if a["flops"] == 0:        # an elementwise kernel dominates: price it against HBM
+        if ai < ridge:             # HBM-side kernel (elementwise, or a short-K GEMM): price the algorithmic bytes against 8 TB/s
             bound, unit, ach, peak = "hbm", "GB/s", a["bytes"] / (a["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS
         res["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                           "arithmetic_intensity_flop_per_B": ai, "ridge_flop_per_B": ridge,
+                           "mfma_frac_of_peak": a["flops"] / (a["ms"] * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS),
                            "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": a["calls"], "avg_launch_ms": a["ms"] / max(a["calls"], 1),
                            "algorithmic_gflop_per_launch": a["flops"] / max(a["calls"], 1) / 1e9,
                            "algorithmic_MB_per_launch": a["bytes"] / max(a["calls"], 1) / 1e6,

@@ -112,7 +112,8 @@ int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, con
  * (ResBlock in_layers / out_layers norms, attention norms, the heads: unet:339-340,374-375; nn.py:16-33): per (64-row record,
  * column) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + column] = float2.  `stats` points at
  * the first column this launch writes (producers of a channel-concatenated tensor fill column slices of one record buffer).
- * M % 64 == 0; not with tile 130, with tile 131 only for Cin <= 256.  The order in which a record's 64 rows are folded belongs
+ * M % 64 == 0; not with tile 130; tile 131 emits them for every K it accepts (K = 128 / 256: a wave owns whole 64-row records;
+ * K = 384 / 512: two waves' half-records are paired through LDS).  The order in which a record's 64 rows are folded belongs
  * to the kernel family (tiles 128 / 129 share one, 131 has its own): a layer must be given the same family at every batch size
  * if its results are to be batch-invariant to the last bit.  mmd_gn_finalize_stats consumes the records. */
 int mmd_conv_gemm_stats(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,

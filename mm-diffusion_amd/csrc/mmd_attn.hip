@@ -1038,7 +1038,8 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
                        ((uintptr_t)Q | (uintptr_t)KV) % 16 == 0 && (uintptr_t)O % 8 == 0;
   // long windows at head width 64 (the ds-2 level): staged-window kernel, K/V staged once per 256 / 512 queries
   const int k_count = win * k_per_group;
-  const bool stage_ok = dtype == MMD_BF16 && aligned && ch == 64;
+  // the staged kernel stores O as whole 16-byte vectors (the per-128-query kernel: 8-byte pieces): stricter output alignment
+  const bool stage_ok = dtype == MMD_BF16 && aligned && ch == 64 && ldo % 8 == 0 && (uintptr_t)O % 16 == 0;
   if (impl == 3 && !stage_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 3 (staged window): needs bf16, head width 64, aligned rows");
   // auto rule from tools/attn_bench.py on MI355X (batch 4): the staged kernel wins where a group has FEW queries per staged key
   // (audio <- video at ds2: 400 queries x 1024 keys, 63 us vs 74 us) and loses a few percent where the per-128-query kernel's three

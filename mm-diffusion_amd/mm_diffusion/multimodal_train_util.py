@@ -240,6 +240,12 @@ class TrainLoop:
                 videos.append(dist_util.all_gather_samples(sample["video"].float().contiguous()).cpu())
                 audios.append(dist_util.all_gather_samples(sample["audio"].float().contiguous()).cpu())
         finally:
+            # the sampling engines (activation pools, graphs, a packed copy of the EMA weights) must not stay resident next to the
+            # training step and its graph mempool: drop them before the master weights come back
+            rel = getattr(self.model, "release_engines", None)
+            if rel is not None and th.cuda.is_available():
+                th.cuda.synchronize()
+                rel()
             if keep is not None:
                 self.opt.flat.copy_(keep)
                 self._params_changed()

@@ -306,6 +306,17 @@ class MultimodalUNet(nn.Module):
             self._engines[key] = eng
         return eng
 
+    def release_engines(self):
+        """Drop every cached launch plan (activation pools, private streams, captured graphs) and the packed-weight cache: HBM goes
+        back to the allocator.  The training loop calls this after its periodic sample dump so that nothing of the sampling engines
+        stays resident next to the training step; the next no-grad forward rebuilds what it needs."""
+        from . import _hip as H
+        for eng in list(self._engines.values()):
+            eng.close()
+        self._engines.clear()
+        self.__dict__.pop("_wcache", None)
+        H.reap()
+
     def forward(self, video, audio, timesteps, label=None):
         """video [N,F,C,H,W], audio [N,C,L], timesteps [N] -> (video_out [N,F,Cv,H,W], audio_out [N,Ca,L]).
 

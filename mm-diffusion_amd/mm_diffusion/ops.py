@@ -204,9 +204,11 @@ def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129), out=None, scratc
         return _tile_cache[key]
     import ctypes
     verify = out is not None and not any(t is not None and t.untyped_storage().data_ptr() == out.untyped_storage().data_ptr() for t in scratch)
+    saved = []
     if verify:
         for t in scratch:
             if t is not None:
+                saved.append((t, t.clone()))      # a plan recorded over a persistent buffer (sampler state, static inputs) gets it back
                 t.normal_()
     best, best_ms, ref = default, None, None
     ev = [ctypes.c_void_p(), ctypes.c_void_p()]
@@ -235,6 +237,8 @@ def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129), out=None, scratc
             best, best_ms = tile, ms.value
     for e in ev:
         H.lib().mmd_event_destroy(e)
+    for t, keep in saved:
+        t.copy_(keep)
     _tile_cache[key] = best
     return best
 

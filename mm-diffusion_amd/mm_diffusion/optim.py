@@ -161,13 +161,21 @@ class FlatAdamW:
         self._ready, self._inflight, self._seen = [], [], set()
         self._folded_buckets = set()
 
-    def _param_done(self, i):
-        """train_ops._grad_slot: the backward kernel that completes parameter i's gradient is about to be enqueued.  Buckets that
-        became complete at EARLIER calls are launched now (their kernels are on the stream by now)."""
+    def _flush_ready(self):
+        """Launch the buckets that became complete at EARLIER _grad_slot calls (their gradient kernels are on the stream by now).
+        Called ONCE per backward kernel wrapper, before any of that kernel's parameters is marked: a kernel that completes the
+        gradients of two parameters (weight + bias, gamma + beta) must not see the bucket its FIRST parameter completes launched while
+        its own launch is still to come (the bucket would be folded and reduced without this step's contribution)."""
         if not self._armed:
             return
         while self._ready:
             self._launch_bucket(self._ready.pop(0))
+
+    def _param_done(self, i):
+        """train_ops._grad_slot: the backward kernel that completes parameter i's gradient is about to be enqueued.  Only marks: a
+        bucket completed here is launched by the next _flush_ready() (the next kernel wrapper) or by all_reduce_grads()."""
+        if not self._armed:
+            return
         if i in self._seen:
             return
         self._seen.add(i)

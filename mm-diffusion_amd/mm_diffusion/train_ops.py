@@ -27,8 +27,12 @@ def _grad_slot(*params):
         g = p.grad
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not p.requires_grad:
             return None
-    for p in params:                # bucketed gradient reduction (optim.FlatAdamW.arm_overlap): this parameter's kernel comes next
-        o = getattr(p, "_mmd_opt", None)
+    # bucketed gradient reduction (optim.FlatAdamW.arm_overlap): first launch what EARLIER kernels completed, then mark this kernel's
+    # parameters - all of them before anything is launched again (one kernel writes the gradients of the whole group)
+    opts = [getattr(p, "_mmd_opt", None) for p in params]
+    for o in {id(o[0]): o[0] for o in opts if o is not None}.values():
+        o._flush_ready()
+    for o in opts:
         if o is not None:
             o[0]._param_done(o[1])
     return [p.grad for p in params]

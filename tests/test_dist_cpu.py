@@ -136,12 +136,40 @@ def _bucket_worker(rank, world, port, q):
         if overlap:
             opt.arm_overlap()
             for i in reversed(range(len(params))):                 # backward order: last parameter first
+                opt._flush_ready()                                 # what train_ops._grad_slot does per backward kernel
                 opt._param_done(i)
+            opt._flush_ready()
             launched_early = len(opt._inflight)
         else:
             launched_early = 0
         opt.all_reduce_grads()
-        res.append((torch.equal(opt.grad, expect), launched_early == (len(opt.buckets) - 1 if overlap else 0)))
+        res.append((torch.equal(opt.grad, expect), launched_early == (len(opt.buckets) if overlap else 0)))
+        assert not opt._inflight and not opt._armed
+    # the real wrapper protocol with ONE PARAMETER PER BUCKET: a backward kernel writes the gradients of a (weight, bias) pair AFTER
+    # train_ops._grad_slot(weight, bias) returned; no bucket may be reduced before the kernel that fills it is enqueued (a bucket
+    # holding only the first tensor of a pair used to be launched by the second tensor's report - its gradient was reduced without
+    # this step's contribution and leaked into the next step)
+    from mm_diffusion import train_ops
+    for step in range(2):
+        if step == 0:
+            torch.manual_seed(1)
+            params = [torch.nn.Parameter(torch.randn(*s)) for s in [(4, 4), (16,)] * 4]   # 4 (weight, bias) pairs of equal sizes: one tensor per bucket
+            opt = FlatAdamW(params, lr=1e-3, grad_buckets=len(params))
+            assert len(opt.buckets) == len(params)
+        opt.zero_grad()
+        g = torch.Generator().manual_seed(200 + 10 * step + rank)
+        grads = [torch.randn(*p.shape, generator=g) for p in params]
+        expect = torch.cat([x.reshape(-1) for x in grads])
+        dist.all_reduce(expect, op=dist.ReduceOp.SUM)
+        expect.div_(world)
+        opt.arm_overlap()
+        for j in reversed(range(0, len(params), 2)):               # backward order, one "kernel" per pair
+            slot = train_ops._grad_slot(params[j], params[j + 1])
+            assert slot is not None
+            slot[0].add_(grads[j])                                 # the kernel: accumulates into .grad after the wrapper's report
+            slot[1].add_(grads[j + 1])
+        opt.all_reduce_grads()
+        res.append((torch.equal(opt.grad, expect), True))
         assert not opt._inflight and not opt._armed
     dist.barrier()
     q.put((rank, [r[0] for r in res], [r[1] for r in res]))
@@ -162,5 +190,5 @@ def test_gloo_world2_bucketed_gradient_allreduce_equals_flat():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, oks, early in res:
-        assert oks == [True, True, True, True]
-        assert early == [True] * 4            # armed: every bucket but the last-completing one (first parameters) was in flight early
+        assert oks == [True] * 6              # 4 bucket configurations + 2 steps of the real wrapper protocol, one parameter per bucket
+        assert early == [True] * 6            # armed: every bucket was in flight before all_reduce_grads() (flush after the last report)
