@@ -91,8 +91,10 @@ int mmd_colsum_slices(int dtype, const void* dY, int64_t lddy, int S, int64_t Tn
  * VideoConv '3d' k=1, AudioConv k=3 dilated (D=(L,1,1), taps (+-d,0,0)) and k=1, and every qkv/proj 1x1 conv
  * (unet:83-131,272,275,378,401,605-610).  W is [Cout][ntaps*Cin] in `dtype`; bias fp32 (nullable);
  * R (nullable) residual in `dtype`.  taps is a HOST pointer.  tile: 0 auto, 64 or 128 (register-staged
- * main loop), 129 (128x128 tile, direct-to-LDS global_load_lds main loop), 131 (bf16 1x1 convs with Cin 128 / 256 / 384:
- * row strips stationary in registers, weights streamed through LDS); these variants are bitwise identical.  130 = halo-tile
+ * main loop), 129 (128x128 tile, direct-to-LDS global_load_lds main loop), 132 (129 with a four-slot LDS ring - three K steps of
+ * DMA in flight, one block per CU - for launches with fewer tiles than the chip has block slots; Cin a multiple of 128 bytes),
+ * 131 (bf16 convs with ntaps * Cin in {128, 256, 384, 512}: row strips stationary in registers, weights streamed through
+ * LDS); these variants are bitwise identical.  130 = halo-tile
  * main loop for spatial 3x3 convs (chunk-major K order: equal to rounding). */
 int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
@@ -122,6 +124,14 @@ int mmd_conv_gemm_stats(int dtype, const void* A, int64_t lda, const void* W, co
 int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
                          int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                          int M, int Cout, int Cin, int tile, float* stats, int64_t stats_ld, void* stream);
+
+/* Spatial 3x3 conv whose input GroupNorm32(+FiLM)(+SiLU) is applied to the staged halo tile in LDS (tile 130, bf16, the nine
+ * (0, dh, dw) taps, slices of whole frames): Y = conv3x3(act(A * gn_a[s(m)] + gn_b[s(m)])) + bias (+ R), zero padding of the
+ * NORMALISED activation.  Replaces GroupNorm32 -> SiLU -> video_conv_spatial of the ResBlock in_layers (unet:339-340,83-99,
+ * 457-458; nn.py:16-33) in one launch; bitwise equal to mmd_gn_apply followed by mmd_conv_gemm tile 130. */
+int mmd_gn_conv_gemm(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
+                     int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                     int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile, void* stream);
 
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).

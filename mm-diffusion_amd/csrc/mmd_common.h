@@ -84,7 +84,9 @@ template <> struct Elt<__bf16> {
   }
 };
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU with v_rcp_f32 (1 ulp) instead of an IEEE division: 5 VALU instructions per element where the division sequence took 14.  Every
+// kernel that applies SiLU in the forward uses this one function, so fused and unfused paths stay bitwise equal.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // 64-lane butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {

@@ -384,17 +384,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 // FAST (Cin a multiple of one K step = 128 bytes per row): every K step lies inside ONE tap, so the tap offset and
 // the channel offset are wave-uniform scalars and a DMA source is  lane-constant row pointer + uniform offset;
 // the per-step address arithmetic drops from ~250 to ~60 instructions (it was 1.5x the MFMA issue time).
-template <typename T, bool FAST>
-__global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmParams p) {
+// NS = LDS ring depth.  NS = 2 (tile 129): the next K step's DMA under this step's MFMAs, two resident blocks per CU cover each
+// other's round trips.  NS = 4 (tile 132, FAST only): launches with FEWER TILES THAN THE CHIP HAS BLOCK SLOTS (the ds8 level: M = 4096
+// -> 128 tiles) have nothing co-resident to overlap with and pay one L2 round trip per K step (3x3 512 -> 512 at ds8: 72 - 144 steps,
+// 73 - 138 us at 260 - 280 TFLOP/s); there the block keeps THREE K steps of DMA in flight over counted s_waitcnt vmcnt(16 / 8 / 0) and
+// one raw s_barrier per step (no fence: __syncthreads() would drain the queue).  Same K order, same epilogue: bitwise equal to the
+// other tiled loops, so the choice between 129 and 132 is free (ops.conv_gemm: by tile count).
+template <typename T, bool FAST, int NS>
+__global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(const ConvGemmParams p) {
   constexpr int BM = 128, BN = 128;
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
   constexpr int LDC = BN + 4;
   constexpr int TILE_B = 128 * 128;
-  constexpr int MAIN_B = (4 * TILE_B > BM * LDC * 4) ? 4 * TILE_B : BM * LDC * 4;
+  constexpr int MAIN_B = (2 * NS * TILE_B > BM * LDC * 4) ? 2 * NS * TILE_B : BM * LDC * 4;
+  static_assert(NS == 2 || (NS == 4 && FAST), "ring depths: 2 (any layer) or 4 (uniform-tap addressing only)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                       // [2][128 rows][128 B]
-  char* sW = smem + 2 * TILE_B;
+  char* sA = smem;                       // [NS][128 rows][128 B]
+  char* sW = smem + NS * TILE_B;
   float* sC = (float*)smem;
   int* s_taps = (int*)(smem + MAIN_B);
 
@@ -546,31 +553,62 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
     }
   };
 
-  issue(0);
   // epilogue operands are fetched ahead of time: the bias here, the residual rows under the last K step's MFMAs -
   // a short-K tile (4-12 steps) otherwise pays both round trips serially after its last barrier
   constexpr int CVN = BN / 8, RP = 256 / CVN, NPASS = BM / RP;
   const int e_cg = tid % CVN, e_rr = tid / CVN;
   const int e_co = n0 + e_cg * 8;
   float bs[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bs[j] = (p.bias && e_co < p.Cout) ? p.bias[e_co + j] : 0.f;
   u32x4 rres[NPASS][8 / EPV];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  GEMM_TL(1);
   int cur = 0;
-  for (int it = 0; it + 1 < nit; ++it) {
-#ifndef GEMM_ABLATE_NODMA                                   // ablation builds (tools/gemm_bench.py): compute-only / DMA-only loops
-    advance();
-    issue(cur ^ 1);                                      // DMA of the next K step runs under this step's MFMAs
-#endif
-#ifndef GEMM_ABLATE_NOMMA
-    compute(cur);
-#endif
+  if constexpr (NS == 2) {
+    issue(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = (p.bias && e_co < p.Cout) ? p.bias[e_co + j] : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    GEMM_TL(1);
+    for (int it = 0; it + 1 < nit; ++it) {
+#ifndef GEMM_ABLATE_NODMA                                   // ablation builds (tools/gemm_bench.py): compute-only / DMA-only loops
+      advance();
+      issue(cur ^ 1);                                      // DMA of the next K step runs under this step's MFMAs
+#endif
+#ifndef GEMM_ABLATE_NOMMA
+      compute(cur);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // ---- deep ring: K steps it+1 .. it+NS-2 stay in flight while step `it` is consumed.  A wave issues 8 DMA instructions per step,
+    // in step order, and the vector-memory counter retires in order, so "at most 8 k outstanding" = "everything up to step
+    // (last issued - k) has landed" (the two bias loads in front of the first step only make the first waits stricter).
+    constexpr int D = NS - 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = (p.bias && e_co < p.Cout) ? p.bias[e_co + j] : 0.f;
+    for (int s0 = 0; s0 < D && s0 < nit; ++s0) {
+      issue(s0);
+      advance();
+    }
+    GEMM_TL(1);
+    for (int it = 0; it + 1 < nit; ++it) {
+      const int ahead = nit - 1 - it < D - 1 ? nit - 1 - it : D - 1;       // younger steps that may stay in flight (uniform)
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // step `it` landed for every wave; every wave is past its fragment reads of step it - 1
+      asm volatile("" ::: "memory");
+      if (it + D < nit) {                    // refill the slot step it - 1 just left
+        issue((it + D) % NS);
+        advance();
+      }
+      compute(it % NS);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    cur = (nit - 1) % NS;
   }
   if (p.R) {
 #pragma unroll
@@ -663,7 +701,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmPa
 // agree to fp32 rounding, not bitwise).  Halo row r = (ph+1+dh)*18 + (pw+1+dw); the 16-byte chunk swizzle is keyed on r,
 // and 16 consecutive pixels of a patch row are 16 consecutive halo rows, so the fragment reads stay conflict free.
 // Requires: taps with d0 offset 0 and |dh|,|dw| <= 1, D1 % 8 == 0, D2 % 16 == 0, M = D0*D1*D2, Cin % (128 B) == 0.
-template <typename T>
+// GN = true (3x3 convs, 9 taps): GroupNorm(+FiLM)(+SiLU) of the INPUT is applied to the staged halo in LDS, once per channel chunk -
+// the normalised tensor never exists in HBM (the gn_apply pass in front of every ResBlock in-conv: unet:339-340,457-458).  The
+// affine rows of a chunk (64 channels of a | b of the block's sample) arrive by DMA in a 1 KB LDS ring one chunk ahead; the halo of
+// chunk c + 1 is complete after step 5 of chunk c (six DMA pieces per wave, one per step), and steps 6, 7, 8 transform it in place:
+// thread (tid, i) owns the 16 bytes at tid * 16 + i * 4096 of the stage - pixel row tid / 8 + 32 i, physical chunk tid % 8, whose
+// LOGICAL chunk (tid % 8) ^ ((tid / 16) % 8) does not depend on i, so a thread needs 8 channels of a | b per chunk.  Padding pixels
+// (the zero page) stay zero: the conv pads the normalised activation.  Same expressions as gn_apply: the result is bitwise equal to
+// gn_apply followed by the plain halo kernel.
+template <typename T, bool GN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmParams p) {
   constexpr int BM = 128, BN = 128, PH = 8, PW = 16, HWD = PW + 2, HR = (PH + 2) * HWD, HG = (HR + 7) / 8, HJ = (HG + 3) / 4;
   constexpr int EPV = Elt<T>::EPV;
@@ -677,6 +723,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   char* sW = smem + 2 * A_B;                   // [2][128 rows][128 B]
   float* sC = (float*)smem;
   int* s_taps = (int*)(smem + MAIN_B);
+  float* sGN = (float*)(smem + MAIN_B + 336);  // GN: [2 chunk parities][a (64 channels) | b (64 channels)]
 
   GEMM_TL(0);
   const int tid = threadIdx.x;
@@ -746,6 +793,51 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * A_B + (wave + 4 * j) * 1024), 16, 0, 0);
     }
   };
+  // ---- fused input GroupNorm (GN): affine ring DMA, in-place transform of a landed halo stage
+  constexpr int NSLOT = (HG * 64 + 255) / 256;                 // 16-byte slots of a stage per thread (the last one is partial)
+  unsigned gvalid = 0;                                         // bit i: slot i is a pixel inside the frame (else padding: stays zero)
+  const float* gn_src = nullptr;                               // waves 0 / 1: this lane's float of the sample's a / b row
+  const int glc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;          // first channel (inside a chunk) of this thread's 16 bytes
+  if (GN) {
+    const int sidx = min((int)(mframe / p.gn_rows), p.gn_S - 1);
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+      const int hr = r / HWD, hc = r - hr * HWD;
+      const bool ok = r < HR && (unsigned)(h0 - 1 + hr) < (unsigned)p.D1 && (unsigned)(w0 - 1 + hc) < (unsigned)p.D2;
+      gvalid |= (ok ? 1u : 0u) << i;
+    }
+    gn_src = (wave == 0 ? p.gn_a : p.gn_b) + (int64_t)sidx * p.Cin + lane;
+  }
+  auto issue_gn = [&](int c) {                                 // 64 floats of a (wave 0) and of b (wave 1) -> ring slot c & 1
+    if (wave < 2)                                              // wave-uniform
+      __builtin_amdgcn_global_load_lds((gptr_t)(gn_src + c * 64), (lptr_t)(sGN + (c & 1) * 128 + wave * 64), 4, 0, 0);
+  };
+  static_assert(!GN || EPV == 8, "fused input GroupNorm: bf16 stages only (64 channels per 128-byte chunk)");
+  auto transform = [&](int buf, int c, int part) {             // part 0..2: a third of the slots; part < 0: all of them
+    constexpr int PER = (NSLOT + 2) / 3;
+    const float* ap = sGN + (c & 1) * 128 + glc;
+    const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4), b0 = *(const f32x4*)(ap + 64), b1 = *(const f32x4*)(ap + 68);
+    const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      if (part >= 0 && i / PER != part) continue;              // (block-uniform)
+      if (i * 256 + 256 <= HG * 64 || tid < HG * 64 - i * 256) {     // the partial last slot: wave-uniform (HG * 64 % 64 == 0)
+        char* q = sA + buf * A_B + tid * 16 + i * 4096;
+        const u32x4 v = *(const u32x4*)q;
+        float f[EPV];
+        Elt<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const float w = f[e] * av[e] + bv[e];
+          f[e] = p.gn_act ? silu_f(w) : w;
+        }
+        const u32x4 y = Elt<T>::pack(f);
+        *(u32x4*)q = ((gvalid >> i) & 1u) ? y : v;
+      }
+    }
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -792,6 +884,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
 #pragma unroll
   for (int j = 0; j < HJ; ++j) issue_h(0, 0, j);
   issue_w(0, 0, 0);
+  if (GN) issue_gn(0);
   constexpr int CVN = BN / 8, RP = 256 / CVN, NPASS = BM / RP;
   const int e_cg = tid % CVN, e_rr = tid / CVN;
   const int e_co = n0 + e_cg * 8;
@@ -801,6 +894,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   u32x4 rres[NPASS][8 / EPV];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (GN) {                                                  // chunk 0: the whole stage is normalised before the first MFMA
+    transform(0, 0, -1);
+    __syncthreads();
+  }
   GEMM_TL(1);
   int c = 0, t = 0;
   for (int it = 0; it + 1 < nit; ++it) {
@@ -811,8 +908,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
 #pragma unroll
       for (int j = 0; j < HJ; ++j)
         if (j % p.ntaps == t) issue_h((c + 1) & 1, c + 1, j);
+      if (GN && t == 0) issue_gn(c + 1);                     // (its ring slot was last read in steps 6-8 of chunk c - 1)
     }
     compute(it & 1, c & 1, t);
+    if (GN && c + 1 < nchunk && t >= HJ && t < HJ + 3)       // the next chunk's halo landed with the barrier of step HJ - 1:
+      transform((c + 1) & 1, c + 1, t - HJ);                 // a third of its slots in each of the three remaining steps (9 taps)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     t = tn;
@@ -1286,7 +1386,7 @@ static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
   return launch_conv1x1_strip<8, 1, 32>(p, st);
 }
 
-template <typename T>
+template <typename T, bool GN>
 static int launch_conv_gemm_halo(const ConvGemmParams& p, hipStream_t st) {
   bool taps_ok = p.ntaps <= 9;
   for (int t = 0; t < p.ntaps && taps_ok; ++t)
@@ -1294,16 +1394,18 @@ static int launch_conv_gemm_halo(const ConvGemmParams& p, hipStream_t st) {
   if (!taps_ok || p.D1 % 8 != 0 || p.D2 % 16 != 0 || (int64_t)p.D0 * p.D1 * p.D2 != p.M || p.Cin % (8 * Elt<T>::EPV) != 0)
     return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 130 (halo): needs spatial taps (|dh|,|dw| <= 1), D1 %% 8 == 0, D2 %% 16 == 0, "
                          "full frames and Cin a multiple of one 128-byte K step");
-  const size_t lds = 2 * (size_t)(23 * 8 * 128) + 2 * (size_t)(128 * 128) + 336;
+  if (GN && (p.ntaps != 9 || p.gn_rows % ((int64_t)p.D1 * p.D2) != 0))
+    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 130 with fused GroupNorm: needs the nine spatial taps and slices of whole frames");
+  const size_t lds = 2 * (size_t)(23 * 8 * 128) + 2 * (size_t)(128 * 128) + 336 + (GN ? 1024 : 0);     // (two blocks per CU: <= 81920 B)
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_halo_kernel<T, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_halo: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = (p.M / 128) * cdiv(p.Cout, 128);
-  hipLaunchKernelGGL((conv_gemm_halo_kernel<T>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_gemm_halo_kernel<T, GN>), dim3(grid), dim3(256), lds, st, p);
   return mmd_check_launch("conv_gemm_halo");
 }
 
@@ -1313,15 +1415,33 @@ static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_glds: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  if (p.Cin % (8 * Elt<T>::EPV) == 0) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true>), dim3(grid), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, false>), dim3(grid), dim3(256), lds, st, p);
+  if (p.Cin % (8 * Elt<T>::EPV) == 0) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 2>), dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, false, 2>), dim3(grid), dim3(256), lds, st, p);
   return mmd_check_launch("conv_gemm_glds");
+}
+
+// tile 132: the direct-to-LDS loop with a four-slot ring (three K steps of DMA in flight), one block per CU
+template <typename T>
+static int launch_conv_gemm_ring(const ConvGemmParams& p, hipStream_t st) {
+  if (p.Cin % (8 * Elt<T>::EPV) != 0)
+    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 132 (deep ring): Cin must be a multiple of one 128-byte K step");
+  const size_t lds = 8 * (size_t)(128 * 128) + 336;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_ring: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128);
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 4>), dim3(grid), dim3(256), lds, st, p);
+  return mmd_check_launch("conv_gemm_ring");
 }
 
 template <typename T, int BM, int BN, bool GN>
@@ -1345,11 +1465,16 @@ static int launch_conv_gemm(const ConvGemmParams& p, hipStream_t st) {
 template <typename T>
 static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st) {
   if (p.gn_a) {
+    if (tile == 130) {
+      if constexpr (Elt<T>::EPV == 8) return launch_conv_gemm_halo<T, true>(p, st);
+      else return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 130 with fused GroupNorm: bf16 only");
+    }
     if (tile == 128) return launch_conv_gemm<T, 128, 128, true>(p, st);
     return launch_conv_gemm<T, 64, 64, true>(p, st);
   }
   if (tile == 129) return launch_conv_gemm_glds<T>(p, st);
-  if (tile == 130) return launch_conv_gemm_halo<T>(p, st);
+  if (tile == 132) return launch_conv_gemm_ring<T>(p, st);
+  if (tile == 130) return launch_conv_gemm_halo<T, false>(p, st);
   if (tile == 128) return launch_conv_gemm<T, 128, 128, false>(p, st);
   return launch_conv_gemm<T, 64, 64, false>(p, st);
 }
@@ -1367,9 +1492,10 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   MMD_REQUIRE(lda % epv == 0 && ldy % epv == 0 && (!R || ldr % epv == 0), "conv_gemm: row strides must be 16-byte multiples");
   MMD_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)R) % 16 == 0, "conv_gemm: pointers must be 16-byte aligned");
   MMD_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "conv_gemm: bad position dims");
-  MMD_REQUIRE(!gn_a || (gn_b && ntaps == 1 && gn_S > 0 && gn_rows >= 128 && (Cin <= 256 || tile == 131) && (int64_t)gn_S * gn_rows == M),
-              "gn_conv1x1: needs contiguous slices of >= 128 rows covering M and Cin <= 256 (got S=%d rows=%ld Cin=%d M=%d)",
-              gn_S, (long)gn_rows, Cin, M);
+  MMD_REQUIRE(!gn_a || (gn_b && (ntaps == 1 || tile == 130) && gn_S > 0 && gn_rows >= 128 && (Cin <= 256 || tile == 131 || tile == 130) &&
+                        (int64_t)gn_S * gn_rows == M),
+              "gn_conv1x1 / gn_conv_gemm: needs contiguous slices of >= 128 rows covering M, Cin <= 256 unless tile 130 / 131, taps only with tile 130 "
+              "(got S=%d rows=%ld Cin=%d M=%d ntaps=%d tile=%d)", gn_S, (long)gn_rows, Cin, M, ntaps, tile);
   ConvGemmParams p;
   p.A = (const char*)A; p.lda = lda; p.W = (const char*)W; p.bias = bias;
   p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
@@ -1381,8 +1507,10 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
-  MMD_REQUIRE(tile == 64 || tile == 128 || ((tile == 129 || tile == 130) && !gn_a) || (tile == 131 && dtype == MMD_BF16),
-              "conv_gemm: tile must be 0, 64, 128, 129 (128 direct-to-LDS), 130 (halo-tile 3x3) or 131 (row strip, bf16 1x1 convs)");
+  MMD_REQUIRE(tile == 64 || tile == 128 || ((tile == 129 || tile == 132) && !gn_a) || (tile == 130 && (!gn_a || dtype == MMD_BF16)) ||
+                  (tile == 131 && dtype == MMD_BF16),
+              "conv_gemm: tile must be 0, 64, 128, 129 (128 direct-to-LDS), 130 (halo-tile 3x3), 131 (row strip, bf16 1x1 convs) or 132 (129 with a "
+              "four-slot ring for launches of few tiles)");
   if (tile == 131) return dispatch_conv1x1_strip(p, st);
   return dtype == MMD_BF16 ? dispatch_conv_gemm<__bf16>(p, tile, st) : dispatch_conv_gemm<float>(p, tile, st);
 }
@@ -1425,4 +1553,16 @@ extern "C" int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const
   MMD_REQUIRE(gn_a && gn_b && stats, "gn_conv1x1_stats: null GroupNorm affine / statistics buffer");
   return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, S,
                         rows_per_slice, stats, stats_ld, stream);
+}
+
+// Spatial 3x3 conv of GroupNorm32(+FiLM)(+SiLU)'d rows on the halo tile (tile 130, bf16): the normalisation is applied to the staged
+// halo in LDS, so the normalised tensor never exists in HBM (mmd_gn_apply + mmd_conv_gemm in one launch; bitwise equal to the pair).
+extern "C" int mmd_gn_conv_gemm(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
+                                int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y,
+                                int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
+                                void* stream) {
+  MMD_REQUIRE(gn_a && gn_b, "gn_conv_gemm: null GroupNorm affine");
+  MMD_REQUIRE(tile == 130, "gn_conv_gemm: the fused input GroupNorm of a conv with taps exists on tile 130 (halo) only");
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, gn_a, gn_b, act, S,
+                        rows_per_slice, nullptr, 0, stream);
 }

@@ -41,6 +41,7 @@ _PROTOS = {
     "mmd_gn_conv1x1": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "mmd_conv_gemm_stats": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp, i64, vp]),
     "mmd_gn_conv1x1_stats": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
+    "mmd_gn_conv_gemm": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_gn_finalize_stats": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp, vp, vp]),
     "mmd_attn_fwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, i64, i32, i64, i32, i32, vp, i32, vp]),
     "mmd_attn_small_fwd": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i64, i64, vp]),

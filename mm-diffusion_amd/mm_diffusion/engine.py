@@ -265,15 +265,26 @@ class UNetEngine:
 
         def stream(x, mod, rows_in, rows_out, out):
             vid = mod == "video"
-            t0 = self._gn(x, f"{p}.{mod}_in_layers.0", Geom.per_sample(N, rows_in // N), act=True)
+            gin = Geom.per_sample(N, rows_in // N)
             # h feeds the out_layers GroupNorm directly unless it is resampled first (up / down blocks) or shifted by the embedding
             # (non-FiLM blocks): then its producer's epilogue statistics would describe a different tensor
             hstats = fh == 1 and ss
+            if vid and ops.halo_gn_ok(x, ops.TAPS_SPATIAL, (N * F, Hh, Hh), gin):
+                # in_layers norm + SiLU inside the 3x3 conv's halo stage: no normalised tensor in HBM (ds1 / ds2 levels)
+                ga, gb = self._gn_affine(x, f"{p}.{mod}_in_layers.0", gin, None)
+                t1 = ops.gn_conv_gemm(x, ga, gb, gin, True, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
+                                      self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), ops.TAPS_SPATIAL, (N * F, Hh, Hh),
+                                      out=self._alloc(rows_in, cout))
+                self._release(ga, gb)
+                t0 = None
+            else:
+                t0 = self._gn(x, f"{p}.{mod}_in_layers.0", gin, act=True)
             if vid:
-                t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
-                                   self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,
-                                   dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
-                self._release(t0)
+                if t0 is not None:
+                    t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
+                                       self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,
+                                       dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
+                    self._release(t0)
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
                 ops.conv_gemm(t1, self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight"),
                               self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), **self._temporal(Hh),

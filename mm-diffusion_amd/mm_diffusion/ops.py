@@ -311,7 +311,20 @@ def strip_tile_pinned(x, Cout, taps=TAPS_1, stats=None, geom=None):
 
 
 def _tile_name(tile):
-    return {129: "128glds", 130: "128halo", 131: "strip"}.get(tile, tile)
+    return {129: "128glds", 130: "128halo", 131: "strip", 132: "128ring"}.get(tile, tile)
+
+
+# tile 132 (mmd_gemm.hip: the direct-to-LDS loop with a four-slot LDS ring, three K steps of DMA in flight, one block per CU) is
+# bitwise equal to tiles 64 / 128 / 129 (statistics included: the 128-row epilogue), so it simply joins the autotune candidates -
+# where it can win: launches with at most ~1.5 tiles per CU (nothing co-resident hides a block's L2 round trips) and >= 4 K steps.
+_RING_MODE = os.environ.get("MMD_GEMM_RING", "1")
+
+
+def ring_tile_candidate(x, Cout, ntaps):
+    M, Cin = x.shape
+    kstep = 128 // x.element_size()
+    return (_RING_MODE != "0" and Cin % kstep == 0 and (Cin * ntaps) // kstep >= 4
+            and ((M + 127) // 128) * ((Cout + 127) // 128) <= 384)
 
 
 def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None):
@@ -338,6 +351,8 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
         # the tile's thread layout (128 / 129 share it, 64 does not), and the choice must not move the last bit of the statistics
         # when the batch size changes the autotuner's verdict
         cands = (128, 129) if stats is not None else (64, 128, 129) + ((130,) if HALO_CANDIDATE and halo_tile_ok(x, taps, dims) else ())
+        if ring_tile_candidate(x, Cout, nt):
+            cands = cands + (132,)
         tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False, tuple(dims) if 130 in cands else None),
                           lambda t: H.call("mmd_conv_gemm", *base, t, H.stream_handle()), M, Cout, cands, out=out, scratch=(x, residual))
     flops = 2 * M * Cout * Cin * nt
@@ -413,6 +428,42 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
         _dispatch("mmd_gn_conv1x1_stats", *base, tile, *_stats_args(stats, M, Cout), meta=meta)
     else:
         _dispatch("mmd_gn_conv1x1", *base, tile, meta=meta)
+    return out
+
+
+# GroupNorm(+FiLM)(+SiLU) of the INPUT of a 3x3 conv applied to the staged halo tile in LDS (mmd_gn_conv_gemm): the gn_apply pass in
+# front of the ResBlock in-convs disappears wherever the conv runs on tile 130.  Bitwise equal to gn_apply + conv_gemm(tile 130), so
+# the switch (MMD_HALO_GN=0: separate pass) is a pure speed choice.
+_HALO_GN = os.environ.get("MMD_HALO_GN", "1") != "0"
+
+
+def halo_gn_ok(x, taps, dims, geom: Geom):
+    """Launches mmd_gn_conv_gemm accepts: what tile 130 is pinned on (bf16 3x3 convs on frames of >= 1024 pixels) with per-sample
+    slices of whole frames."""
+    return (_HALO_GN and halo_tile_pinned(x, taps, dims) and geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn
+            and geom.S * geom.Tn == x.shape[0] and geom.Tn % (dims[1] * dims[2]) == 0)
+
+
+def gn_conv_gemm(x, a, b, geom: Geom, act, w, bias, taps, dims, residual=None, out=None):
+    """3x3 conv of GroupNorm'd rows with the normalisation applied to the staged halo (include/mmd.h: mmd_gn_conv_gemm, tile 130)."""
+    _chk2d(x)
+    M, Cin = x.shape
+    Cout = w.shape[0]
+    if w.dtype != x.dtype or w.shape[1] != len(taps) * Cin or not w.is_contiguous():
+        raise H.MMDError(f"gn_conv_gemm: weight {tuple(w.shape)} {w.dtype} does not match input {tuple(x.shape)} {x.dtype} x {len(taps)} taps")
+    if not (halo_tile_ok(x, taps, dims) and len(taps) == 9 and x.dtype == torch.bfloat16 and geom.S * geom.Tn == M
+            and geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn % (dims[1] * dims[2]) == 0):
+        raise H.MMDError("gn_conv_gemm: needs a bf16 3x3 conv tile 130 accepts and contiguous slices of whole frames")
+    out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    arr, nt = H.taps_array(taps)
+    es = x.element_size()
+    flops = 2 * M * Cout * Cin * nt
+    nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
+    _dispatch("mmd_gn_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
+              w.data_ptr(), H.ptr(bias), H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
+              M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), 130,
+              meta=(f"gn_conv_gemm<bf16,128halo>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
     return out
 
 

@@ -1,0 +1,127 @@
+"""Round-3 kernels through the C ABI.
+
+* mmd_gn_conv_gemm: GroupNorm(+FiLM)(+SiLU) of a 3x3 conv's input applied to the staged halo in LDS (tile 130).  Pinned two ways:
+  bitwise against the two launches it replaces (mmd_gn_apply + mmd_conv_gemm tile 130: same expressions, same rounding points - both
+  are themselves checked against the oracle's GroupNorm / conv primitives in test_ops_gpu.py), and against the fp32 torch
+  restatement of norm -> SiLU -> conv3d on the same bf16-rounded inputs (rel-L2 <= 1e-2, the bf16 bound of test_ops_gpu.py).
+"""
+import pytest
+import torch
+import torch.nn.functional as F_
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from mm_diffusion import ops as o
+    return o
+
+
+@pytest.mark.parametrize("act", [True, False])
+@pytest.mark.parametrize("N,F,H,W,Cin,Cout,cat", [(2, 3, 32, 32, 64, 128, 0), (1, 2, 16, 64, 128, 96, 0), (2, 2, 32, 32, 192, 264, 64),
+                                                 (1, 2, 64, 64, 384, 128, 0)])
+def test_halo_fused_groupnorm(ops, act, N, F, H, W, Cin, Cout, cat):
+    """Several channel chunks (the affine ring and the in-loop transform of chunk c + 1 under the MFMAs of chunk c), patches on every
+    border (padding pixels must stay zero AFTER the normalisation), a ragged Cout, the input as a column slice of a wider buffer."""
+    M = N * F * H * W
+    g = torch.Generator(device="cuda").manual_seed(M + Cin)
+    xb = (torch.randn(M, Cin + cat, device="cuda", generator=g) * 1.5 + 0.3).to(BF)
+    x = xb[:, cat:]
+    w = (torch.randn(Cout, Cin * 9, device="cuda", generator=g) * (Cin * 9) ** -0.5).to(BF)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    gamma = 1 + 0.2 * torch.randn(Cin, device="cuda", generator=g)
+    beta = 0.2 * torch.randn(Cin, device="cuda", generator=g)
+    geom = ops.Geom.per_sample(N, F * H * W)
+    ga, gb = ops.gn_stats(x, gamma, beta, geom)
+    dims = (N * F, H, W)
+    assert ops.halo_tile_ok(x, ops.TAPS_SPATIAL, dims)
+    y = ops.gn_conv_gemm(x, ga, gb, geom, act, w, b, ops.TAPS_SPATIAL, dims)
+    xn = ops.gn_apply(x, ga, gb, geom, act=act)
+    y2 = ops.conv_gemm(xn, w, b, taps=ops.TAPS_SPATIAL, dims=dims, tile=130)
+    torch.cuda.synchronize()
+    e_pair = rel_l2(y.float().cpu(), y2.float().cpu().numpy())
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), f"fused halo GroupNorm differs from gn_apply + tile 130: rel-L2 {e_pair:.3e}"
+    # fp32 restatement on the same rounded inputs
+    xf = x.float().cpu().reshape(N, F, H, W, Cin).permute(0, 4, 1, 2, 3)                       # [N, C, F, H, W]
+    ref = F_.group_norm(xf, 32, gamma.cpu(), beta.cpu(), eps=1e-5)
+    ref = F_.silu(ref) if act else ref
+    wt = w.float().cpu().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)                          # packed K = tap * Cin + ci
+    ref = F_.conv3d(ref, wt[:, :, None], b.cpu(), padding=(0, 1, 1))
+    got = y.float().cpu().reshape(N, F, H, W, Cout).permute(0, 4, 1, 2, 3)
+    assert rel_l2(got, ref) < 1e-2
+
+
+def test_engine_uses_the_fused_halo_norm_and_matches_the_unfused_plan(monkeypatch):
+    """The launch plan of the mid-size model with and without MMD_HALO_GN: same outputs bitwise (the fusion is a pure speed choice)
+    and the fused plan really carries gn_conv_gemm launches."""
+    import importlib
+    from helpers import flags, inputs
+    from mm_diffusion import multimodal_script_util as msu, ops as o
+    from mm_diffusion.synth import synth_init_
+    fl = flags("mid", use_fp16=True)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(o, "_HALO_GN", on)
+        model, _ = msu.create_model_and_diffusion(**fl)
+        synth_init_(model)
+        model.cuda().eval()
+        v, a = inputs(fl, 2, 3)
+        import random
+        random.seed(5)
+        with torch.no_grad():
+            ov, oa = model(v.cuda(), a.cuda(), torch.tensor([17, 400]).cuda())
+        eng = next(iter(model._engines.values()))
+        names = [e[2] for e in eng.plan]
+        outs.append((ov.clone(), oa.clone(), names.count("mmd_gn_conv_gemm"), names.count("mmd_gn_apply")))
+        model.release_engines()
+    assert outs[0][2] > 0 and outs[1][2] == 0 and outs[0][3] < outs[1][3]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("M,Cin,Cout,taps", [(4096, 512, 512, "3x3"), (128 * 9 + 37, 64, 136, "1"), (1600, 128, 256, "a2"), (700, 256, 64, "1"),
+                                            (2 * 6 * 16 * 16, 192, 384, "3x3"), (300, 64, 64, "a400")])
+def test_deep_ring_tile_is_bitwise_the_tiled_loop(ops, dt, res, M, Cin, Cout, taps):
+    """conv_gemm tile 132 (four-slot LDS ring, counted vmcnt waits, one raw barrier per K step) against the register-staged 128 tile:
+    same K order and epilogue, so bitwise equal - with 1, 2, 3 (fewer than the ring depth) and many K steps, ragged M / Cout edges,
+    padding taps (3x3 borders, a dilation beyond the sequence), a residual, fp32 (32-channel K steps) and bf16."""
+    if taps == "3x3":
+        side = 8 if M == 4096 else 16
+        tp, dims = ops.TAPS_SPATIAL, (M // (side * side), side, side)
+    elif taps == "1":
+        tp, dims = ops.TAPS_1, (1, 1, 1)
+    else:
+        tp, dims = ops.taps_audio(int(taps[1:])), (M // 2 if taps == "a2" else M, 1, 1)
+    g = torch.Generator(device="cuda").manual_seed(M + Cin)
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(dt)
+    w = (torch.randn(Cout, Cin * len(tp), device="cuda", generator=g) * (Cin * len(tp)) ** -0.5).to(dt)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(M, Cout, device="cuda", generator=g).to(dt) if res else None
+    y0 = ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=128)
+    for _ in range(3):
+        y1 = ops.conv_gemm(x, w, b, taps=tp, dims=dims, residual=r, tile=132)
+        assert torch.equal(y0, y1), f"rel-L2 {rel_l2(y1.float().cpu(), y0.float().cpu().numpy()):.3e}"
+
+
+def test_deep_ring_tile_statistics(ops):
+    """The ring tile shares the 128-row epilogue: output statistics records bitwise equal to tile 129's."""
+    M, Cin, Cout = 4096, 512, 512
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(BF)
+    w = (torch.randn(Cout, Cin * 3, device="cuda", generator=g) * (Cin * 3) ** -0.5).to(BF)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    recs = []
+    for tile in (129, 132):
+        rec = torch.zeros(M // 64, Cout, 2, device="cuda")
+        y = ops.conv_gemm(x, w, b, taps=ops.TAPS_TEMPORAL, dims=(16, 64, 1), tile=tile, stats=rec)
+        recs.append((y.clone(), rec))
+    assert torch.equal(recs[0][0], recs[1][0]) and torch.equal(recs[0][1], recs[1][1])
+    ysum = recs[0][0].float().reshape(M // 64, 64, Cout).sum(1)
+    assert rel_l2(recs[1][1][:, :, 0].cpu(), ysum.cpu().numpy()) < 1e-5
