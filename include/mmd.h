@@ -95,7 +95,8 @@ int mmd_colsum_slices(int dtype, const void* dY, int64_t lddy, int S, int64_t Tn
  * DMA in flight, one block per CU - for launches with fewer tiles than the chip has block slots; Cin a multiple of 128 bytes),
  * 131 (bf16 convs with ntaps * Cin in {128, 256, 384, 512}: row strips stationary in registers, weights streamed through
  * LDS); these variants are bitwise identical.  130 = halo-tile
- * main loop for spatial 3x3 convs (chunk-major K order: equal to rounding). */
+ * main loop for spatial 3x3 convs (chunk-major K order: equal to rounding); 133 = the same on 16 x 16 pixel patches (bf16, 8 waves,
+ * one block per CU, three-slot weight ring; D1 % 16 == 0, D2 % 16 == 0), bitwise equal to 130. */
 int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
                   void* stream);
@@ -128,7 +129,7 @@ int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const float* gn_
 /* Spatial 3x3 conv whose input GroupNorm32(+FiLM)(+SiLU) is applied to the staged halo tile in LDS (tile 130, bf16, the nine
  * (0, dh, dw) taps, slices of whole frames): Y = conv3x3(act(A * gn_a[s(m)] + gn_b[s(m)])) + bias (+ R), zero padding of the
  * NORMALISED activation.  Replaces GroupNorm32 -> SiLU -> video_conv_spatial of the ResBlock in_layers (unet:339-340,83-99,
- * 457-458; nn.py:16-33) in one launch; bitwise equal to mmd_gn_apply followed by mmd_conv_gemm tile 130. */
+ * 457-458; nn.py:16-33) in one launch; bitwise equal to mmd_gn_apply followed by mmd_conv_gemm tile 130.  tile = 130 or 133. */
 int mmd_gn_conv_gemm(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
                      int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                      int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile, void* stream);

@@ -83,6 +83,18 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
 
 #define ROWB 144   // LDS bytes per staged operand row
 
+// Fragment reads of a K step: hipcc places each ds_read_b128 right in front of the MFMA that consumes it and waits lgkmcnt(0) - eight
+// exposed LDS round trips per K step (GEMM_FRAG_HOIST=0 keeps that order for A/B builds).  With the 16 reads of a step issued first
+// and pinned there, every MFMA waits with a counted lgkmcnt and the LDS latency of read n + 1 hides under MFMA n.
+#ifndef GEMM_FRAG_HOIST
+#define GEMM_FRAG_HOIST 1
+#endif
+#if GEMM_FRAG_HOIST
+#define FRAG_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FRAG_FENCE() do { } while (0)
+#endif
+
 // Padding taps / out-of-range rows read this zero page instead of branching around the load: every thread then issues a
 // STATIC number of global loads per K step, so the compiler can keep the newer register stage in flight with a counted
 // s_waitcnt vmcnt(N) (a load under a divergent branch forces vmcnt(0) and serialises the pipeline).
@@ -538,19 +550,28 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
   auto compute = [&](int buf) {
     const char* bW = sW + buf * TILE_B + (wc * 64 + l31) * 128;
     const char* bA = sA + buf * TILE_B + (wr * 64 + l31) * 128;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    u32x4 fw[4][2], fa[4][2];
+    auto rd = [&](int c) {
       const int phys = ((2 * c + half) ^ xsw) * 16;
-      u32x4 fw[2], fa[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fw[a] = *(const u32x4*)(bW + a * 32 * 128 + phys);
+      for (int a = 0; a < 2; ++a) fw[c][a] = *(const u32x4*)(bW + a * 32 * 128 + phys);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) fa[b] = *(const u32x4*)(bA + b * 32 * 128 + phys);
+      for (int b = 0; b < 2; ++b) fa[c][b] = *(const u32x4*)(bA + b * 32 * 128 + phys);
+    };
+    auto mm = [&](int c) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
-    }
+        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[c][a], fa[c][b], acc[a][b]);
+    };
+    rd(0); rd(1);
+    FRAG_FENCE();
+    rd(2); mm(0);
+    FRAG_FENCE();
+    rd(3); mm(1);
+    FRAG_FENCE();
+    mm(2); mm(3);
+    FRAG_FENCE();
   };
 
   // epilogue operands are fetched ahead of time: the bias here, the residual rows under the last K step's MFMAs -
@@ -866,18 +887,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
       key[b] = (r >> 1) & 7;
       bA[b] = sA + bufa * A_B + r * 128;
     }
+    u32x4 fw[4][2], fa[4][2];
+    auto rd = [&](int c) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      u32x4 fw[2], fa[2];
+      for (int a = 0; a < 2; ++a) fw[c][a] = *(const u32x4*)(bW + a * 32 * 128 + (((2 * c + half) ^ xsw) * 16));
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fw[a] = *(const u32x4*)(bW + a * 32 * 128 + (((2 * c + half) ^ xsw) * 16));
-#pragma unroll
-      for (int b = 0; b < 2; ++b) fa[b] = *(const u32x4*)(bA[b] + (((2 * c + half) ^ key[b]) * 16));
+      for (int b = 0; b < 2; ++b) fa[c][b] = *(const u32x4*)(bA[b] + (((2 * c + half) ^ key[b]) * 16));
+    };
+    auto mm = [&](int c) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[a], fa[b], acc[a][b]);
-    }
+        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[c][a], fa[c][b], acc[a][b]);
+    };
+    // two k-groups of reads ahead of the MFMAs that consume them (pinned: see FRAG_FENCE)
+    rd(0); rd(1);
+    FRAG_FENCE();
+    rd(2); mm(0);
+    FRAG_FENCE();
+    rd(3); mm(1);
+    FRAG_FENCE();
+    mm(2); mm(3);
+    FRAG_FENCE();
   };
 
   // prologue: whole halo of chunk 0 + weights of step 0
@@ -970,6 +1001,295 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
     }
   }
   GEMM_TL(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Halo-tile main loop, 16 x 16 pixel patches (tile code 133, bf16): the 8 x 16 kernel above runs two 4-wave blocks per CU, each
+// streaming its OWN copy of the weights (per chunk 23 KB of halo + 9 x 16 KB of weights for 128 pixels) with one K step of DMA in
+// flight; measured 31 GB/s of LDS fill per CU at 0.74 - 0.98 PFLOP/s: neither the fill path (~27 B/clk/CU) nor the matrix pipe
+// (41 % busy) is the limit, the serial DMA -> barrier -> MFMA step is.  Here ONE 8-wave block per CU owns a 16 x 16 patch: every
+// weight byte feeds twice the pixels (per chunk 41 KB + 9 x 16 KB for 256 pixels: 204 flop per staged byte, was 113), which frees
+// the LDS for a THREE-slot weight ring (two K steps of DMA in flight over a counted s_waitcnt and one raw s_barrier per step,
+// like tile 132) beside the double-buffered halo.  Every wave issues exactly THREE DMA instructions per step (two weight row
+// groups + a halo piece of the next chunk / an affine row / a dummy), so "vmcnt(3)" = "everything but the newest step has landed".
+// K order (chunk, tap, k) and epilogue equal tile 130's: bitwise the same output.  GN as in tile 130: the in-place transform of
+// halo slot j (= the row groups {w + 8 j}, DMA piece j of every wave, issued at step j) runs at step j + 2 of the previous chunk.
+// Requires D1 % 16 == 0, D2 % 16 == 0, nine spatial taps, full frames, Cin % 64 == 0.
+// Issue-side diet (round 3): the first version of this kernel issued ~290 non-MFMA instructions per K step and wave (64-bit per-lane
+// DMA addresses with zero-page selects, register arrays indexed by the runtime tap, tap offsets fetched from LDS) beside its 16
+// MFMAs - it ran exactly as fast as tile 130, which has the same per-step overhead: both were bound by instruction issue, not by
+// the matrix pipe, the LDS fill or the DMA depth.  Now: the nine taps are unrolled (canonical 3 x 3 order is required, so the halo
+// shift of a tap is a literal), every DMA is a buffer_load ... lds through a wave-uniform descriptor with a lane-constant 32-bit
+// offset and a SCALAR step offset (padding rows: an offset beyond the descriptor's range - they are never fetched, the stage's
+// padding rows are zeroed once).
+template <bool GN>
+__global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemmParams p) {
+  typedef __bf16 T;
+  constexpr int BM = 256, BN = 128, PH = 16, PW = 16, HWD = PW + 2, HR = (PH + 2) * HWD, HG = (HR + 7) / 8, HJ = (HG + 7) / 8;
+  constexpr int NT = 9;
+  constexpr int EPV = 8, ES = 2;
+  constexpr int LDC = BN + 4;
+  constexpr int A_B = HG * 8 * 128;            // halo stage: 41 groups of 8 rows
+  constexpr int W_B = 128 * 128, NWS = 3;
+  constexpr int OPS_B = 2 * A_B + NWS * W_B;
+  constexpr int MAIN_B = (OPS_B > BM * LDC * 4) ? OPS_B : BM * LDC * 4;
+  static_assert(HJ == 6, "halo pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                             // [2][HG*8 rows][128 B]
+  char* sW = smem + 2 * A_B;                   // [3][128 rows][128 B]
+  float* sC = (float*)smem;
+  float* sGN = (float*)(smem + MAIN_B);        // [2 chunk parities][a (64 channels) | b (64 channels)]
+  char* sDummy = smem + MAIN_B + 1024;         // 256 B: target of the DMA instructions that only keep the per-step count uniform
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int Nt = (p.Cout + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wgid % Nt, mt = wgid / Nt;
+  const int n0 = nt * BN;
+  const int TW = p.D2 / PW, tpf = TW * (p.D1 / PH);
+  const int d0 = mt / tpf, trem = mt - d0 * tpf;
+  const int h0 = (trem / TW) * PH, w0 = (trem % TW) * PW;
+  const int64_t mframe = (int64_t)d0 * p.D1 * p.D2;
+
+  const int nchunk = p.Cin >> 6;
+  const int K = p.Cin * NT;
+
+  const int lrow = lane >> 3, pc = lane & 7;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // ---- DMA descriptors (wave-uniform) and lane-constant byte offsets.  A: the frame's rows; W: this block's 128 weight rows.
+  const uint32_t OOB = 0xfffffff0u;            // beyond every descriptor: the lane fetches nothing and writes nothing useful (see below)
+  const int64_t a_bytes = ((int64_t)p.D1 * p.D2 - 1) * p.lda * ES + (int64_t)p.Cin * ES;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + mframe * p.lda * ES), 0, (int)(a_bytes < 0x7fffffff ? a_bytes : 0x7fffffff), 0x00020000);
+  const int w_rows = p.Cout - n0 < BN ? p.Cout - n0 : BN;
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * K * ES), 0, w_rows * K * ES, 0x00020000);
+  uint32_t h_off[HJ];                          // wave w stages halo row groups g = w + 8 j
+  unsigned h_okmask = 0;
+#pragma unroll
+  for (int j = 0; j < HJ; ++j) {
+    const int g = wave + 8 * j;
+    const int r = 8 * g + lrow;
+    const int hr = r / HWD, hc = r - hr * HWD;
+    const int hh = h0 - 1 + hr, ww = w0 - 1 + hc;
+    const bool ok = g < HG && r < HR && (unsigned)hh < (unsigned)p.D1 && (unsigned)ww < (unsigned)p.D2;
+    const int logical = pc ^ ((r >> 1) & 7);
+    h_off[j] = ok ? (uint32_t)((((int64_t)hh * p.D2 + ww) * p.lda + logical * EPV) * ES) : OOB;
+    h_okmask |= (ok ? 1u : 0u) << j;
+  }
+  uint32_t w_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + 8 * i) + lrow;
+    const int logical = pc ^ ((row >> 1) & 7);
+    w_off[i] = row < w_rows ? (uint32_t)((row * K + logical * EPV) * ES) : OOB;     // rows past Cout: their outputs are never stored
+  }
+  // ---- fused input GroupNorm
+  constexpr int NSLOT = (HG * 64 + 511) / 512;                 // 16-byte slots of a halo stage per thread (6; the last one: wave 0 only)
+  unsigned gvalid = 0;
+  const float* gn_src = nullptr;
+  const int glc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;          // first channel (inside a chunk) of this thread's 16 bytes: the same in every slot
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int r = (tid >> 3) + 64 * i;
+    const int hr = r / HWD, hc = r - hr * HWD;
+    const bool ok = r < HR && (unsigned)(h0 - 1 + hr) < (unsigned)p.D1 && (unsigned)(w0 - 1 + hc) < (unsigned)p.D2;
+    gvalid |= (ok ? 1u : 0u) << i;
+  }
+  if (GN) {
+    const int sidx = min((int)(mframe / p.gn_rows), p.gn_S - 1);
+    gn_src = (wave == 0 ? p.gn_a : p.gn_b) + (int64_t)sidx * p.Cin + lane;
+  }
+  // padding rows of both halo stages are zeroed ONCE: an out-of-range DMA lane may or may not write its (zero) result, the
+  // in-place transform leaves padding slots alone, and the validity of a slot does not depend on the chunk
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i)
+    if ((i * 512 + 512 <= HG * 64 || tid < HG * 64 - i * 512) && !((gvalid >> i) & 1u)) {
+      *(u32x4*)(sA + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)(sA + A_B + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
+    }
+  __syncthreads();
+
+  auto dma_dummy = [&]() { __builtin_amdgcn_global_load_lds((gptr_t)g_zero_page, (lptr_t)sDummy, 4, 0, 0); };
+  auto issue_w = [&](int slot, int c2, int t2) {               // weights of (chunk c2, tap t2): two DMA instructions
+    const int soff = (t2 * p.Cin + c2 * 64) * ES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * W_B + (wave + 8 * i) * 1024), 16, w_off[i], soff, 0, 0);
+  };
+  auto issue_h = [&](int buf, int c, int j) {                  // exactly one DMA instruction (j is a literal at every call site)
+    if (wave + 8 * j < HG)                                     // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(sA + buf * A_B + (wave + 8 * j) * 1024), 16, h_off[j], c * 128, 0, 0);
+    else
+      dma_dummy();
+  };
+  auto issue_gn = [&](int c) {                                 // exactly one DMA instruction: 64 floats of a (wave 0) / b (wave 1) -> ring slot c & 1
+    if (GN && wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)(gn_src + c * 64), (lptr_t)(sGN + (c & 1) * 128 + wave * 64), 4, 0, 0);
+    else dma_dummy();
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int xsw = (l31 >> 1) & 7;
+  int rb[2];                                   // halo row of this lane's pixel (tap 0,0) per m sub-tile
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int px = wr * 64 + b * 32 + l31;
+    rb[b] = ((px >> 4) + 1) * HWD + (px & 15) + 1;
+  }
+  const char* bWl = sW + (wc * 64 + l31) * 128;                // + slot * W_B
+  auto compute = [&](int wslot, int bufa, int toff) {          // toff: the tap's halo-row shift (a literal)
+    const char* bW = bWl + wslot * W_B;
+    const char* bA[2];
+    int key[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int r = rb[b] + toff;
+      key[b] = (r >> 1) & 7;
+      bA[b] = sA + bufa * A_B + r * 128;
+    }
+    u32x4 fw[4][2], fa[4][2];
+    auto rd = [&](int c) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fw[c][a] = *(const u32x4*)(bW + a * 32 * 128 + (((2 * c + half) ^ xsw) * 16));
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fa[c][b] = *(const u32x4*)(bA[b] + (((2 * c + half) ^ key[b]) * 16));
+    };
+    auto mm = [&](int c) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Mma<T>::run(fw[c][a], fa[c][b], acc[a][b]);
+    };
+    rd(0); rd(1);
+    FRAG_FENCE();
+    rd(2); mm(0);
+    FRAG_FENCE();
+    rd(3); mm(1);
+    FRAG_FENCE();
+    mm(2); mm(3);
+    FRAG_FENCE();
+  };
+  auto transform = [&](int buf, int c, int i) {                // halo slot i of stage buf (chunk c): act(x a + b) in place
+    if (i * 512 + 512 <= HG * 64 || tid < HG * 64 - i * 512) { // the partial last slot: wave-uniform
+      const float* ap = sGN + (c & 1) * 128 + glc;
+      const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4), b0 = *(const f32x4*)(ap + 64), b1 = *(const f32x4*)(ap + 68);
+      const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      char* q = sA + buf * A_B + tid * 16 + i * 8192;
+      const u32x4 v = *(const u32x4*)q;
+      float f[EPV];
+      Elt<T>::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const float w = f[e] * av[e] + bv[e];
+        f[e] = p.gn_act ? silu_f(w) : w;
+      }
+      const u32x4 y = Elt<T>::pack(f);
+      *(u32x4*)q = ((gvalid >> i) & 1u) ? y : v;
+    }
+  };
+
+  // ---- prologue: halo of chunk 0 (six groups of three DMA instructions with the affine rows of chunks 0 and 1 and the weights of
+  //      steps 0 and 1 in the free positions), then everything of chunk 0 is normalised before the first MFMA
+#pragma unroll
+  for (int j = 0; j < HJ; ++j) issue_h(0, 0, j);
+  issue_gn(0);
+  if (nchunk > 1) issue_gn(1); else dma_dummy();
+  dma_dummy();
+  issue_w(0, 0, 0);
+  dma_dummy();
+  issue_w(1, 0, 1);
+  dma_dummy();
+  constexpr int CVN = BN / 8, RP = 512 / CVN, NPASS = BM / RP;
+  const int e_cg = tid % CVN, e_rr = tid / CVN;
+  const int e_co = n0 + e_cg * 8;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = (p.bias && e_co < p.Cout) ? p.bias[e_co + j] : 0.f;
+  if (GN) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (also the weights of steps 0 / 1: the loop's first waits are then no-ops)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) transform(0, 0, i);
+    // (the loop's first barrier orders these LDS writes before the first fragment reads)
+  }
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); // everything but the newest group of three has landed: this step is complete
+      __builtin_amdgcn_s_barrier();                            // ... for every wave; every wave is past its fragment reads of the previous step
+      asm volatile("" ::: "memory");
+      const int wslot = (c * NT + t) % NWS;
+      // the DMA group of this step: weights of the step after next into the slot the previous step left + one instruction for a later chunk
+      auto group = [&]() {
+        const int t2 = (t + 2) % NT, c2 = c + (t + 2) / NT;
+        if (c2 < nchunk) issue_w((wslot + 2) % NWS, c2, t2);
+        else { dma_dummy(); dma_dummy(); }
+        if (t < HJ) { if (more) issue_h((c + 1) & 1, c + 1, t); else dma_dummy(); }
+        else if (t == NT - 1 && c + 2 < nchunk) issue_gn(c + 2); // (its ring slot was last read in steps 2 .. 7 of chunk c - 1)
+        else dma_dummy();
+      };
+      constexpr int TOFF[9] = {-19, -18, -17, -1, 0, 1, 17, 18, 19};   // (dh, dw) in row-major 3 x 3 order -> halo-row shift dh * 18 + dw
+      int toff = TOFF[t];
+      asm volatile("" : "+s"(toff));       // keep the 72 per-tap fragment addresses out of the registers: recomputed per step (~20 VALU)
+      group();
+      compute(wslot, c & 1, toff);
+      if (GN && more && t >= 2 && t < 2 + NSLOT) transform((c + 1) & 1, c + 1, t - 2);   // piece t - 2 landed with this step's wait
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                             // every wave is past its last operand read: sC may alias
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const int ml = wr * 64 + b2 * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = wc * 64 + a * 32 + 8 * q + 4 * half;
+        f32x4 v = {acc[a][b2][4 * q], acc[a][b2][4 * q + 1], acc[a][b2][4 * q + 2], acc[a][b2][4 * q + 3]};
+        *(f32x4*)(sC + ml * LDC + col) = v;
+      }
+    }
+  __syncthreads();
+  if (e_co < p.Cout) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int ml = e_rr + ps * RP;
+      const int64_t m = mframe + (int64_t)(h0 + (ml >> 4)) * p.D2 + w0 + (ml & 15);
+      float v[8];
+      const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + e_cg * 8);
+      const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + e_cg * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
+      if (p.R) {
+        float rf[EPV];
+        Elt<T>::unpack(*(const u32x4*)(p.R + (m * p.ldr + e_co) * ES), rf);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) v[j] += rf[j];
+      }
+      *(u32x4*)(p.Y + (m * p.ldy + e_co) * ES) = Elt<T>::pack(v);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1409,6 +1729,32 @@ static int launch_conv_gemm_halo(const ConvGemmParams& p, hipStream_t st) {
   return mmd_check_launch("conv_gemm_halo");
 }
 
+// tile 133: halo-tile main loop on 16 x 16 patches, 8 waves, three-slot weight ring (bf16, nine spatial taps)
+template <bool GN>
+static int launch_conv_gemm_halo16(const ConvGemmParams& p, hipStream_t st) {
+  bool taps_ok = p.ntaps == 9;
+  for (int t = 0; t < p.ntaps && taps_ok; ++t)       // canonical order (dh, dw) row-major: the kernel's tap shifts are literals
+    taps_ok = p.taps[t * 3] == 0 && p.taps[t * 3 + 1] == t / 3 - 1 && p.taps[t * 3 + 2] == t % 3 - 1;
+  if (!taps_ok || p.D1 % 16 != 0 || p.D2 % 16 != 0 || (int64_t)p.D0 * p.D1 * p.D2 != p.M || p.Cin % 64 != 0 ||
+      ((int64_t)p.D1 * p.D2 - 1) * p.lda * 2 + (int64_t)p.Cin * 2 >= 0x7fffffffLL || (int64_t)128 * p.Cin * 9 * 2 >= 0x7fffffffLL)
+    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 133 (halo, 16 x 16 patches): needs the nine spatial taps in row-major (dh, dw) order, "
+                         "D1 %% 16 == 0, D2 %% 16 == 0, full frames, Cin %% 64 == 0 and frames below 2 GB");
+  if (GN && p.gn_rows % ((int64_t)p.D1 * p.D2) != 0)
+    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 133 with fused GroupNorm: needs slices of whole frames");
+  constexpr size_t OPS_B = 2 * (size_t)(41 * 8 * 128) + 3 * (size_t)(128 * 128), C_B = 256 * 132 * sizeof(float);
+  const size_t lds = (OPS_B > C_B ? OPS_B : C_B) + 1024 + 256;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_halo16_kernel<GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_halo16: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = (p.M / 256) * cdiv(p.Cout, 128);
+  hipLaunchKernelGGL((conv_gemm_halo16_kernel<GN>), dim3(grid), dim3(512), lds, st, p);
+  return mmd_check_launch("conv_gemm_halo16");
+}
+
 template <typename T>
 static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds = 128 * 132 * sizeof(float) + 336;
@@ -1464,6 +1810,10 @@ static int launch_conv_gemm(const ConvGemmParams& p, hipStream_t st) {
 
 template <typename T>
 static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st) {
+  if (tile == 133) {
+    if constexpr (Elt<T>::EPV == 8) return p.gn_a ? launch_conv_gemm_halo16<true>(p, st) : launch_conv_gemm_halo16<false>(p, st);
+    else return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 133: bf16 only");
+  }
   if (p.gn_a) {
     if (tile == 130) {
       if constexpr (Elt<T>::EPV == 8) return launch_conv_gemm_halo<T, true>(p, st);
@@ -1492,7 +1842,7 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   MMD_REQUIRE(lda % epv == 0 && ldy % epv == 0 && (!R || ldr % epv == 0), "conv_gemm: row strides must be 16-byte multiples");
   MMD_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)R) % 16 == 0, "conv_gemm: pointers must be 16-byte aligned");
   MMD_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "conv_gemm: bad position dims");
-  MMD_REQUIRE(!gn_a || (gn_b && (ntaps == 1 || tile == 130) && gn_S > 0 && gn_rows >= 128 && (Cin <= 256 || tile == 131 || tile == 130) &&
+  MMD_REQUIRE(!gn_a || (gn_b && (ntaps == 1 || tile == 130 || tile == 133) && gn_S > 0 && gn_rows >= 128 && (Cin <= 256 || tile == 131 || tile == 130 || tile == 133) &&
                         (int64_t)gn_S * gn_rows == M),
               "gn_conv1x1 / gn_conv_gemm: needs contiguous slices of >= 128 rows covering M, Cin <= 256 unless tile 130 / 131, taps only with tile 130 "
               "(got S=%d rows=%ld Cin=%d M=%d ntaps=%d tile=%d)", gn_S, (long)gn_rows, Cin, M, ntaps, tile);
@@ -1501,14 +1851,14 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
   p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = gn_act; p.gn_S = gn_S; p.gn_rows = gn_rows;
-  MMD_REQUIRE(!stats || (M % 64 == 0 && stats_ld >= Cout && tile != 130 && (uintptr_t)stats % 8 == 0),
-              "conv_gemm: output statistics need M %% 64 == 0, stats_ld >= Cout and a row-tiled main loop (not tile 130)");
+  MMD_REQUIRE(!stats || (M % 64 == 0 && stats_ld >= Cout && tile != 130 && tile != 133 && (uintptr_t)stats % 8 == 0),
+              "conv_gemm: output statistics need M %% 64 == 0, stats_ld >= Cout and a row-tiled main loop (not tiles 130 / 133)");
   p.stats = stats; p.stats_ld = stats_ld;
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
   MMD_REQUIRE(tile == 64 || tile == 128 || ((tile == 129 || tile == 132) && !gn_a) || (tile == 130 && (!gn_a || dtype == MMD_BF16)) ||
-                  (tile == 131 && dtype == MMD_BF16),
+                  ((tile == 131 || tile == 133) && dtype == MMD_BF16),
               "conv_gemm: tile must be 0, 64, 128, 129 (128 direct-to-LDS), 130 (halo-tile 3x3), 131 (row strip, bf16 1x1 convs) or 132 (129 with a "
               "four-slot ring for launches of few tiles)");
   if (tile == 131) return dispatch_conv1x1_strip(p, st);
@@ -1562,7 +1912,7 @@ extern "C" int mmd_gn_conv_gemm(int dtype, const void* A, int64_t lda, const flo
                                 int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
                                 void* stream) {
   MMD_REQUIRE(gn_a && gn_b, "gn_conv_gemm: null GroupNorm affine");
-  MMD_REQUIRE(tile == 130, "gn_conv_gemm: the fused input GroupNorm of a conv with taps exists on tile 130 (halo) only");
+  MMD_REQUIRE(tile == 130 || tile == 133, "gn_conv_gemm: the fused input GroupNorm of a conv with taps exists on the halo tiles (130 / 133) only");
   return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, gn_a, gn_b, act, S,
                         rows_per_slice, nullptr, 0, stream);
 }

@@ -260,6 +260,20 @@ def halo_tile_ok(x, taps, dims):
             and dims[2] % 16 == 0 and dims[0] * dims[1] * dims[2] == M and Cin % (128 // x.element_size()) == 0)
 
 
+# tile 133 = the halo-tile main loop on 16 x 16 patches (8 waves, one block per CU, three-slot weight ring): same K order as tile 130,
+# bitwise the same output, so wherever tile 130 is pinned and the frame sides are multiples of 16 the faster of the two may run
+# (MMD_HALO16=0: always tile 130).
+_HALO16 = os.environ.get("MMD_HALO16", "1") != "0"
+
+
+def halo_tile_code(x, taps, dims):
+    """130 or 133 for a launch tile 130 accepts.  Measured (tools/halo_bench.py, MI355X): the one-block-per-CU tile 133 wins from four
+    channel chunks on (ds1 256->128: 193 -> 164 us, ds2 640->256: 200 -> 166 us); with two chunks its prologue and epilogue have no
+    co-resident block to hide behind (ds1 128->128: 103 vs 110 us)."""
+    return 133 if (_HALO16 and x.dtype == torch.bfloat16 and len(taps) == 9 and dims[1] % 16 == 0 and dims[2] % 16 == 0
+                   and x.shape[1] >= 256 and tuple(tuple(t) for t in taps) == tuple(TAPS_SPATIAL)) else 130
+
+
 def _stats_args(stats, M, Cout):
     """stats: fp32 view [M / 64, Cout, 2] (a column slice of the output's record buffer) -> (pointer, row stride in float2)."""
     if stats.dtype != torch.float32 or tuple(stats.shape) != (M // 64, Cout, 2) or M % 64 or stats.stride(1) != 2 or stats.stride(2) != 1:
@@ -311,7 +325,7 @@ def strip_tile_pinned(x, Cout, taps=TAPS_1, stats=None, geom=None):
 
 
 def _tile_name(tile):
-    return {129: "128glds", 130: "128halo", 131: "strip", 132: "128ring"}.get(tile, tile)
+    return {129: "128glds", 130: "128halo", 131: "strip", 132: "128ring", 133: "256halo"}.get(tile, tile)
 
 
 # tile 132 (mmd_gemm.hip: the direct-to-LDS loop with a four-slot LDS ring, three K steps of DMA in flight, one block per CU) is
@@ -343,7 +357,7 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, nt, arr,
             int(dims[0]), int(dims[1]), int(dims[2]))
     if tile == 0 and stats is None and halo_tile_pinned(x, taps, dims):
-        tile = 130
+        tile = halo_tile_code(x, taps, dims)
     if tile == 0 and strip_tile_pinned(x, Cout, taps, stats):
         tile = 131
     if tile == 0:
@@ -444,8 +458,8 @@ def halo_gn_ok(x, taps, dims, geom: Geom):
             and geom.S * geom.Tn == x.shape[0] and geom.Tn % (dims[1] * dims[2]) == 0)
 
 
-def gn_conv_gemm(x, a, b, geom: Geom, act, w, bias, taps, dims, residual=None, out=None):
-    """3x3 conv of GroupNorm'd rows with the normalisation applied to the staged halo (include/mmd.h: mmd_gn_conv_gemm, tile 130)."""
+def gn_conv_gemm(x, a, b, geom: Geom, act, w, bias, taps, dims, residual=None, out=None, tile=0):
+    """3x3 conv of GroupNorm'd rows with the normalisation applied to the staged halo (include/mmd.h: mmd_gn_conv_gemm, tiles 130 / 133)."""
     _chk2d(x)
     M, Cin = x.shape
     Cout = w.shape[0]
@@ -462,8 +476,8 @@ def gn_conv_gemm(x, a, b, geom: Geom, act, w, bias, taps, dims, residual=None, o
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
     _dispatch("mmd_gn_conv_gemm", H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
               w.data_ptr(), H.ptr(bias), H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
-              M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), 130,
-              meta=(f"gn_conv_gemm<bf16,128halo>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
+              M, Cout, Cin, nt, arr, int(dims[0]), int(dims[1]), int(dims[2]), tile or halo_tile_code(x, taps, dims),
+              meta=(f"gn_conv_gemm<bf16,{_tile_name(tile or halo_tile_code(x, taps, dims))}>[M={M},K={Cin * nt},N={Cout}]", flops, nbytes))
     return out
 
 

@@ -41,7 +41,10 @@ def test_halo_fused_groupnorm(ops, act, N, F, H, W, Cin, Cout, cat):
     ga, gb = ops.gn_stats(x, gamma, beta, geom)
     dims = (N * F, H, W)
     assert ops.halo_tile_ok(x, ops.TAPS_SPATIAL, dims)
-    y = ops.gn_conv_gemm(x, ga, gb, geom, act, w, b, ops.TAPS_SPATIAL, dims)
+    y = ops.gn_conv_gemm(x, ga, gb, geom, act, w, b, ops.TAPS_SPATIAL, dims, tile=130)
+    if H % 16 == 0 and W % 16 == 0:        # the 16 x 16-patch halo tile: same K order, same transform -> bitwise the same
+        y16 = ops.gn_conv_gemm(x, ga, gb, geom, act, w, b, ops.TAPS_SPATIAL, dims, tile=133)
+        assert torch.equal(y.view(torch.int16), y16.view(torch.int16)), f"tile 133 vs 130 (fused norm): rel-L2 {rel_l2(y16.float().cpu(), y.float().cpu().numpy()):.3e}"
     xn = ops.gn_apply(x, ga, gb, geom, act=act)
     y2 = ops.conv_gemm(xn, w, b, taps=ops.TAPS_SPATIAL, dims=dims, tile=130)
     torch.cuda.synchronize()
@@ -125,3 +128,23 @@ def test_deep_ring_tile_statistics(ops):
     assert torch.equal(recs[0][0], recs[1][0]) and torch.equal(recs[0][1], recs[1][1])
     ysum = recs[0][0].float().reshape(M // 64, 64, Cout).sum(1)
     assert rel_l2(recs[1][1][:, :, 0].cpu(), ysum.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("D0,H,W,Cin,Cout", [(5, 16, 32, 64, 128), (3, 16, 16, 128, 96), (2, 32, 48, 192, 256 + 8), (1, 64, 64, 640, 128)])
+def test_halo16_tile_is_bitwise_the_halo_tile(ops, res, D0, H, W, Cin, Cout):
+    """conv_gemm tile 133 (16 x 16 patches, 8 waves, three-slot weight ring, counted waits) against tile 130: chunk-major K order in
+    both, so bitwise equal - 1 to 10 channel chunks, patches on every border, a single-patch frame, ragged Cout, a residual; and
+    against the tap-major direct-to-LDS loop to rounding."""
+    M = D0 * H * W
+    g = torch.Generator(device="cuda").manual_seed(M + Cin)
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(BF)
+    w = (torch.randn(Cout, Cin * 9, device="cuda", generator=g) * (Cin * 9) ** -0.5).to(BF)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(M, Cout, device="cuda", generator=g).to(BF) if res else None
+    y0 = ops.conv_gemm(x, w, b, taps=ops.TAPS_SPATIAL, dims=(D0, H, W), residual=r, tile=130)
+    for _ in range(3):
+        y1 = ops.conv_gemm(x, w, b, taps=ops.TAPS_SPATIAL, dims=(D0, H, W), residual=r, tile=133)
+        assert torch.equal(y0, y1), f"rel-L2 {rel_l2(y1.float().cpu(), y0.float().cpu().numpy()):.3e}"
+    y2 = ops.conv_gemm(x, w, b, taps=ops.TAPS_SPATIAL, dims=(D0, H, W), residual=r, tile=129)
+    assert rel_l2(y1.float().cpu(), y2.float().cpu().numpy()) < 4e-3
