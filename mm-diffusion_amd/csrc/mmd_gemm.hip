@@ -32,6 +32,8 @@ struct ConvGemmParams {
   // optional GroupNorm statistics of the OUTPUT for its consumer (mmd_gn_finalize_stats): per (64-row record, column) the sum and
   // sum of squares of the stored values, stats[(m / 64) * stats_ld + column] = float2; M % 64 == 0
   float* stats; int64_t stats_ld;
+  // or: in-launch statistics + affine of the consumer GroupNorm (include/mmd.h: mmd_gn_tail); gt.acc != nullptr switches it on
+  mmd_gn_tail gt;
   int taps[27 * 3];
 };
 
@@ -65,6 +67,7 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
       }
   }
   __syncthreads();
+  float* sQ = sP + 4 * NREC * BN * 2;                   // tail mode: the per-(record, column) totals, then folded into the consumer's groups
   for (int t = tid; t < NREC * BN; t += 256) {
     const int r = t / BN, col = t % BN;
     float a = 0.f, b = 0.f;
@@ -73,10 +76,26 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
       a += sP[(((w * NREC + r) * BN) + col) * 2];
       b += sP[(((w * NREC + r) * BN) + col) * 2 + 1];
     }
-    if (n0 + col < p.Cout && m0 + r * 64 < p.M) {
+    if (p.gt.acc) {
+      sQ[t * 2] = a;
+      sQ[t * 2 + 1] = b;
+    } else if (n0 + col < p.Cout && m0 + r * 64 < p.M) {
       float* d = p.stats + ((int64_t)(m0 / 64 + r) * p.stats_ld + n0 + col) * 2;
       d[0] = a;
       d[1] = b;
+    }
+  }
+  if (p.gt.acc) {                                       // block-uniform: quads of 4 columns into the buffer's integer accumulators
+    __syncthreads();
+    const int ncol = p.Cout - n0 < BN ? p.Cout - n0 : BN, nq = ncol >> 2;
+    for (int t = tid; t < NREC * nq; t += 256) {
+      const int r = t / nq, q = t - r * nq;
+      if (m0 + r * 64 < p.M) {
+        const float* v = sQ + (r * BN + 4 * q) * 2;
+        const float a = (v[0] + v[2]) + (v[4] + v[6]), b = (v[1] + v[3]) + (v[5] + v[7]);
+        const int sl = (int)((m0 + r * 64) / p.gt.rows_per_slice);
+        gn_tail_add(p.gt.acc + ((int64_t)sl * p.gt.q_ld + p.gt.q_off + (n0 >> 2) + q) * 4, a, b);
+      }
     }
   }
 }
@@ -192,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
         for (int h = 0; h < 8 / EPV; ++h) {
           const u32x4 pk = Elt<T>::pack(v + h * EPV);
           *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = pk;
-          if (p.stats) {                 // statistics of the values as STORED (what the consumer GroupNorm reads back)
+          if (p.stats || p.gt.acc) {     // statistics of the values as STORED (what the consumer GroupNorm reads back)
             float rf[EPV];
             Elt<T>::unpack(pk, rf);
 #pragma unroll
@@ -202,9 +221,10 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
       }
     }
   }
-  if (p.stats) {                         // block-uniform
+  if (p.stats || p.gt.acc) {             // block-uniform
     __syncthreads();                     // every thread is past its last sC read: the wave partials alias the staging tile
     epilogue_stats<BM, BN>(p, ssum, ssq, sC, m0, n0, tid);
+    if (p.gt.acc) gn_tail_arrive(p.gt, (unsigned*)sC, tid, 256, gridDim.x);
   }
 }
 
@@ -402,8 +422,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 // 73 - 138 us at 260 - 280 TFLOP/s); there the block keeps THREE K steps of DMA in flight over counted s_waitcnt vmcnt(16 / 8 / 0) and
 // one raw s_barrier per step (no fence: __syncthreads() would drain the queue).  Same K order, same epilogue: bitwise equal to the
 // other tiled loops, so the choice between 129 and 132 is free (ops.conv_gemm: by tile count).
-template <typename T, bool FAST, int NS>
+// DESC (FAST only, round 3): the DMA instructions go through wave-uniform buffer descriptors - a lane-constant 32-bit row offset
+// that is recomputed only when the tap changes (padding rows: an offset beyond the descriptor, the DMA then writes zeros), and a
+// SCALAR offset for the K step - instead of per-step 64-bit pointers with zero-page selects: ~150 -> ~50 non-MFMA instructions per
+// step (the tiled loops are issue-bound, see tile 133).  Needs the activation view below 2 GB.
+template <typename T, bool FAST, int NS, bool DESC>
 __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(const ConvGemmParams p) {
+  static_assert(!DESC || FAST, "descriptor addressing: uniform-tap K steps only");
   constexpr int BM = 128, BN = 128;
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
@@ -477,7 +502,42 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // DESC state: descriptors over the activation view / this block's weight rows, lane-constant offsets
+  const uint32_t OOB = 0xfffffff0u;
+  const int w_rows = p.Cout - n0 < BN ? p.Cout - n0 : BN;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)p.M - 1) * p.lda * ES + (int64_t)p.Cin * ES), 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * K * ES), 0, (int)((int64_t)w_rows * K * ES), 0x00020000);
+  uint32_t a_base[4], w_off[4], a_voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_base[i] = (uint32_t)((arow[i] * p.lda + (int64_t)c_par[i & 1] * EPV) * ES);
+    const int row = wave * 32 + 8 * i + lrow;
+    w_off[i] = row < w_rows ? (uint32_t)((row * K + (int64_t)c_par[i & 1] * EPV) * ES) : OOB;
+    a_voff[i] = OOB;
+  }
   auto issue = [&](int buf) {
+    if constexpr (DESC) {
+      if (u_civ == 0) {                                   // a new tap (uniform): row validity and row shift of this tap
+        const int t3 = u_tap * 3;
+        const int o0 = __builtin_amdgcn_readfirstlane(s_taps[t3]), o1 = __builtin_amdgcn_readfirstlane(s_taps[t3 + 1]),
+                  o2 = __builtin_amdgcn_readfirstlane(s_taps[t3 + 2]);
+        const int shift = (int)((((int64_t)o0 * D12 + (int64_t)o1 * p.D2 + o2) * p.lda) * ES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = (unsigned)(pp0[i] + o0) < (unsigned)p.D0 && (unsigned)(pp1[i] + o1) < (unsigned)p.D1 &&
+                          (unsigned)(pp2[i] + o2) < (unsigned)p.D2;
+          a_voff[i] = ok ? a_base[i] + (uint32_t)shift : OOB;
+        }
+      }
+      const int soffA = u_civ * 16, soffW = (u_tap * p.Cin + u_civ * EPV) * ES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(sA + buf * TILE_B + (wave * 32 + 8 * i) * 128), 16, a_voff[i], soffA, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + buf * TILE_B + (wave * 32 + 8 * i) * 128), 16, w_off[i], soffW, 0, 0);
+      return;
+    }
     if (FAST) {
       const int t3 = u_tap * 3;
       const int o0 = __builtin_amdgcn_readfirstlane(s_taps[t3]), o1 = __builtin_amdgcn_readfirstlane(s_taps[t3 + 1]),
@@ -687,7 +747,7 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
         for (int h = 0; h < 8 / EPV; ++h) {
           const u32x4 pk = Elt<T>::pack(v + h * EPV);
           *(u32x4*)(p.Y + ((int64_t)m * p.ldy + e_co + h * EPV) * ES) = pk;
-          if (p.stats) {                 // statistics of the values as STORED (what the consumer GroupNorm reads back)
+          if (p.stats || p.gt.acc) {     // statistics of the values as STORED (what the consumer GroupNorm reads back)
             float rf[EPV];
             Elt<T>::unpack(pk, rf);
 #pragma unroll
@@ -697,9 +757,10 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
       }
     }
   }
-  if (p.stats) {                         // block-uniform
+  if (p.stats || p.gt.acc) {             // block-uniform
     __syncthreads();                     // every thread is past its last sC read: the wave partials alias the staging tile
     epilogue_stats<128, 128>(p, ssum, ssq, sC, m0, n0, tid);
+    if (p.gt.acc) gn_tail_arrive(p.gt, (unsigned*)sC, tid, 256, gridDim.x);
   }
   GEMM_TL(3);
 #ifdef GEMM_TIMELINE
@@ -1349,7 +1410,8 @@ __device__ __forceinline__ float halfwave_sum16(const float (&u)[16], int l31) {
 #else
 #define STRIP_WAVES_K128 3
 #endif
-template <int KS, int RF, int CC, int GNM>   // GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
+template <int KS, int RF, int CC, int GNM, int STM>   // STM: output statistics 0 none / 1 per-column records / 2 in-launch tail (compile
+                                             // time: the runtime branches cost the K = 128 instance 30 spilled registers).  GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
                                              // normalisation in one kernel spill ~100 registers around the branch)
 __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
   constexpr int K = 64 * KS;                 // input channels
@@ -1381,6 +1443,8 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
   float* sBias = (float*)(smem + 2 * STAGE_B);          // [Cs] bias of this block's column range
   float* sGN = sBias + ((Cs + 3) & ~3);                 // [2 slices][a | b][K] fused GroupNorm affine
   float* sRec = sGN + (GNM != 0 ? 4 * K : 0);           // RF = 1: [2 chunk parities][4 waves][NA * 2][32] half-record statistics
+  // tail mode (p.gt.acc): the block's exact integer accumulators [4 local slices][32 groups][4], flushed to global memory at the end
+  long long* sAccT = (long long*)(sRec + (RF == 1 ? 2 * 4 * (CC / 32) * 2 * 32 : 0) + 2);   // (+2 floats: 16-byte carve -> 8-byte aligned)
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -1463,6 +1527,10 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     if (tid + 256 * i < Cs) sBias[tid + 256 * i] = bias_v[i];
+  if (STM == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sAccT[tid + 256 * e] = 0;           // 16 KB (launcher: TAIL_B)
+  }
   if (gn) {
 #pragma unroll
     for (int e = 0; e < KS; ++e) sGN[tid + 256 * e] = tv[e];
@@ -1498,6 +1566,16 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
   const int xsw = (l31 >> 1) & 7;
   const bool wave_ok = (int64_t)m0 + wave * (32 * RF) < p.M;      // wave-uniform: statistics records are whole waves (RF = 2)
   const int64_t rec = ((int64_t)m0 + wave * (32 * RF)) / 64;
+  // tail mode: the local slice of this wave's rows (a wave's 32 * RF rows lie inside one 64-row record, a record inside one slice);
+  // the block's quad accumulators live in LDS when [t_nsl local slices][Cs / 4 quads][4] fits 16 KB, else the waves add to global memory
+  int t_sl = 0, t_s0 = 0, t_nsl = 1;
+  bool t_lds = false;
+  if (STM == 2) {
+    t_s0 = (int)(m0 / p.gt.rows_per_slice);
+    t_sl = (int)(((int64_t)m0 + wave * (32 * RF)) / p.gt.rows_per_slice) - t_s0;    // 0 .. 3 (rows_per_slice >= 64, block of <= 256 rows)
+    t_nsl = (int)(((int64_t)m0 + BR - 1) / p.gt.rows_per_slice) - t_s0 + 1;
+    t_lds = t_nsl * (Cs >> 2) * 4 <= 2048;
+  }
 #if defined(STRIP_ABLATE) && STRIP_ABLATE == 4      // prologue + one chunk
   for (int ci = 0; ci < 1; ++ci) {
 #else
@@ -1610,14 +1688,48 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
           if (DEFER && a == NA - 1) outv[f][j2] = pk;
           else if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = pk;
 #endif
-          if (p.stats) {                                 // statistics of the values as STORED
+          if (STM == 1) {                                 // statistics of the values as STORED
             float rf[8];
             Elt<__bf16>::unpack(pk, rf);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { u[2 * j] += rf[j]; u[2 * j + 1] += rf[j] * rf[j]; }
           }
+          if (STM == 2) {                                // tail mode: the lane's 8 channels = two quads of the buffer
+            float rf[8];
+            Elt<__bf16>::unpack(pk, rf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              u[0] += rf[j];
+              u[1] += rf[4 + j];
+              u[2] += rf[j] * rf[j];
+              u[3] += rf[4 + j] * rf[4 + j];
+            }
+          }
         }
-        if (p.stats) {                                   // block-uniform
+        if (STM == 2) {                                  // block-uniform.  Four values over the 32 rows of the half-wave: recursive halving
+          const bool h16 = (l31 & 16) != 0, h8 = (l31 & 8) != 0;
+          const float k0 = h16 ? u[2] : u[0], s0 = h16 ? u[0] : u[2], k1 = h16 ? u[3] : u[1], s1 = h16 ? u[1] : u[3];
+          const float a0 = k0 + __shfl_xor(s0, 16, 64), a1 = k1 + __shfl_xor(s1, 16, 64);     // lane: (sum q0, sum q1) or (sq q0, sq q1)
+          float tt = (h8 ? a1 : a0) + __shfl_xor(h8 ? a0 : a1, 8, 64);                          // quad h8, quantity h16
+          tt += __shfl_xor(tt, 4, 64);
+          tt += __shfl_xor(tt, 2, 64);
+          tt += __shfl_xor(tt, 1, 64);
+          if (wave_ok && (l31 & 7) == 0) {
+            int hi, lw;
+            gn_tail_split(tt, h16 ? GN_TAIL_HQ : GN_TAIL_HS, hi, lw);
+            const int ql = ((col - cbase) >> 2) + (h8 ? 1 : 0);                                  // quad inside this block's column range
+            if (t_lds) {
+              gn_u64* d = (gn_u64*)(sAccT + ((t_sl * (Cs >> 2) + ql) * 4 + (h16 ? 2 : 0)));
+              atomicAdd(d, (gn_u64)(long long)hi);
+              atomicAdd(d + 1, (gn_u64)(long long)lw);
+            } else {
+              gn_u64* d = (gn_u64*)(p.gt.acc + ((int64_t)(t_s0 + t_sl) * p.gt.q_ld + p.gt.q_off + (cbase >> 2) + ql) * 4 + (h16 ? 2 : 0));
+              atomicAdd(d, (gn_u64)(long long)hi);
+              atomicAdd(d + 1, (gn_u64)(long long)lw);
+            }
+          }
+        }
+        if (STM == 1) {                                   // block-uniform
           const float tot = halfwave_sum16(u, l31);      // float (l31 >> 1) of the 8 channels' (sum, sum of squares) records
           if (RF == 1) {
             // a wave holds HALF a record (32 rows): park the partial for the even wave of the pair, which adds (own + partner) after
@@ -1643,16 +1755,29 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
         if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = outv[f][j2];
 #endif
       if (RF == 1) {
-        if (p.stats && wave_ok && (wave & 1) == 0 && (l31 & 1) == 0) {
+        if (STM == 1 && wave_ok && (wave & 1) == 0 && (l31 & 1) == 0) {
           const float other = sRec[(((ci & 1) * 4 + wave + 1) * (NA * 2) + (NA - 1) * 2 + j2) * 32 + half * 16 + (l31 >> 1)];
           p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2] + other;
         }
-      } else if (p.stats && wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2];
+      } else if (STM == 1 && wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2];
     }
+  }
+  if (STM == 2) {                                        // block-uniform: flush the block's integer accumulators, then the ticket protocol
+    __syncthreads();
+    if (t_lds) {
+      const int nq4 = (Cs >> 2) * 4, tot = t_nsl * nq4;  // [local slice][quad][4]
+      for (int i = tid; i < tot; i += 256) {
+        const long long v = sAccT[i];
+        const int sl = i / nq4, r = i - sl * nq4;
+        if (v != 0 && t_s0 + sl < p.gt.S)
+          atomicAdd((gn_u64*)(p.gt.acc + ((int64_t)(t_s0 + sl) * p.gt.q_ld + p.gt.q_off + (cbase >> 2)) * 4 + r), (gn_u64)v);
+      }
+    }
+    gn_tail_arrive(p.gt, (unsigned*)sAccT, tid, 256, gridDim.x);
   }
 }
 
-template <int KS, int RF, int CC, int GNM>
+template <int KS, int RF, int CC, int GNM, int STM>
 static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
   constexpr int BR = 128 * RF, STAGE_B = KS * CC * 128;
   const int rowblocks = cdiv(p.M, BR), nch = p.Cout / CC;
@@ -1671,24 +1796,31 @@ static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
     }
   const int Cs = p.Cout / nsplit;
   constexpr size_t REC_B = RF == 1 ? 2 * 4 * (CC / 32) * 2 * 32 * sizeof(float) : 0;
-  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0) + REC_B;
-  const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4 + REC_B;
+  constexpr size_t TAIL_B = 8 + 2048 * sizeof(long long);
+  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0) + REC_B + (p.gt.acc ? TAIL_B : 0);
+  const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4 + REC_B + TAIL_B;
   if (lds > lds_max) return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): %d output channels per block", Cs);
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_strip_kernel<KS, RF, CC, GNM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_strip_kernel<KS, RF, CC, GNM, STM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv1x1_strip: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv1x1_strip_kernel<KS, RF, CC, GNM>), dim3(rowblocks * nsplit), dim3(256), lds, st, p, nsplit);
+  hipLaunchKernelGGL((conv1x1_strip_kernel<KS, RF, CC, GNM, STM>), dim3(rowblocks * nsplit), dim3(256), lds, st, p, nsplit);
   return mmd_check_launch("conv1x1_strip");
+}
+
+template <int KS, int RF, int CC, int STM>
+static int launch_conv1x1_strip_st(const ConvGemmParams& p, hipStream_t st) {
+  if (!p.gn_a) return launch_conv1x1_strip_mode<KS, RF, CC, 0, STM>(p, st);
+  return p.gn_act ? launch_conv1x1_strip_mode<KS, RF, CC, 2, STM>(p, st) : launch_conv1x1_strip_mode<KS, RF, CC, 1, STM>(p, st);
 }
 
 template <int KS, int RF, int CC>
 static int launch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
-  if (!p.gn_a) return launch_conv1x1_strip_mode<KS, RF, CC, 0>(p, st);
-  return p.gn_act ? launch_conv1x1_strip_mode<KS, RF, CC, 2>(p, st) : launch_conv1x1_strip_mode<KS, RF, CC, 1>(p, st);
+  if (p.gt.acc) return launch_conv1x1_strip_st<KS, RF, CC, 2>(p, st);
+  return p.stats ? launch_conv1x1_strip_st<KS, RF, CC, 1>(p, st) : launch_conv1x1_strip_st<KS, RF, CC, 0>(p, st);
 }
 
 // tile 131: bf16 convs whose whole K = ntaps * Cin is 128 / 256 (two row fragments per wave) or 384 / 512 (one fragment): the 1x1
@@ -1755,20 +1887,37 @@ static int launch_conv_gemm_halo16(const ConvGemmParams& p, hipStream_t st) {
   return mmd_check_launch("conv_gemm_halo16");
 }
 
+// descriptor addressing of the direct-to-LDS loops: 32-bit byte offsets into the activation view and the block's 128 weight rows;
+// MMD_GEMM_DESC=0 keeps the 64-bit pointer path (A/B)
+template <typename T>
+static bool glds_desc_ok(const ConvGemmParams& p) {
+  static const bool on = [] { const char* e = getenv("MMD_GEMM_DESC"); return !(e && e[0] == '0'); }();
+  constexpr int ES = 16 / Elt<T>::EPV;
+  int maxshift = 0;
+  for (int t = 0; t < p.ntaps; ++t) {
+    const int64_t sh = ((int64_t)p.taps[3 * t] * p.D1 * p.D2 + (int64_t)p.taps[3 * t + 1] * p.D2 + p.taps[3 * t + 2]) * p.lda * ES;
+    if (sh > 0x3fffffff || sh < -0x3fffffff) return false;
+    (void)maxshift;
+  }
+  return on && ((int64_t)p.M * p.lda + p.Cin) * ES < 0x7fffffffLL && (int64_t)128 * p.Cin * p.ntaps * ES < 0x7fffffffLL;
+}
+
 template <typename T>
 static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
   const size_t lds = 128 * 132 * sizeof(float) + 336;
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_glds: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  if (p.Cin % (8 * Elt<T>::EPV) == 0) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 2>), dim3(grid), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, false, 2>), dim3(grid), dim3(256), lds, st, p);
+  if (p.Cin % (8 * Elt<T>::EPV) != 0) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, false, 2, false>), dim3(grid), dim3(256), lds, st, p);
+  else if (glds_desc_ok<T>(p)) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 2, true>), dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 2, false>), dim3(grid), dim3(256), lds, st, p);
   return mmd_check_launch("conv_gemm_glds");
 }
 
@@ -1781,12 +1930,14 @@ static int launch_conv_gemm_ring(const ConvGemmParams& p, hipStream_t st) {
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_ring: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 4>), dim3(grid), dim3(256), lds, st, p);
+  if (glds_desc_ok<T>(p)) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 4, true>), dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 4, false>), dim3(grid), dim3(256), lds, st, p);
   return mmd_check_launch("conv_gemm_ring");
 }
 
@@ -1832,7 +1983,7 @@ static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st)
 static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                           void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
                           int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_S, int64_t gn_rows, float* stats,
-                          int64_t stats_ld, void* stream) {
+                          int64_t stats_ld, void* stream, const mmd_gn_tail* tail = nullptr) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_gemm: bad dtype %d", dtype);
   MMD_REQUIRE(A && W && Y && M > 0 && Cout > 0 && Cin > 0, "conv_gemm: null/empty argument");
@@ -1854,6 +2005,22 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   MMD_REQUIRE(!stats || (M % 64 == 0 && stats_ld >= Cout && tile != 130 && tile != 133 && (uintptr_t)stats % 8 == 0),
               "conv_gemm: output statistics need M %% 64 == 0, stats_ld >= Cout and a row-tiled main loop (not tiles 130 / 133)");
   p.stats = stats; p.stats_ld = stats_ld;
+  p.gt = mmd_gn_tail{};
+  if (tail && tail->acc) {
+    const mmd_gn_tail& g = *tail;
+    MMD_REQUIRE(!stats, "conv_gemm: records and the in-launch tail are alternatives");
+    MMD_REQUIRE(tile != 130 && tile != 133 && M % 64 == 0, "conv_gemm tail: needs M %% 64 == 0 and a row-tiled main loop (not tiles 130 / 133)");
+    MMD_REQUIRE(g.S > 0 && g.rows_per_slice > 0 && g.rows_per_slice % 64 == 0 && (int64_t)g.S * g.rows_per_slice == M,
+                "conv_gemm tail: S slices of rows_per_slice rows (a multiple of 64) must cover M (S=%d rows=%lld M=%d)", g.S, g.rows_per_slice, M);
+    MMD_REQUIRE(g.q_ld > 0 && g.q_off >= 0 && g.q_off + Cout / 4 <= g.q_ld && Cout % 4 == 0,
+                "conv_gemm tail: quads %d .. %d of %d per slice", g.q_off, g.q_off + Cout / 4, g.q_ld);
+    MMD_REQUIRE(!g.shared_counter || (g.C > 0 && g.C % 128 == 0 && g.C <= 2048 && g.fq0 >= 0 && g.fq0 + g.C / 4 <= g.q_ld),
+                "conv_gemm tail: consumer norm over %d channels (a multiple of 128: groups of whole quads) from quad %d", g.C, g.fq0);
+    MMD_REQUIRE(((uintptr_t)g.acc) % 8 == 0, "conv_gemm tail: accumulators must be 8-byte aligned");
+    MMD_REQUIRE(!g.shared_counter || (g.launch_counter && g.n_producers >= 1 && g.gamma && g.beta && g.a_out && g.b_out && g.eps > 0.f),
+                "conv_gemm tail: the finalising form needs both counters, n_producers, gamma / beta and the affine outputs");
+    p.gt = g;
+  }
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
@@ -1915,4 +2082,36 @@ extern "C" int mmd_gn_conv_gemm(int dtype, const void* A, int64_t lda, const flo
   MMD_REQUIRE(tile == 130 || tile == 133, "gn_conv_gemm: the fused input GroupNorm of a conv with taps exists on the halo tiles (130 / 133) only");
   return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, gn_a, gn_b, act, S,
                         rows_per_slice, nullptr, 0, stream);
+}
+
+// mmd_conv_gemm / mmd_gn_conv1x1 whose epilogue also leaves the statistics of Y in the consumer GroupNorm's integer accumulators and,
+// in the last block of the last producer launch, turns them into that norm's fused affine (include/mmd.h: mmd_gn_tail): neither a
+// statistics pass nor a finalize launch.  `tail` is a HOST pointer, read at call time.
+extern "C" int mmd_conv_gemm_tail(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
+                                  void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
+                                  int tile, const mmd_gn_tail* tail, void* stream) {
+  MMD_REQUIRE(tail, "conv_gemm_tail: null tail");
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 0,
+                        0, nullptr, 0, stream, tail);
+}
+
+extern "C" int mmd_gn_conv1x1_tail(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
+                                   int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y,
+                                   int64_t ldy, int M, int Cout, int Cin, int tile, const mmd_gn_tail* tail, void* stream) {
+  static const int tap0[3] = {0, 0, 0};
+  MMD_REQUIRE(gn_a && gn_b && tail, "gn_conv1x1_tail: null GroupNorm affine / tail");
+  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, S,
+                        rows_per_slice, nullptr, 0, stream, tail);
+}
+
+// The finalize step on its own (one block): the fused affine from accumulators that some launches filled without finalising
+// (tail.shared_counter == NULL there) - tests, and producers that cannot know they are the last.
+__global__ __launch_bounds__(256) void gn_tail_finalize_kernel(const mmd_gn_tail g) { gn_tail_finalize(g, threadIdx.x, 256); }
+
+extern "C" int mmd_gn_tail_finalize(const mmd_gn_tail* tail, void* stream) {
+  MMD_REQUIRE(tail && tail->acc && tail->gamma && tail->beta && tail->a_out && tail->b_out, "gn_tail_finalize: null pointer");
+  MMD_REQUIRE(tail->S > 0 && tail->C > 0 && tail->C % 128 == 0 && tail->rows_per_slice > 0 && tail->eps > 0.f && tail->fq0 >= 0 &&
+                  tail->fq0 + tail->C / 4 <= tail->q_ld, "gn_tail_finalize: bad geometry");
+  hipLaunchKernelGGL(gn_tail_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *tail);
+  return mmd_check_launch("gn_tail_finalize");
 }

@@ -70,6 +70,20 @@ class UNetEngine:
         mode = os.environ.get("MMD_GN_EPILOGUE", "1")
         self.rec_enabled = mode == "2" or (mode != "0" and dtype == torch.bfloat16)
         self._recs = {}
+        # Round 3: in-launch statistics + affine (include/mmd.h: mmd_gn_tail) instead of records + a finalize launch per norm: the
+        # producers add exact integer partial sums per (slice, quad of channels) into the buffer's accumulators and the last block of
+        # the last producer leaves the consumer norm's fused affine.  MMD_GN_TAIL=0 keeps the record path (A/B).
+        # MEASURED (round 3, profiles/r03_*): correct and bitwise order-free, but the device-scope 64-bit atomics cost ~75 ns per thousand
+        # (13 G/s chip-wide): a ds2 GEMM with 1024 tiles x 256 atomics pays +20 us, more than the finalize launch it saves.  So a buffer
+        # gets a tail only when rows x channels <= MMD_GN_TAIL_MAX (default 2^21: the ds8 level, ~32 k atomics ~ 2.5 us against 7 us + a
+        # launch boundary); larger buffers keep per-column records + the finalize launch.  MMD_GN_TAIL=0 / =all: never / always.
+        tmode = os.environ.get("MMD_GN_TAIL", "auto")
+        self.tail_enabled = self.rec_enabled and tmode != "0"
+        self.tail_max = (1 << 62) if tmode == "all" else int(os.environ.get("MMD_GN_TAIL_MAX", str(1 << 21)))
+        self._tails = {}              # buffer storage -> entry (slice geometry, accumulator offset, producer structs)
+        self._tail_structs = []       # every GnTail handed to a producer launch: (struct, entry)
+        self._tail_bytes = 0          # bump allocator of the per-forward-zeroed arena (accumulators + counters)
+        self._tail_static = []        # affine tables written by producers: never pooled (they are live from the producer launch on)
         H.reap()
         self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
         self.aux = self._aux.torch          # audio-chain launches
@@ -96,7 +110,13 @@ class UNetEngine:
         raw = pool.get(rows * C * es)
         t = raw[: rows * C * es].view(dtype).view(rows, C)
         t._raw, t._pool = raw, pool
-        if stats and self.rec_enabled and rows % 64 == 0 and unit % 64 == 0:
+        if stats and self.tail_enabled and rows * C <= self.tail_max and rows % unit == 0 and unit % 64 == 0 and C % 4 == 0:
+            S = rows // unit
+            off = self._tail_bytes
+            self._tail_bytes += S * (C // 4) * 4 * 8                     # [S][C / 4 quads][4] int64
+            self._tails[raw.untyped_storage().data_ptr()] = dict(ptr=t.data_ptr(), es=es, rows=rows, C=C, unit=unit, S=S, off=off,
+                                                                 producers=[], active=False)
+        elif stats and self.rec_enabled and rows % 64 == 0 and unit % 64 == 0:
             rec = self._alloc(rows // 64, 2 * C, torch.float32)
             self._recs[raw.untyped_storage().data_ptr()] = dict(rec=rec, view=rec.view(rows // 64, C, 2), ptr=t.data_ptr(), es=es,
                                                                 rows=rows, C=C, cover=[])
@@ -108,6 +128,7 @@ class UNetEngine:
                 ent = self._recs.pop(t._raw.untyped_storage().data_ptr(), None)
                 if ent is not None:
                     self._release(ent["rec"])
+                self._tails.pop(t._raw.untyped_storage().data_ptr(), None)      # (its structs stay valid: they point into the arena)
                 t._pool.put(t._raw)
                 del t._raw
 
@@ -127,6 +148,88 @@ class UNetEngine:
             return None
         ent["cover"].append((c0, c0 + out.shape[1]))
         return ent["view"][:, c0:c0 + out.shape[1], :]
+
+    # ------------------------------------------------------------------ in-launch statistics + affine (tails)
+    def _tail_slice(self, t):
+        ent = self._tails.get(t.untyped_storage().data_ptr())
+        if ent is None or t.stride(0) != ent["C"] or t.shape[0] != ent["rows"]:
+            return None, 0
+        c0 = (t.data_ptr() - ent["ptr"]) // ent["es"]
+        return (ent, c0) if 0 <= c0 and c0 + t.shape[1] <= ent["C"] else (None, 0)
+
+    def _has_stats(self, out):
+        return self._tail_slice(out)[0] is not None or self._rec_slice(out)[0] is not None
+
+    def _stats_kw(self, out):
+        """Keyword arguments for the GEMM that writes `out`: {"tail": struct} (filled in when the consumer norm is recorded; left
+        empty - a plain GEMM - when no norm claims it), {"stats": record view} on the record path, or {}."""
+        ent, c0 = self._tail_slice(out)
+        if ent is not None and c0 % 4 == 0 and out.shape[1] % 4 == 0:
+            st = H.GnTail()
+            ent["producers"].append((c0, c0 + out.shape[1], st))
+            self._tail_structs.append((st, ent))
+            st.q_ld, st.q_off, st.S, st.rows_per_slice = ent["C"] // 4, c0 // 4, ent["S"], ent["unit"]
+            return {"tail": st}
+        rec = self._stats_for(out)
+        return {} if rec is None else {"stats": rec}
+
+    def _tail_claim(self, x, geom, gamma, beta, film):
+        """The fused affine of a GroupNorm over x from its producers' tails: x's columns must be exactly covered by recorded producer
+        launches of a tail buffer with x's slice geometry.  The LAST of them (all producers of a buffer run on one stream, in plan
+        order) finalises; the affine tables are static buffers - they are written at the producer's launch, long before this point
+        of the plan.  None -> the caller runs the statistics pass."""
+        ent, c0 = self._tail_slice(x)
+        C = x.shape[1]
+        if (ent is None or geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn != ent["unit"]
+                or geom.S != ent["S"] or C % 128 or c0 % 4):
+            return None
+        inside = [pr for pr in ent["producers"] if pr[0] < c0 + C and pr[1] > c0]
+        if not inside or any(pr[0] < c0 or pr[1] > c0 + C for pr in inside):
+            return None
+        pos = c0
+        for lo, hi, _ in sorted(inside, key=lambda pr: pr[0]):
+            if lo > pos:
+                return None
+            pos = max(pos, hi)
+        if pos < c0 + C:
+            return None
+        st = inside[-1][2]                         # recorded last = runs last
+        if st.shared_counter:                      # that launch already finalises another norm
+            return None
+        a = torch.empty(geom.S, C, dtype=torch.float32, device=self.device)
+        b = torch.empty(geom.S, C, dtype=torch.float32, device=self.device)
+        self._tail_static += [a, b]
+        coff = self._tail_bytes
+        self._tail_bytes += 16                     # launch counter, shared counter (+ padding: the accumulators stay 8-byte aligned)
+        st._coff = coff
+        st.n_producers, st.C, st.fq0 = 1, C, c0 // 4
+        st.gamma, st.beta = gamma.data_ptr(), beta.data_ptr()
+        st.film, st.film_ld = (0 if film is None else film.data_ptr()), (0 if film is None else film.stride(0))
+        st.eps = ops.GN_EPS
+        st.a_out, st.b_out = a.data_ptr(), b.data_ptr()
+        st.shared_counter = 1                      # placeholder (non-null = "finalises"): the arena address is filled in by _tail_commit
+        ent["active"] = True
+        return a, b
+
+    def _tail_commit(self):
+        """After recording: allocate the arena, point every struct of an active buffer at its accumulators / counters (inactive
+        buffers keep acc = NULL: their producers run as plain GEMMs) and put the arena's reset in front of the plan."""
+        if not self._tail_structs:
+            return None
+        self._tail_arena = torch.zeros(max(self._tail_bytes, 16) // 8 + 2, dtype=torch.int64, device=self.device)
+        base = self._tail_arena.data_ptr()
+        for st, ent in self._tail_structs:
+            if ent["active"]:
+                st.acc = base + ent["off"]
+                if st.shared_counter:
+                    st.launch_counter, st.shared_counter = base + st._coff, base + st._coff + 4
+            else:
+                st.acc, st.shared_counter = None, None
+        head = []
+        with ops.recording(head):
+            ops.cur_sid = 0
+            ops.zero(self._tail_arena)
+        return head
 
     def _rec_ready(self, x, geom):
         """The record view a GroupNorm over x can finalize from: every column of x written by a statistics-emitting GEMM, contiguous
@@ -192,6 +295,10 @@ class UNetEngine:
         a = self._alloc(geom.S, C, torch.float32)
         b = self._alloc(geom.S, C, torch.float32)
         gamma, beta = self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias")
+        ab = self._tail_claim(x, geom, gamma, beta, film) if self.tail_enabled else None
+        if ab is not None:
+            self._release(a, b)
+            return ab
         rec = self._rec_ready(x, geom)
         if rec is not None:
             ops.gn_finalize_stats(rec, gamma, beta, geom, film=film, a=a, b=b)
@@ -205,7 +312,7 @@ class UNetEngine:
         """GroupNorm32(+FiLM)(+SiLU) -> 1x1 conv with the normalisation applied inside the GEMM loader."""
         C = x.shape[1]
         Cout = self.params[wkey].shape[0]
-        will_emit = True if (out is not None and self._rec_slice(out)[0] is not None) else None    # the launch below fills out's records
+        will_emit = True if (out is not None and self._has_stats(out)) else None    # the launch below emits out's statistics
         if not ops.gn_fusable(geom, C, Cout, x, will_emit, act):
             # wide outputs (qkv, deep levels) outside the row-strip kernel's shapes: every column tile would redo the normalisation
             # in its loader (measured 2x slower than materialising once), so normalise once and run the plain GEMM; likewise a strip
@@ -216,13 +323,13 @@ class UNetEngine:
             return y
         a, b = self._gn_affine(x, gn_prefix, geom, film)
         y = self._alloc(x.shape[0], Cout) if out is None else out
-        ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, stats=self._stats_for(y))
+        ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, **self._stats_kw(y))
         self._release(a, b)
         return y
 
     def _pw(self, x, wkey, bkey, residual=None, out=None):
         y = self._alloc(x.shape[0], self.params[wkey].shape[0]) if out is None else out
-        return ops.conv_gemm(x, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, stats=self._stats_for(y))
+        return ops.conv_gemm(x, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, **self._stats_kw(y))
 
     # ------------------------------------------------------------------ blocks
     def _self_attn(self, x, prefix, kind, Hh, out):
@@ -288,13 +395,13 @@ class UNetEngine:
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
                 ops.conv_gemm(t1, self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight"),
                               self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), **self._temporal(Hh),
-                              out=h, stats=self._stats_for(h))
+                              out=h, **self._stats_kw(h))
                 self._release(t1)
             else:
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
                 ops.conv_gemm(t0, self._gemm_w(f"{p}.audio_in_layers.2.audio_conv.weight"),
                               self._f32(f"{p}.audio_in_layers.2.audio_conv.bias"), taps=ops.taps_audio(layer["dilation"]),
-                              dims=(L, 1, 1), out=h, stats=self._stats_for(h))
+                              dims=(L, 1, 1), out=h, **self._stats_kw(h))
                 self._release(t0)
             xs = x
             if fh != 1:        # conv at the input resolution, THEN resample both h and x (unet:441-448)
@@ -426,6 +533,9 @@ class UNetEngine:
 
         # two plans that differ only in the timestep dtype read by the first kernel
         self.plan = record(self.t_i64)
+        head = self._tail_commit()
+        if head:
+            self.plan = head + self.plan
         self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name, meta, sid, tag) if name == "mmd_temb_fwd"
                          else (fn, args, name, meta, sid, tag) for fn, args, name, meta, sid, tag in self.plan]
 
@@ -477,7 +587,7 @@ class UNetEngine:
                     nv = tv if tv is not None else self._alloc(N * F * Hh * Hh, C0, stats=True, unit=F * Hh * Hh)
                     ops.conv_gemm(s1, self._gemm_w(p + ".video_conv.video_conv_temporal.weight"),
                                   self._f32(p + ".video_conv.video_conv_temporal.bias"), **self._temporal(Hh), out=nv,
-                                  stats=self._stats_for(nv))
+                                  **self._stats_kw(nv))
                     self._release(s1)
                     ops.cur_sid = 1
                     na = ta if ta is not None else self._alloc(N * L, C0)
