@@ -111,6 +111,12 @@ int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, con
                    int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                    int M, int Cout, int Cin, int tile, void* stream);
 
+/* GroupNorm32(+SiLU) of S SHORT slices (Tn <= 16 rows; geometry as mmd_gn_stats) in one launch and one read of the tensor: the
+ * temporal-attention norm over the frames of a pixel (unet:489-490 -> nn.py:16-33) = mmd_gn_stats + mmd_gn_apply.  Exact two-pass
+ * statistics on register-resident data; channel groups must be whole quads (C % 128 == 0). */
+int mmd_gn_small(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int S, int Tn, int inner, int64_t outer_stride,
+                 int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, float eps, int act, void* stream);
+
 /* In-launch GroupNorm statistics + affine ("tail", round 3) - what mmd_conv_gemm_tail / mmd_gn_conv1x1_tail add to a GEMM launch
  * whose output Y (a column range of a buffer that GroupNorm32s normalise next; nn.py:16-33) then needs neither a statistics pass
  * nor a finalize launch:

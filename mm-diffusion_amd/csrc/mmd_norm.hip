@@ -277,6 +277,105 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const char* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-pass GroupNorm32 (+SiLU) for SHORT slices (Tn <= 16 rows: the temporal-attention norm over the 16 frames of a pixel,
+// unet:489-490 -> nn.py:16-33): statistics pass + finalize + apply cost three launches and read the tensor twice; here a thread owns
+// ONE 16-byte channel vector of ONE slice for all of its rows (16 vectors in registers, packed), so the tensor is read once and the
+// statistics are exact two-pass ones (mean first, then sum (x - mean)^2 - the data never leaves the registers).  A group is cpg
+// channels x Tn rows: the thread folds its two QUADS of channels (every group size of the model is a multiple of 4), the quads go
+// through LDS, and each thread sums the quads of the (at most two) groups it needs - two barriers per block, no atomics.
+// Block = SPB slices x C / EPV vectors (<= 256 threads).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_small_kernel(const char* __restrict__ x, int64_t ldx, char* __restrict__ y, int64_t ldy, int C,
+                                                       SliceGeom g, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int act, int SPB) {
+  constexpr int EPV = Elt<T>::EPV, ES = 16 / EPV, MAXT = 16, QPV = EPV / 4;   // quads per vector: 2 (bf16) / 1 (fp32)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sQ = (float*)smem;                       // [SPB][C / 4] quad partials (pass 1: sums, pass 2: centred sums of squares)
+  const int CV = C / EPV, NQ = C / 4, cpg = C / GN_GROUPS, qpg = cpg / 4;
+  const int tid = threadIdx.x, pl = tid / CV, cv = tid - pl * CV;
+  const int s = blockIdx.x * SPB + pl;
+  const bool live = pl < SPB && s < g.S;
+  u32x4 v[MAXT];
+  const int64_t base = live ? slice_base(g, s) : 0;
+  const char* xp = x + (base * ldx + (int64_t)cv * EPV) * ES;
+  const int64_t xs = g.tstride * ldx * ES;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+    if (live && j < g.Tn) v[j] = *(const u32x4*)(xp + (int64_t)j * xs);
+  float q[2] = {0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (j < g.Tn) {
+        float f[EPV];
+        Elt<T>::unpack(v[j], f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) q[e / 4] += f[e];
+      }
+#pragma unroll
+    for (int h = 0; h < QPV; ++h) sQ[pl * NQ + cv * QPV + h] = q[h];
+  }
+  __syncthreads();
+  // the groups of this thread's quads: quad k belongs to group k / qpg; a vector touches at most two groups
+  const float inv_cnt = 1.f / ((float)cpg * (float)g.Tn);
+  float mean[2] = {0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int h = 0; h < QPV; ++h) {
+      const int gi = (cv * QPV + h) / qpg;
+      float a = 0.f;
+      for (int k = 0; k < qpg; ++k) a += sQ[pl * NQ + gi * qpg + k];
+      mean[h] = a * inv_cnt;
+    }
+  }
+  __syncthreads();
+  if (live) {
+    q[0] = q[1] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (j < g.Tn) {
+        float f[EPV];
+        Elt<T>::unpack(v[j], f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { const float d = f[e] - mean[e / 4]; q[e / 4] += d * d; }
+      }
+#pragma unroll
+    for (int h = 0; h < QPV; ++h) sQ[pl * NQ + cv * QPV + h] = q[h];
+  }
+  __syncthreads();
+  if (live) {
+    float av[EPV], bv[EPV];
+#pragma unroll
+    for (int h = 0; h < QPV; ++h) {
+      const int gi = (cv * QPV + h) / qpg;
+      float a = 0.f;
+      for (int k = 0; k < qpg; ++k) a += sQ[pl * NQ + gi * qpg + k];
+      const float rstd = rsqrtf(a * inv_cnt + eps);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = cv * EPV + h * 4 + e;
+        av[h * 4 + e] = rstd * gamma[c];
+        bv[h * 4 + e] = beta[c] - mean[h] * av[h * 4 + e];
+      }
+    }
+    char* yp = y + (base * ldy + (int64_t)cv * EPV) * ES;
+    const int64_t ys = g.tstride * ldy * ES;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (j < g.Tn) {
+        float f[EPV];
+        Elt<T>::unpack(v[j], f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const float w = f[e] * av[e] + bv[e];
+          f[e] = act ? silu_f(w) : w;
+        }
+        *(u32x4*)(yp + (int64_t)j * ys) = Elt<T>::pack(f);
+      }
+  }
+}
+
 // x[m, c] += e[n(m), c]   (non-FiLM ResBlock: h + emb_out, multimodal_unet.py:473-477)
 template <typename T>
 __global__ __launch_bounds__(256) void add_rowbias_kernel(char* __restrict__ x, int64_t ld, int64_t rows, int C,
@@ -470,3 +569,26 @@ extern "C" int mmd_add_rowbias(int dtype, void* x, int64_t ld, int64_t rows, int
     hipLaunchKernelGGL(add_rowbias_kernel<float>, dim3(grid), dim3(256), 0, st, (char*)x, ld, rows, C, rows_per_sample, e, e_ld);
   return mmd_check_launch("add_rowbias");
 }
+
+// GroupNorm32(+SiLU) of S short slices (Tn <= 16 rows each; geometry as mmd_gn_stats) in ONE launch: y = act(GN(x) gamma + beta).
+extern "C" int mmd_gn_small(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int S, int Tn, int inner,
+                            int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta,
+                            float eps, int act, void* stream) {
+  int rc = check_geom("gn_small", dtype, C, S, Tn, inner);
+  if (rc) return rc;
+  MMD_REQUIRE(x && y && gamma && beta, "gn_small: null pointer");
+  MMD_REQUIRE(Tn <= 16 && (C / GN_GROUPS) % 4 == 0, "gn_small: slices of at most 16 rows, groups of whole channel quads (got Tn=%d C=%d)", Tn, C);
+  SliceGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};
+  const int cv = C / (dtype == MMD_BF16 ? 8 : 4);
+  MMD_REQUIRE(cv <= 256, "gn_small: %d channels is too wide", C);
+  const int spb = 256 / cv;
+  const size_t lds = (size_t)spb * (C / 4) * sizeof(float);
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL((gn_small_kernel<__bf16>), dim3(cdiv(S, spb)), dim3(256), lds, (hipStream_t)stream, (const char*)x, ldx, (char*)y, ldy, C, g,
+                       gamma, beta, eps, act, spb);
+  else
+    hipLaunchKernelGGL((gn_small_kernel<float>), dim3(cdiv(S, spb)), dim3(256), lds, (hipStream_t)stream, (const char*)x, ldx, (char*)y, ldy, C, g,
+                       gamma, beta, eps, act, spb);
+  return mmd_check_launch("gn_small");
+}
+

@@ -79,6 +79,7 @@ class UNetEngine:
         # launch boundary); larger buffers keep per-column records + the finalize launch.  MMD_GN_TAIL=0 / =all: never / always.
         tmode = os.environ.get("MMD_GN_TAIL", "auto")
         self.tail_enabled = self.rec_enabled and tmode != "0"
+        self._gn_small = os.environ.get("MMD_GN_SMALL", "1") != "0"
         self.tail_max = (1 << 62) if tmode == "all" else int(os.environ.get("MMD_GN_TAIL_MAX", str(1 << 21)))
         self._tails = {}              # buffer storage -> entry (slice geometry, accumulator offset, producer structs)
         self._tail_structs = []       # every GnTail handed to a producer launch: (struct, entry)
@@ -282,6 +283,10 @@ class UNetEngine:
     def _gn(self, x, prefix, geom, act, film=None, out=None):
         """GroupNorm32(+FiLM)(+SiLU): stats -> fused affine -> apply.  Returns the normalised tensor."""
         C = x.shape[1]
+        if film is None and self._gn_small and ops.gn_small_ok(x, geom):
+            # short slices (the temporal-attention norm: 16 frames of a pixel): one launch, one read of the tensor
+            y = self._alloc(x.shape[0], C) if out is None else out
+            return ops.gn_small(x, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), geom, act=act, out=y)
         a, b = self._gn_affine(x, prefix, geom, film)
         y = self._alloc(x.shape[0], C) if out is None else out
         ops.gn_apply(x, a, b, geom, act=act, out=y)

@@ -168,6 +168,20 @@ def gn_tail_finalize(tail):
     _dispatch("mmd_gn_tail_finalize", ctypes.pointer(tail), meta=("gn_tail_finalize", 0, tail.S * tail.C * 8))
 
 
+def gn_small_ok(x, geom: Geom):
+    return geom.Tn <= 16 and x.shape[1] % 128 == 0 and x.shape[1] // (8 if x.element_size() == 2 else 4) <= 256
+
+
+def gn_small(x, gamma, beta, geom: Geom, act=False, out=None):
+    """One-launch GroupNorm32(+SiLU) for short slices (include/mmd.h: mmd_gn_small) = gn_stats + gn_apply."""
+    _chk2d(x)
+    out = alloc(x.shape, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    _dispatch("mmd_gn_small", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], *geom.args(), gamma.data_ptr(),
+              beta.data_ptr(), GN_EPS, 1 if act else 0, meta=(f"gn_small[S={geom.S},Tn={geom.Tn},C={x.shape[1]}]", 0, 2 * x.shape[0] * x.shape[1] * x.element_size()))
+    return out
+
+
 def add_rowbias(x, e, rows_per_sample):
     _chk2d(x)
     _dispatch("mmd_add_rowbias", H.dt_of(x), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], rows_per_sample,
@@ -241,14 +255,17 @@ def _pick_tile(key, launch, M, Cout, candidates=(64, 128, 129), out=None, scratc
             elif not torch.equal(out.view(torch.int16 if out.element_size() == 2 else torch.int32),
                                  ref.view(torch.int16 if ref.element_size() == 2 else torch.int32)):
                 raise H.MMDError(f"GEMM tile {tile} is not bitwise equal to tile {candidates[0]} on {key}")
-        H.call("mmd_event_record", ev[0], st)
-        for _ in range(3):
-            launch(tile)
-        H.call("mmd_event_record", ev[1], st)
-        ms = ctypes.c_float()
-        H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
-        if best_ms is None or ms.value < best_ms:
-            best, best_ms = tile, ms.value
+        t_min = None
+        for _ in range(2):               # the better of two rounds of five launches: three launches once picked a 30 % slower tile
+            H.call("mmd_event_record", ev[0], st)
+            for _ in range(5):
+                launch(tile)
+            H.call("mmd_event_record", ev[1], st)
+            ms = ctypes.c_float()
+            H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
+            t_min = ms.value if t_min is None else min(t_min, ms.value)
+        if best_ms is None or t_min < best_ms:
+            best, best_ms = tile, t_min
     for e in ev:
         H.lib().mmd_event_destroy(e)
     for t, keep in saved:

@@ -276,3 +276,26 @@ def test_engine_tails_match_the_record_path(monkeypatch):
         outs[mode] = res[0]
         model.release_engines()
     assert rel_l2(outs["all"][0].cpu(), outs["0"][0].cpu().numpy()) < 3e-2 and rel_l2(outs["all"][1].cpu(), outs["0"][1].cpu().numpy()) < 3e-2
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("N,F,HW,C", [(2, 16, 64, 256), (1, 16, 37, 384), (2, 8, 16, 128), (1, 16, 20, 512), (1, 5, 9, 1024)])
+def test_gn_small_is_stats_plus_apply(ops, dt, act, N, F, HW, C):
+    """mmd_gn_small (one pass, register-resident two-pass statistics) on temporal slices (the frames of a pixel, strided rows) against
+    torch's group_norm on the same values, and against gn_stats + gn_apply; ragged slice counts, every group size (4 ... 32 channels)."""
+    g = torch.Generator(device="cuda").manual_seed(C + HW)
+    x = (torch.randn(N * F * HW, C, device="cuda", generator=g) * 2 + 0.7).to(dt)
+    gamma, beta = 1 + 0.3 * torch.randn(C, device="cuda", generator=g), 0.3 * torch.randn(C, device="cuda", generator=g)
+    geom = ops.Geom.temporal(N, F, HW)
+    assert ops.gn_small_ok(x, geom)
+    y = ops.gn_small(x, gamma, beta, geom, act=act)
+    a, b = ops.gn_stats(x, gamma, beta, geom)
+    y2 = ops.gn_apply(x, a, b, geom, act=act)
+    xt = x.float().reshape(N, F, HW, C).permute(0, 2, 3, 1).reshape(N * HW, C, F)         # slices (n, pixel): [C, F]
+    ref = F_.group_norm(xt, 32, gamma, beta, eps=1e-5)
+    ref = F_.silu(ref) if act else ref
+    ref = ref.reshape(N, HW, C, F).permute(0, 3, 1, 2).reshape(N * F * HW, C)
+    tol = 2e-5 if dt == torch.float32 else 1e-2
+    assert rel_l2(y.float().cpu(), ref.cpu().numpy()) < tol
+    assert rel_l2(y.float().cpu(), y2.float().cpu().numpy()) < tol
