@@ -73,11 +73,12 @@ class UNetEngine:
         # Round 3: in-launch statistics + affine (include/mmd.h: mmd_gn_tail) instead of records + a finalize launch per norm: the
         # producers add exact integer partial sums per (slice, quad of channels) into the buffer's accumulators and the last block of
         # the last producer leaves the consumer norm's fused affine.  MMD_GN_TAIL=0 keeps the record path (A/B).
-        # MEASURED (round 3, profiles/r03_*): correct and bitwise order-free, but the device-scope 64-bit atomics cost ~75 ns per thousand
-        # (13 G/s chip-wide): a ds2 GEMM with 1024 tiles x 256 atomics pays +20 us, more than the finalize launch it saves.  So a buffer
-        # gets a tail only when rows x channels <= MMD_GN_TAIL_MAX (default 2^21: the ds8 level, ~32 k atomics ~ 2.5 us against 7 us + a
-        # launch boundary); larger buffers keep per-column records + the finalize launch.  MMD_GN_TAIL=0 / =all: never / always.
-        tmode = os.environ.get("MMD_GN_TAIL", "auto")
+        # MEASURED (round 3, gpurun c7 / c8): correct and bitwise order-free, but SLOWER than records + finalize launches - the
+        # device-scope 64-bit atomics run at ~13 G/s chip-wide (a ds2 GEMM with 1024 tiles x 256 atomics pays +20 us) and even on the
+        # small ds8 launches the drain + ticket round trip + last-block finalize costs what the 7 us finalize launch cost: 14.7 ms per
+        # step with tails everywhere, 13.6 with tails on buffers of <= 2^21 elements, 12.8 without.  So the default is OFF (records);
+        # MMD_GN_TAIL=all / =auto (buffers of <= MMD_GN_TAIL_MAX elements) switch the experiment on.
+        tmode = os.environ.get("MMD_GN_TAIL", "0")
         self.tail_enabled = self.rec_enabled and tmode != "0"
         self._gn_small = os.environ.get("MMD_GN_SMALL", "1") != "0"
         self.tail_max = (1 << 62) if tmode == "all" else int(os.environ.get("MMD_GN_TAIL_MAX", str(1 << 21)))
