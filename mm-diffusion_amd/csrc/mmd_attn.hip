@@ -353,6 +353,229 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
   }
 }
 
+// ============================================================================= DMA-staged MFMA attention (bf16, head width 64; round 3)
+// attn_mfma_kernel above issues ~360 instructions per 64-key tile and wave for its 16 MFMAs: ~110 of them stage K / V (per-lane 64-bit
+// addresses, bounds branches, register round trip, eight 2-byte transposing LDS writes per lane), 32 re-zero the score accumulators, and
+// a tile costs two barriers.  The tiled GEMMs turned out to be bound by exactly this kind of issue overhead (tile 133); the same
+// diet here:
+//   * K and V tiles go global -> LDS by buffer_load ... lds through ONE descriptor: a lane-constant 32-bit offset per 8-row group
+//     (circular window row, bounds -> an out-of-range offset, which lands zeros), no register staging, no ds_write at all;
+//   * V stays ROW-MAJOR in LDS ([key][d], 16-byte chunks XOR-swizzled with bit 1 of the key so the four key rows of a transposing
+//     read fall on different bank quarters) and the V^T fragments of O^T += V^T P^T come out of ds_read_b64_tr_b16: lane i of a
+//     16-lane group supplies the 8 bytes V[key0 + i / 4][d0 + 4 (i % 4) ..] and receives V[key0 .. key0 + 3][d0 + i];
+//   * K row-major with the GEMMs' swizzle (chunk ^ (row >> 1) & 7), fragments by ds_read_b128;
+//   * the first S^T MFMA of a tile takes a zero accumulator operand instead of 32 v_mov;
+//   * tile t + 1 is in flight while tile t is consumed: one raw s_barrier per tile behind a counted s_waitcnt.
+// Same arithmetic as attn_mfma_kernel (S^T = K Q^T in the log2 domain, lane-local online softmax, P as the B operand straight from the
+// S^T registers): bitwise the same output.
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
+  static_assert(D == 64, "DMA-staged attention: head width 64 (one 128-byte LDS row per key)");
+  constexpr int KST = D / 16, DT = D / 32, TILE_B = 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                     // [2 stages][64 keys][128 B]
+  char* sV = smem + 2 * TILE_B;        // [2 stages][64 keys][128 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int qt, h, bg;
+  attn_block_coords(qt, h, bg);
+  const GroupInfo gi = group_info(p, bg);
+  const int q0 = qt * 128;
+  if (q0 >= gi.q_count) return;        // uniform per block
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l31, half) holds d = 16 s + 8 half + [0, 8)
+  const int qi = q0 + wave * 32 + l31;
+  const bool qok = qi < gi.q_count;
+  u32x4 qf[KST];
+  {
+    const char* qp = p.Q + ((gi.q_row0 + qi) * p.ldq + p.q_off + h * D) * 2;
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qok) v = *(const u32x4*)(qp + (s * 16 + half * 8) * 2);
+      qf[s] = v;
+    }
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
+
+  // ---- DMA: wave w stages row groups {w, w + 4} of K and of V; lane L of a group covers row 8 g + L / 8, physical chunk L % 8
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.KV, 0, (int)((int64_t)p.nb * p.k_rows_per_batch * p.ldkv * 2), 0x00020000);
+  const int lrow = lane >> 3, pc = lane & 7;
+  int row_in_tile[2];
+  uint32_t kcol[2], vcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + 4 * i) + lrow;
+    row_in_tile[i] = row;
+    kcol[i] = (uint32_t)((p.k_off + h * D) * 2 + ((pc ^ ((row >> 1) & 7)) * 16));
+    vcol[i] = (uint32_t)((p.v_off + h * D) * 2 + ((pc ^ (((row >> 1) & 1) << 2)) * 16));
+  }
+  const uint32_t ldb = (uint32_t)(p.ldkv * 2);
+  auto issue = [&](int stage, int kt0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = kt0 + row_in_tile[i];
+      int r = gi.k_start + kk;
+      r = r >= gi.k_mod ? r - gi.k_mod : r;
+      const uint32_t rowoff = (uint32_t)(gi.k_row0 + r) * ldb;
+      const bool ok = kk < gi.k_count;
+      const uint32_t ko = ok ? rowoff + kcol[i] : 0xfffffff0u, vo = ok ? rowoff + vcol[i] : 0xfffffff0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(sK + stage * TILE_B + (wave + 4 * i) * 1024), 16, ko, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(sV + stage * TILE_B + (wave + 4 * i) * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  // fragment addresses.  K: row 32 kt + l31, logical chunk 2 st + half.  V^T by transposing reads: group (kt, st, u) of 4 keys
+  // key0 = 32 kt + 16 st + 8 u + 4 half; this lane supplies row key0 + (lane & 15) / 4, columns dt * 32 + 16 ((lane >> 4) & 1) + 4 (lane & 3)
+  const int kx = (l31 >> 1) & 7;
+  const char* kbase = sK + l31 * 128;
+  const int vrow0 = 4 * half + ((lane & 15) >> 2);                   // + 32 kt + 16 st + 8 u  (bit 1 of the row = bit 1 of vrow0's low part)
+  const int vcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;   // byte column inside a 64-byte d tile: chunk = vcolb / 16 + 4 dt
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4* lp4;
+
+  const int ntiles = (gi.k_count + 63) >> 6;
+  issue(0, 0);
+  auto tile_body = [&](int t, auto ragged) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this tile's DMA (the only one in flight) has landed
+    __builtin_amdgcn_s_barrier();                                    // ... for every wave; everyone is past the other stage's reads
+    asm volatile("" ::: "memory");
+    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64);            // in flight during this tile's MFMAs
+    const char* kb = kbase + (t & 1) * TILE_B;
+    const char* vb = sV + (t & 1) * TILE_B;
+    // ---- S^T = K Q^T : two 32-key sub-tiles, the first k-step on a zero accumulator
+    f32x16 s[2];
+    u32x4 kf[KST][2];
+#pragma unroll
+    for (int st = 0; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) kf[st][kt] = *(const u32x4*)(kb + kt * 32 * 128 + (((2 * st + half) ^ kx) * 16));
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0][kt]), __builtin_bit_cast(bf16x8, qf[0]), z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int st = 1; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[st][kt]), __builtin_bit_cast(bf16x8, qf[st]), s[kt], 0, 0, 0);
+    // ---- V^T fragments of this tile, requested under the softmax
+    bf16x8 vf[2][2][DT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          s16x4 lo, hi;
+          {
+            const int row = 32 * kt + 16 * st + vrow0;
+            const int ch = ((vcolb >> 4) + 4 * dt) ^ (((row >> 1) & 1) << 2);
+            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(vb + row * 128 + ch * 16 + (vcolb & 15)));
+          }
+          {
+            const int row = 32 * kt + 16 * st + 8 + vrow0;
+            const int ch = ((vcolb >> 4) + 4 * dt) ^ (((row >> 1) & 1) << 2);
+            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(vb + row * 128 + ch * 16 + (vcolb & 15)));
+          }
+          const s16x4 l2 = lo, h2 = hi;
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 both = {l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
+          vf[kt][st][dt] = __builtin_bit_cast(bf16x8, both);
+        }
+    // ---- online softmax (lane-local row; partner lane ^ 32 holds the other 32 keys)
+    if constexpr (decltype(ragged)::value) {
+      const int kbase2 = t * 64 + 4 * half;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = kbase2 + 32 * kt + (r & 3) + 8 * (r >> 2);
+          s[kt][r] = kk < gi.k_count ? s[kt][r] : -3e38f;
+        }
+    }
+    float mx = -3e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * sc);        // sc > 0: max commutes with the scale
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
+        s[kt][r] = e;
+        ps += e;
+      }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    if (__any(m_new != m_run)) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    m_run = m_new;
+    // ---- O^T += V^T P^T : P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * st + j];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][st][dt], pf, o[dt], 0, 0, 0);
+      }
+  };
+  const int nfull = gi.k_count >> 6;
+  for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+  if (nfull < ntiles) tile_body(nfull, std::true_type{});
+  // ---- normalise, transpose through LDS (stage 0 of K / V: free after the last tile) and store whole 128-byte head rows
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    constexpr int SO = D * 2 + 16;           // padded row of the transposed tile
+    const float inv = 1.f / l_run;
+    if (p.lse2 && half == 0 && qok) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);
+    char* so = smem + (wave * 32) * SO;      // this wave's 32 rows; written and read by this wave only (4 x 4.6 KB < 32 KB)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * half;
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[dt][4 * q4 + e] * inv);
+        *(bf16x4*)(so + l31 * SO + d * 2) = w;
+      }
+    const int tq = q0 + wave * 32;
+#pragma unroll
+    for (int ps2 = 0; ps2 < 32 * (D / 8) / 64; ++ps2) {
+      const int idx = ps2 * 64 + lane;
+      const int row = idx / (D / 8), v = idx % (D / 8);
+      if (tq + row < gi.q_count) {
+        const u32x4 x = *(const u32x4*)(so + row * SO + v * 16);
+        *(u32x4*)(p.O + ((gi.q_row0 + tq + row) * p.ldo + h * D + v * 8) * 2) = x;
+      }
+    }
+  }
+}
+
 // ============================================================================= staged-window MFMA attention (bf16)
 // For the long windows of the ds-2 level (spatial self-attention 1024 x 1024, RS cross-attention 1024 x 400 / 400 x 1024: ~80 % of
 // the attention FLOPs of a step).  attn_mfma_kernel above re-stages K/V for every 128 queries, pays two barriers per 64 keys with
@@ -986,6 +1209,14 @@ static int launch_mfma(const AttnParams& p, int qmax, hipStream_t st) {
 }
 
 template <int D>
+static int launch_dma(const AttnParams& p, int qmax, hipStream_t st) {
+  const size_t lds = 4 * 64 * 128;
+  dim3 grid(cdiv(qmax, 128), p.heads, p.nb * p.G);
+  hipLaunchKernelGGL(attn_dma_kernel<D>, grid, dim3(256), lds, st, p);
+  return mmd_check_launch("attn_dma");
+}
+
+template <int D>
 static int launch_stage(const AttnParams& p, int qmax, hipStream_t st) {
   const size_t lds = (size_t)ATS_KEYS * (D * 2 + 16) + (size_t)D * ATS_VT_STRIDE;
   static bool attr_done[MMD_MAX_DEVICES] = {};
@@ -1040,6 +1271,11 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   const int k_count = win * k_per_group;
   // the staged kernel stores O as whole 16-byte vectors (the per-128-query kernel: 8-byte pieces): stricter output alignment
   const bool stage_ok = dtype == MMD_BF16 && aligned && ch == 64 && ldo % 8 == 0 && (uintptr_t)O % 16 == 0;
+  // DMA-staged kernel (impl 4; the default at head width 64 unless MMD_ATTN_DMA=0): 32-bit byte offsets into the K/V rows
+  static const bool dma_on = [] { const char* e = getenv("MMD_ATTN_DMA"); return !(e && e[0] == '0'); }();
+  const bool dma_ok = stage_ok && (int64_t)nb * k_rows_per_batch * ldkv * 2 < 0x7fffffffLL;
+  if (impl == 4 && !dma_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 4 (DMA-staged): needs bf16, head width 64, aligned rows, K/V below 2 GB");
+  if (dma_ok && (impl == 4 || (impl == 0 && dma_on))) return launch_dma<64>(p, qmax, st);
   if (impl == 3 && !stage_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 3 (staged window): needs bf16, head width 64, aligned rows");
   // auto rule from tools/attn_bench.py on MI355X (batch 4): the staged kernel wins where a group has FEW queries per staged key
   // (audio <- video at ds2: 400 queries x 1024 keys, 63 us vs 74 us) and loses a few percent where the per-128-query kernel's three

@@ -299,3 +299,27 @@ def test_gn_small_is_stats_plus_apply(ops, dt, act, N, F, HW, C):
     tol = 2e-5 if dt == torch.float32 else 1e-2
     assert rel_l2(y.float().cpu(), ref.cpu().numpy()) < tol
     assert rel_l2(y.float().cpu(), y2.float().cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("name,N,F,qr,qg,kr,kg,win,heads", [
+    ("spatial 1024", 2, 4, 4 * 1024, 1024, 4 * 1024, 1024, 1, 4), ("v<-a", 2, 16, 16 * 256, 256, 1600, 100, 1, 4),
+    ("a<-v window 4", 1, 16, 1600, 100, 16 * 256, 256, 4, 6), ("ragged keys / queries", 2, 8, 8 * 77, 77, 8 * 50, 50, 3, 2),
+    ("last group takes the remainder", 1, 16, 1610, 100, 16 * 64, 64, 8, 2), ("one short tile", 1, 16, 16 * 64, 64, 16 * 25, 25, 1, 8)])
+def test_attn_dma_kernel_is_bitwise_the_mfma_kernel(ops, name, N, F, qr, qg, kr, kg, win, heads):
+    """mmd_attn_fwd impl 4 (K / V tiles by buffer_load ... lds, V^T fragments by transposing LDS reads, one barrier per tile) against
+    impl 2 (register-staged, transposing 2-byte LDS writes): same arithmetic in the same order -> bitwise equal; circular windows with
+    a shift, key counts that are not multiples of 64 (zero-filled DMA rows + masking), ragged query tiles, the last group's
+    remainder.  (impl 2 is the kernel test_ops_gpu.py pins against the oracle's attention.)"""
+    ch = 64
+    C = heads * ch
+    g = torch.Generator(device="cuda").manual_seed(qr + kr)
+    q = torch.randn(N * qr, 3 * C, device="cuda", generator=g).to(BF)
+    kv = torch.randn(N * kr, 3 * C, device="cuda", generator=g).to(BF)
+    for shift in (0, 5):
+        sh = torch.tensor([shift], dtype=torch.int32, device="cuda")
+        o2 = torch.zeros(N * qr, C, device="cuda", dtype=BF)
+        o4 = torch.full((N * qr, C), 7.0, device="cuda", dtype=BF)
+        ops.attn(q, kv, o2, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=2)
+        ops.attn(q, kv, o4, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=4)
+        torch.cuda.synchronize()
+        assert torch.equal(o2, o4), f"{name} shift {shift}: rel-L2 {rel_l2(o4.float().cpu(), o2.float().cpu().numpy()):.3e}"

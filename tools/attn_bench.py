@@ -39,8 +39,8 @@ def main():
         flops = 4.0 * N * qr * win * kg * C
         line = f"{name:22s} ({flops/1e9:5.1f} GF)"
         ref = None
-        for impl in impls:             # 2 = per-128-query MFMA kernel, 3 = staged-window kernel (head width 64 only)
-            if impl == 3 and ch != 64:
+        for impl in impls:             # 2 = per-128-query MFMA kernel, 3 = staged-window kernel, 4 = DMA-staged kernel (head width 64 only)
+            if impl in (3, 4) and ch != 64:
                 continue
             out = torch.zeros(N * qr, C, device="cuda", dtype=dt)
             for _ in range(2):
