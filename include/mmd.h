@@ -69,7 +69,8 @@ int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, int Tn, int
                  int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, const float* film,
                  int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out, void* workspace, void* stream);
 /* The same fused affine from PRODUCER-side statistics: the GEMM that wrote x (mmd_conv_gemm_stats / mmd_gn_conv1x1_stats) left per
- * (64-row record, channel) float2 (sum, sum of squares) in rec[(row / 64) * rec_ld + c]; S contiguous slices of Tn rows, Tn % 64 == 0.
+ * (64-row record, QUAD of 4 channels) float2 (sum, sum of squares) in rec[(row / 64) * rec_ld + quad]; rec points at the first quad of
+ * the C normalised channels (C % 128 == 0: groups of whole quads); S contiguous slices of Tn rows, Tn % 64 == 0.
  * Replaces the statistics pass over x of GroupNorm32 (nn.py:16-33) for conv-fed norms. */
 int mmd_gn_finalize_stats(const float* rec, int64_t rec_ld, int C, int S, int Tn, const float* gamma, const float* beta,
                           const float* film, int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out, void* stream);
@@ -164,8 +165,10 @@ int mmd_zero(void* ptr, int64_t bytes, void* stream);
 
 /* The two GEMMs above with the GroupNorm statistics of their OUTPUT produced in the epilogue, for the norm that consumes Y next
  * (ResBlock in_layers / out_layers norms, attention norms, the heads: unet:339-340,374-375; nn.py:16-33): per (64-row record,
- * column) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + column] = float2.  `stats` points at
- * the first column this launch writes (producers of a channel-concatenated tensor fill column slices of one record buffer).
+ * QUAD of 4 consecutive columns) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + quad] =
+ * float2 (per column until round 3: every group size of the model is a multiple of 4 and the per-quad fold costs the producers a
+ * third of the instructions).  `stats` points at the first quad this launch writes (producers of a channel-concatenated tensor
+ * fill column slices of one record buffer); Cout % 4 == 0.
  * M % 64 == 0; not with tile 130; tile 131 emits them for every K it accepts (K = 128 / 256: a wave owns whole 64-row records;
  * K = 384 / 512: two waves' half-records are paired through LDS).  The order in which a record's 64 rows are folded belongs
  * to the kernel family (tiles 128 / 129 share one, 131 has its own): a layer must be given the same family at every batch size

@@ -368,8 +368,11 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
 //   * tile t + 1 is in flight while tile t is consumed: one raw s_barrier per tile behind a counted s_waitcnt.
 // Same arithmetic as attn_mfma_kernel (S^T = K Q^T in the log2 domain, lane-local online softmax, P as the B operand straight from the
 // S^T registers): bitwise the same output.
+#ifndef ATTN_DMA_WAVES
+#define ATTN_DMA_WAVES 2
+#endif
 template <int D>
-__global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const AttnParams p) {
   static_assert(D == 64, "DMA-staged attention: head width 64 (one 128-byte LDS row per key)");
   constexpr int KST = D / 16, DT = D / 32, TILE_B = 64 * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -444,15 +447,19 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
 
   const int ntiles = (gi.k_count + 63) >> 6;
   issue(0, 0);
-  auto tile_body = [&](int t, auto ragged) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this tile's DMA (the only one in flight) has landed
-    __builtin_amdgcn_s_barrier();                                    // ... for every wave; everyone is past the other stage's reads
-    asm volatile("" ::: "memory");
-    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64);            // in flight during this tile's MFMAs
-    const char* kb = kbase + (t & 1) * TILE_B;
-    const char* vb = sV + (t & 1) * TILE_B;
-    // ---- S^T = K Q^T : two 32-key sub-tiles, the first k-step on a zero accumulator
-    f32x16 s[2];
+  // S^T = K Q^T of the tile in `stage`: two 32-key sub-tiles, the first k-step on a zero accumulator
+  auto compute_s = [&](int stage, f32x16 (&s)[2]) {
+    const char* kb = kbase + stage * TILE_B;
+#ifdef ATTN_DMA_LEAN          // fragments read where they are consumed (4 waves per SIMD: 128 registers)
+#pragma unroll
+    for (int st = 0; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const u32x4 kf1 = *(const u32x4*)(kb + kt * 32 * 128 + (((2 * st + half) ^ kx) * 16));
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf1), __builtin_bit_cast(bf16x8, qf[st]), st == 0 ? z : s[kt], 0, 0, 0);
+      }
+#else
     u32x4 kf[KST][2];
 #pragma unroll
     for (int st = 0; st < KST; ++st)
@@ -468,8 +475,11 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[st][kt]), __builtin_bit_cast(bf16x8, qf[st]), s[kt], 0, 0, 0);
-    // ---- V^T fragments of this tile, requested under the softmax
-    bf16x8 vf[2][2][DT];
+#endif
+  };
+  // V^T fragments of the tile in `stage` (transposing reads)
+  auto read_v = [&](int stage, bf16x8 (&vf)[2][2][DT]) {
+    const char* vb = sV + stage * TILE_B;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -487,12 +497,13 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
             const int ch = ((vcolb >> 4) + 4 * dt) ^ (((row >> 1) & 1) << 2);
             hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(vb + row * 128 + ch * 16 + (vcolb & 15)));
           }
-          const s16x4 l2 = lo, h2 = hi;
           typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x8 both = {l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
+          const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           vf[kt][st][dt] = __builtin_bit_cast(bf16x8, both);
         }
-    // ---- online softmax (lane-local row; partner lane ^ 32 holds the other 32 keys)
+  };
+  // online softmax of tile t (scores in s, lane-local row; partner lane ^ 32 holds the other 32 keys), then O^T += V^T P^T
+  auto softmax_pv = [&](int t, f32x16 (&s)[2], bf16x8 (&vf)[2][2][DT], auto ragged) {
     if constexpr (decltype(ragged)::value) {
       const int kbase2 = t * 64 + 4 * half;
 #pragma unroll
@@ -503,14 +514,35 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
           s[kt][r] = kk < gi.k_count ? s[kt][r] : -3e38f;
         }
     }
+#ifdef ATTN_DMA_CHAINS
+    float mxp[4] = {-3e38f, -3e38f, -3e38f, -3e38f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mxp[r & 3] = fmaxf(mxp[r & 3], s[kt][r]);
+    float mx = fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3]));
+#else
     float mx = -3e38f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+#endif
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * sc);        // sc > 0: max commutes with the scale
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#ifdef ATTN_DMA_CHAINS
+    float psp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
+        s[kt][r] = e;
+        psp[r & 3] += e;
+      }
+    float ps = (psp[0] + psp[1]) + (psp[2] + psp[3]);
+#else
     float ps = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -520,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
         s[kt][r] = e;
         ps += e;
       }
+#endif
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
     if (__any(m_new != m_run)) {
@@ -529,7 +562,10 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
     m_run = m_new;
-    // ---- O^T += V^T P^T : P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
+#ifdef ATTN_DMA_LEAN
+    read_v(t & 1, vf);
+#endif
+    // P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -542,8 +578,49 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
       }
   };
   const int nfull = gi.k_count >> 6;
+#ifdef ATTN_DMA_PIPE
+  // software pipeline inside the wave: the S^T MFMAs of tile t + 1 are issued BEFORE the softmax of tile t, so the matrix pipe works
+  // under this wave's own VALU phase (not only under another wave's); two score register sets, two waves per SIMD
+  f32x16 sa[2], sb[2];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (ntiles > 1) issue(1, 64);
+  compute_s(0, sa);
+  auto step = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2]) {
+    bf16x8 vf[2][2][DT];
+    read_v(t & 1, vf);
+    if (t + 1 < ntiles) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // tile t + 1 has landed; this wave holds tile t's V fragments
+      __builtin_amdgcn_s_barrier();                                  // ... every wave does: stage t & 1 is free
+      asm volatile("" ::: "memory");
+      if (t + 2 < ntiles) issue(t & 1, (t + 2) * 64);
+      compute_s((t + 1) & 1, snext);
+    }
+    if (t >= nfull) softmax_pv(t, scur, vf, std::true_type{});
+    else softmax_pv(t, scur, vf, std::false_type{});
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(t, sa, sb);
+    if (t + 1 < ntiles) step(t + 1, sb, sa);
+  }
+#else
+  auto tile_body = [&](int t, auto ragged) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this tile's DMA (the only one in flight) has landed
+    __builtin_amdgcn_s_barrier();                                    // ... for every wave; everyone is past the other stage's reads
+    asm volatile("" ::: "memory");
+    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64);            // in flight during this tile's MFMAs
+    f32x16 s[2];
+    compute_s(t & 1, s);
+    bf16x8 vf[2][2][DT];
+#ifndef ATTN_DMA_LEAN
+    read_v(t & 1, vf);                                               // requested under the softmax
+#endif
+    softmax_pv(t, s, vf, ragged);
+  };
   for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
+#endif
   // ---- normalise, transpose through LDS (stage 0 of K / V: free after the last tile) and store whole 128-byte head rows
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();

@@ -67,7 +67,7 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
       }
   }
   __syncthreads();
-  float* sQ = sP + 4 * NREC * BN * 2;                   // tail mode: the per-(record, column) totals, then folded into the consumer's groups
+  float* sQ = sP + 4 * NREC * BN * 2;                   // the per-(record, column) totals, then folded into QUADS of 4 columns
   for (int t = tid; t < NREC * BN; t += 256) {
     const int r = t / BN, col = t % BN;
     float a = 0.f, b = 0.f;
@@ -76,25 +76,23 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
       a += sP[(((w * NREC + r) * BN) + col) * 2];
       b += sP[(((w * NREC + r) * BN) + col) * 2 + 1];
     }
-    if (p.gt.acc) {
-      sQ[t * 2] = a;
-      sQ[t * 2 + 1] = b;
-    } else if (n0 + col < p.Cout && m0 + r * 64 < p.M) {
-      float* d = p.stats + ((int64_t)(m0 / 64 + r) * p.stats_ld + n0 + col) * 2;
-      d[0] = a;
-      d[1] = b;
-    }
+    sQ[t * 2] = a;
+    sQ[t * 2 + 1] = b;
   }
-  if (p.gt.acc) {                                       // block-uniform: quads of 4 columns into the buffer's integer accumulators
-    __syncthreads();
-    const int ncol = p.Cout - n0 < BN ? p.Cout - n0 : BN, nq = ncol >> 2;
-    for (int t = tid; t < NREC * nq; t += 256) {
-      const int r = t / nq, q = t - r * nq;
-      if (m0 + r * 64 < p.M) {
-        const float* v = sQ + (r * BN + 4 * q) * 2;
-        const float a = (v[0] + v[2]) + (v[4] + v[6]), b = (v[1] + v[3]) + (v[5] + v[7]);
+  __syncthreads();
+  const int ncol = p.Cout - n0 < BN ? p.Cout - n0 : BN, nq = ncol >> 2;
+  for (int t = tid; t < NREC * nq; t += 256) {
+    const int r = t / nq, q = t - r * nq;
+    if (m0 + r * 64 < p.M) {
+      const float* v = sQ + (r * BN + 4 * q) * 2;
+      const float a = (v[0] + v[2]) + (v[4] + v[6]), b = (v[1] + v[3]) + (v[5] + v[7]);
+      if (p.gt.acc) {                                   // into the buffer's integer accumulators (tail mode)
         const int sl = (int)((m0 + r * 64) / p.gt.rows_per_slice);
         gn_tail_add(p.gt.acc + ((int64_t)sl * p.gt.q_ld + p.gt.q_off + (n0 >> 2) + q) * 4, a, b);
+      } else {                                          // quad record of this 64-row record
+        float* d = p.stats + ((int64_t)(m0 / 64 + r) * p.stats_ld + (n0 >> 2) + q) * 2;
+        d[0] = a;
+        d[1] = b;
       }
     }
   }
@@ -1370,6 +1368,21 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 // recursive-halving butterfly over the 32 lanes of a half-wave), so launches that emit statistics are chosen by layer geometry,
 // never by timing (ops.strip_tile_pinned).
 // Grid = row strips x nsplit column ranges (nsplit fills the chip when M is small; results do not depend on it).
+// Sum over the 32 lanes of each half-wave without LDS traffic or selects (round 3: the shuffle butterfly above compiled to 64
+// ds_bpermute + 121 v_cndmask per chunk): four DPP row rotations give every lane of a 16-lane row the row total, row_bcast:15 then
+// adds the total of rows 0 / 2 into rows 1 / 3.  Valid in lanes 16-31 (half 0) and 48-63 (half 1).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float halfwave_total(float v) {
+  v = dpp_add<0x128, 0xf>(v);      // row_ror:8
+  v = dpp_add<0x124, 0xf>(v);      // row_ror:4
+  v = dpp_add<0x122, 0xf>(v);      // row_ror:2
+  v = dpp_add<0x121, 0xf>(v);      // row_ror:1
+  return dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+}
+
 __device__ __forceinline__ float halfwave_sum16(const float (&u)[16], int l31) {
   // sum of u[i] over the 32 lanes of a half-wave for all sixteen i at once: each xor step halves what a lane carries; the lane
   // ends with the total of u[l31 >> 1] (the xor-1 step completes it in both lanes of a pair)
@@ -1586,7 +1599,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
     if (ci + 1 < nchunk) issue(st ^ 1, ci + 1);         // next chunk's weights land under this chunk's MFMAs
 #endif
     u32x4 outv[RF][2];                                  // the LAST sub-tile's stores wait until after the barrier (see above)
-    float srec[2];
+    float srec[2][2];
 #ifdef STRIP_JOINT
     // experiment (-DSTRIP_JOINT, K = 128 only): the MFMAs of BOTH 32-channel sub-tiles of a chunk issued together = four independent
     // accumulator chains per wave instead of two (the SQ counters show ~50 % issue stalls), the epilogues after them
@@ -1688,13 +1701,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
           if (DEFER && a == NA - 1) outv[f][j2] = pk;
           else if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = pk;
 #endif
-          if (STM == 1) {                                 // statistics of the values as STORED
-            float rf[8];
-            Elt<__bf16>::unpack(pk, rf);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { u[2 * j] += rf[j]; u[2 * j + 1] += rf[j] * rf[j]; }
-          }
-          if (STM == 2) {                                // tail mode: the lane's 8 channels = two quads of the buffer
+          if (STM != 0) {                                // statistics of the values as STORED: the lane's 8 channels = two QUADS
             float rf[8];
             Elt<__bf16>::unpack(pk, rf);
 #pragma unroll
@@ -1729,16 +1736,26 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
             }
           }
         }
-        if (STM == 1) {                                   // block-uniform
-          const float tot = halfwave_sum16(u, l31);      // float (l31 >> 1) of the 8 channels' (sum, sum of squares) records
+        if (STM == 1) {                                   // block-uniform: quad records (sum, sum of squares) per 64 rows
+          // lanes 16 / 17 of each half end up with the (sum, sum of squares) of quad 0 / 1 of the lane group's 8 channels
+          const float t0 = halfwave_total(u[0]), t1 = halfwave_total(u[1]), t2 = halfwave_total(u[2]), t3 = halfwave_total(u[3]);
+          const float msum = (l31 & 1) ? t1 : t0, msq = (l31 & 1) ? t3 : t2;
           if (RF == 1) {
             // a wave holds HALF a record (32 rows): park the partial for the even wave of the pair, which adds (own + partner) after
             // the chunk's barrier; the buffer alternates with the chunk parity, so a wave that runs ahead into the next chunk cannot
             // overwrite what its partner has not read yet
-            if ((l31 & 1) == 0) sRec[(((ci & 1) * 4 + wave) * (NA * 2) + a * 2 + j2) * 32 + half * 16 + (l31 >> 1)] = tot;
-            srec[j2] = tot;                              // RF = 1 has one sub-tile per chunk (CC = 32)
-          } else if (DEFER && a == NA - 1) srec[j2] = tot;
-          else if (wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = tot;
+            if ((l31 >> 1) == 8) {
+              float* d = sRec + ((((ci & 1) * 4 + wave) * (NA * 2) + a * 2 + j2) * 2 + half) * 4 + (l31 & 1) * 2;
+              d[0] = msum;
+              d[1] = msq;
+            }
+            srec[j2][0] = msum;                          // RF = 1 has one sub-tile per chunk (CC = 32)
+            srec[j2][1] = msq;
+          } else if (wave_ok && (l31 >> 1) == 8) {
+            float* d = p.stats + (rec * p.stats_ld + (col >> 2) + (l31 & 1)) * 2;
+            d[0] = msum;
+            d[1] = msq;
+          }
         }
       }
     }
@@ -1755,11 +1772,13 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
         if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = outv[f][j2];
 #endif
       if (RF == 1) {
-        if (STM == 1 && wave_ok && (wave & 1) == 0 && (l31 & 1) == 0) {
-          const float other = sRec[(((ci & 1) * 4 + wave + 1) * (NA * 2) + (NA - 1) * 2 + j2) * 32 + half * 16 + (l31 >> 1)];
-          p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2] + other;
+        if (STM == 1 && wave_ok && (wave & 1) == 0 && (l31 >> 1) == 8) {
+          const float* o = sRec + ((((ci & 1) * 4 + wave + 1) * (NA * 2) + (NA - 1) * 2 + j2) * 2 + half) * 4 + (l31 & 1) * 2;
+          float* d = p.stats + (rec * p.stats_ld + (col >> 2) + (l31 & 1)) * 2;
+          d[0] = srec[j2][0] + o[0];
+          d[1] = srec[j2][1] + o[1];
         }
-      } else if (STM == 1 && wave_ok && (l31 & 1) == 0) p.stats[(rec * p.stats_ld + col) * 2 + (l31 >> 1)] = srec[j2];
+      }
     }
   }
   if (STM == 2) {                                        // block-uniform: flush the block's integer accumulators, then the ticket protocol
@@ -2002,8 +2021,8 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
   p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = gn_act; p.gn_S = gn_S; p.gn_rows = gn_rows;
-  MMD_REQUIRE(!stats || (M % 64 == 0 && stats_ld >= Cout && tile != 130 && tile != 133 && (uintptr_t)stats % 8 == 0),
-              "conv_gemm: output statistics need M %% 64 == 0, stats_ld >= Cout and a row-tiled main loop (not tiles 130 / 133)");
+  MMD_REQUIRE(!stats || (M % 64 == 0 && Cout % 4 == 0 && stats_ld >= Cout / 4 && tile != 130 && tile != 133 && (uintptr_t)stats % 8 == 0),
+              "conv_gemm: output statistics need M %% 64 == 0, Cout %% 4 == 0, stats_ld >= Cout / 4 (quads) and a row-tiled main loop (not tiles 130 / 133)");
   p.stats = stats; p.stats_ld = stats_ld;
   p.gt = mmd_gn_tail{};
   if (tail && tail->acc) {
@@ -2039,9 +2058,9 @@ extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* 
                         0, nullptr, 0, stream);
 }
 
-// As mmd_conv_gemm, and the epilogue also leaves the GroupNorm statistics of the output for its consumer: per (64-row record,
-// column) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + column] = float2 (stats points at the
-// first column this launch writes, so producers of a channel-concatenated tensor fill column slices of one record buffer).
+// As mmd_conv_gemm, and the epilogue also leaves the GroupNorm statistics of the output for its consumer: per (64-row record, QUAD
+// of 4 columns) the sum and the sum of squares of the values as stored, stats[(m / 64) * stats_ld + quad] = float2 (stats points at
+// the first quad this launch writes, so producers of a channel-concatenated tensor fill column slices of one record buffer).
 // mmd_gn_finalize_stats turns the records into the fused affine; the statistics pass over the tensor disappears.
 extern "C" int mmd_conv_gemm_stats(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                                    void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,

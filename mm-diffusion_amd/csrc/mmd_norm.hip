@@ -460,8 +460,8 @@ extern "C" int mmd_gn_stats(int dtype, const void* x, int64_t ld, int C, int S, 
   return mmd_check_launch("gn_finalize");
 }
 
-// ---- GroupNorm finalize from PRODUCER-side statistics (mmd_conv_gemm_stats): rec[(row / 64) * rec_ld + c] = (sum, sum of squares) of
-// the stored values of 64 consecutive rows of channel c.  One block per (group, slice): the slice's Tn / 64 records x cpg channels
+// ---- GroupNorm finalize from PRODUCER-side statistics (mmd_conv_gemm_stats): rec[(row / 64) * rec_ld + q] = (sum, sum of squares) of
+// the stored values of 64 consecutive rows of the channel QUAD q (4 channels; per column until round 3).  One block per (group, slice): the slice's Tn / 64 records x cpg channels
 // are summed in double in a fixed order (thread-strided, then a fixed tree), var = E[x^2] - mean^2 in double (no pivot: the records
 // carry plain sums; the sums themselves are exact to fp32 rounding of <= 64-term partials, so the cancellation costs
 // (1 + mean^2 / var) x 1e-7 relative - fine for conv outputs; the engine uses this path in bf16 mode only).
@@ -472,17 +472,17 @@ __global__ __launch_bounds__(256) void gn_finalize_rec_kernel(const float* __res
   __shared__ double s_a[4], s_b[4];
   __shared__ float s_mr[2];
   const int gi = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-  const int cpg = C / GN_GROUPS;
+  const int cpg = C / GN_GROUPS, qpg = cpg / 4;           // records are per QUAD of 4 channels (round 3)
   const int nrec = Tn / 64;
-  const float* base = rec + ((int64_t)s * nrec * rec_ld + (int64_t)gi * cpg) * 2;
-  const int total = nrec * cpg;
+  const float* base = rec + ((int64_t)s * nrec * rec_ld + (int64_t)gi * qpg) * 2;
+  const int total = nrec * qpg;
   double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < total; i += 1024) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {          // branch-free: clamped address, masked value -> the four loads issue together
       const int k = i + 256 * u;
       const int kk = min(k, total - 1);
-      const int r = kk / cpg, c = kk - r * cpg;
+      const int r = kk / qpg, c = kk - r * qpg;
       const float2 v = *(const float2*)(base + ((int64_t)r * rec_ld + c) * 2);
       const double m = k < total ? 1.0 : 0.0;
       a[u] += m * (double)v.x;
@@ -529,7 +529,8 @@ extern "C" int mmd_gn_finalize_stats(const float* rec, int64_t rec_ld, int C, in
                                      const float* film, int64_t film_ld, float eps, float* a_out, float* b_out, float* mr_out,
                                      void* stream) {
   MMD_REQUIRE(rec && gamma && beta && a_out && b_out, "gn_finalize_stats: null pointer");
-  MMD_REQUIRE(C > 0 && C % GN_GROUPS == 0 && C / GN_GROUPS <= 256 && rec_ld >= C, "gn_finalize_stats: bad channel count %d (ld %ld)", C, (long)rec_ld);
+  MMD_REQUIRE(C > 0 && C % (4 * GN_GROUPS) == 0 && C / GN_GROUPS <= 256 && rec_ld >= C / 4,
+              "gn_finalize_stats: channel count %d (groups of whole quads: a multiple of 128; ld %ld quads)", C, (long)rec_ld);
   MMD_REQUIRE(S > 0 && Tn > 0 && Tn % 64 == 0, "gn_finalize_stats: slices must be multiples of 64 rows (S=%d Tn=%d)", S, Tn);
   hipLaunchKernelGGL(gn_finalize_rec_kernel, dim3(GN_GROUPS, S), dim3(256), 0, (hipStream_t)stream, rec, rec_ld, C, S, Tn, gamma, beta,
                      film, film_ld, eps, a_out, b_out, mr_out);

@@ -118,9 +118,9 @@ class UNetEngine:
             self._tail_bytes += S * (C // 4) * 4 * 8                     # [S][C / 4 quads][4] int64
             self._tails[raw.untyped_storage().data_ptr()] = dict(ptr=t.data_ptr(), es=es, rows=rows, C=C, unit=unit, S=S, off=off,
                                                                  producers=[], active=False)
-        elif stats and self.rec_enabled and rows % 64 == 0 and unit % 64 == 0:
-            rec = self._alloc(rows // 64, 2 * C, torch.float32)
-            self._recs[raw.untyped_storage().data_ptr()] = dict(rec=rec, view=rec.view(rows // 64, C, 2), ptr=t.data_ptr(), es=es,
+        elif stats and self.rec_enabled and rows % 64 == 0 and unit % 64 == 0 and C % 4 == 0:
+            rec = self._alloc(rows // 64, C // 2, torch.float32)            # one (sum, sum of squares) record per 64 rows and channel QUAD
+            self._recs[raw.untyped_storage().data_ptr()] = dict(rec=rec, view=rec.view(rows // 64, C // 4, 2), ptr=t.data_ptr(), es=es,
                                                                 rows=rows, C=C, cover=[])
         return t
 
@@ -146,10 +146,10 @@ class UNetEngine:
     def _stats_for(self, out):
         """The record view a GEMM writing `out` should fill (None: the buffer has no record buffer)."""
         ent, c0 = self._rec_slice(out)
-        if ent is None:
+        if ent is None or c0 % 4 or out.shape[1] % 4:
             return None
         ent["cover"].append((c0, c0 + out.shape[1]))
-        return ent["view"][:, c0:c0 + out.shape[1], :]
+        return ent["view"][:, c0 // 4:(c0 + out.shape[1]) // 4, :]
 
     # ------------------------------------------------------------------ in-launch statistics + affine (tails)
     def _tail_slice(self, t):
@@ -237,14 +237,15 @@ class UNetEngine:
         """The record view a GroupNorm over x can finalize from: every column of x written by a statistics-emitting GEMM, contiguous
         slices that are multiples of 64 rows.  None -> the classic statistics pass."""
         ent, c0 = self._rec_slice(x)
-        if ent is None or geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn % 64 or geom.S * geom.Tn != x.shape[0]:
+        if (ent is None or geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn % 64 or geom.S * geom.Tn != x.shape[0]
+                or c0 % 4 or x.shape[1] % 128):                    # quad records: groups must be whole quads
             return None
         need, pos = c0 + x.shape[1], c0
         for lo, hi in sorted(ent["cover"]):
             if lo > pos:
                 break
             pos = max(pos, hi)
-        return ent["view"][:, c0:need, :] if pos >= need else None
+        return ent["view"][:, c0 // 4:need // 4, :] if pos >= need else None
 
     def _static(self, shape, dtype):
         t = torch.zeros(shape, dtype=dtype, device=self.device)

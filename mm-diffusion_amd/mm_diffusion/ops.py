@@ -132,8 +132,11 @@ def gn_stats(x, gamma, beta, geom: Geom, film=None, a=None, b=None, ws=None, mr=
 
 def gn_finalize_stats(rec, gamma, beta, geom: Geom, film=None, a=None, b=None, mr=None):
     """The fused GroupNorm affine from producer-side statistics (include/mmd.h: mmd_gn_finalize_stats): rec = fp32 view
-    [rows / 64, C, 2] over exactly the channels of the normalised tensor; S contiguous slices of Tn rows."""
-    C = rec.shape[1]
+    [rows / 64, C / 4, 2] (one record per QUAD of channels) over exactly the channels of the normalised tensor; S contiguous slices
+    of Tn rows."""
+    C = rec.shape[1] * 4
+    if C % 128:
+        raise H.MMDError("gn_finalize_stats: the normalised channels must be a multiple of 128 (groups of whole quads)")
     if geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn % 64 or rec.shape[0] * 64 != geom.S * geom.Tn:
         raise H.MMDError("gn_finalize_stats: needs contiguous slices that are multiples of 64 rows")
     a = alloc(geom.S, C, dtype=torch.float32, device=rec.device) if a is None else a
@@ -302,20 +305,28 @@ def halo_tile_code(x, taps, dims):
     channel chunks on (ds1 256->128: 193 -> 164 us, ds2 640->256: 200 -> 166 us); with two chunks its prologue and epilogue have no
     co-resident block to hide behind (ds1 128->128: 103 vs 110 us)."""
     return 133 if (_HALO16 and x.dtype == torch.bfloat16 and len(taps) == 9 and dims[1] % 16 == 0 and dims[2] % 16 == 0
-                   and x.shape[1] >= 256 and tuple(tuple(t) for t in taps) == tuple(TAPS_SPATIAL)) else 130
+                   and (x.shape[1] >= 256 or dims[1] % 8) and tuple(tuple(t) for t in taps) == tuple(TAPS_SPATIAL)) else 130
 
 
 def _stats_args(stats, M, Cout):
-    """stats: fp32 view [M / 64, Cout, 2] (a column slice of the output's record buffer) -> (pointer, row stride in float2)."""
-    if stats.dtype != torch.float32 or tuple(stats.shape) != (M // 64, Cout, 2) or M % 64 or stats.stride(1) != 2 or stats.stride(2) != 1:
-        raise H.MMDError(f"GEMM output statistics: expected an fp32 [M/64, Cout, 2] view, got {tuple(stats.shape)} strides {stats.stride()}")
+    """stats: fp32 view [M / 64, Cout / 4, 2] (a quad-column slice of the output's record buffer) -> (pointer, row stride in float2)."""
+    if (stats.dtype != torch.float32 or Cout % 4 or tuple(stats.shape) != (M // 64, Cout // 4, 2) or M % 64 or stats.stride(1) != 2
+            or stats.stride(2) != 1):
+        raise H.MMDError(f"GEMM output statistics: expected an fp32 [M/64, Cout/4, 2] view, got {tuple(stats.shape)} strides {stats.stride()}")
     return stats.data_ptr(), stats.stride(0) // 2
+
+
+# frames of >= 256 pixels since round 3 (was 1024): after the issue-side diet tile 133 ties the direct-to-LDS loop on the ds4 level
+# (16 x 16 frames, 48.1 vs 48.2 us) and brings the fused input GroupNorm with it (one launch and one pass fewer per ResBlock)
+# 1024: ds1 / ds2.  Pinning the ds4 frames (256 pixels) too was measured a loss in round 3: tile 133 runs those 3x3 convs in 67 us
+# against 48.6 us on the direct-to-LDS tile with descriptor addressing, more than the fused GroupNorm apply gives back.
+_HALO_MIN_PIXELS = int(os.environ.get("MMD_HALO_MIN_PIXELS", "1024"))
 
 
 def halo_tile_pinned(x, taps, dims):
     """The layers that always run on tile 130: spatial 3x3 convs on frames of >= 1024 pixels (ds1 / ds2 of the base model) - a property
     of the layer, independent of the batch size."""
-    return (_HALO_MODE == "pin" and x.dtype == torch.bfloat16 and len(taps) == 9 and dims[1] * dims[2] >= 1024
+    return (_HALO_MODE == "pin" and x.dtype == torch.bfloat16 and len(taps) == 9 and dims[1] * dims[2] >= _HALO_MIN_PIXELS
             and halo_tile_ok(x, taps, dims))
 
 

@@ -196,15 +196,18 @@ def test_halo_tile_block_flow_model():
 
 
 def test_halo_tile_is_pinned_by_layer_geometry_only():
-    """Tile 130 is chosen for spatial 3x3 convs on frames of >= 1024 pixels whatever the batch (ops.halo_tile_pinned): the choice may
-    never depend on the batch size, or a batch-4 plan and a batch-1 plan would differ in the last bit."""
+    """The halo tiles (130 / 133) are chosen for spatial 3x3 convs on frames of >= 1024 pixels whatever the batch
+    (ops.halo_tile_pinned): the choice may never depend on the batch size, or a batch-4 plan and a batch-1 plan would differ in the
+    last bit; between 130 and 133 (bitwise equal) the channel count decides."""
     import torch
     from mm_diffusion import ops
     for n in (1, 2, 4, 8):
         x = torch.zeros(n * 16 * 32 * 32, 256, dtype=torch.bfloat16)
         assert ops.halo_tile_pinned(x, ops.TAPS_SPATIAL, (n * 16, 32, 32))                     # ds2 frames: 1024 pixels
         x = torch.zeros(n * 16 * 16 * 16, 384, dtype=torch.bfloat16)
-        assert not ops.halo_tile_pinned(x, ops.TAPS_SPATIAL, (n * 16, 16, 16))                 # ds4 frames: 256 pixels
+        assert not ops.halo_tile_pinned(x, ops.TAPS_SPATIAL, (n * 16, 16, 16))                 # ds4 frames: 256 pixels (measured a loss)
+        assert ops.halo_tile_code(x, ops.TAPS_SPATIAL, (n * 16, 16, 16)) == 133
+    assert ops.halo_tile_code(torch.zeros(16 * 64 * 64, 128, dtype=torch.bfloat16), ops.TAPS_SPATIAL, (16, 64, 64)) == 130
     x = torch.zeros(16 * 64 * 64, 128, dtype=torch.bfloat16)
     assert not ops.halo_tile_pinned(x, ops.TAPS_TEMPORAL, (16, 4096, 1))                      # temporal k=3: not a 9-tap conv
     assert not ops.halo_tile_pinned(x.float(), ops.TAPS_SPATIAL, (16, 64, 64))                # fp32 mode keeps the bitwise-equal tiles

@@ -120,8 +120,8 @@ def test_halo_tile_variant_temporal_form(ops, dt):
 @pytest.mark.parametrize("tile", [64, 128, 129])
 @pytest.mark.parametrize("M,Cin,Cout,taps3,res", [(256, 64, 96, False, True), (1024, 128, 128, True, False), (192, 256, 264, False, False)])
 def test_gemm_epilogue_statistics(ops, dt, tile, M, Cin, Cout, taps3, res):
-    """mmd_conv_gemm_stats: per (64-row record, column) sum and sum of squares of the values AS STORED, written into a column slice of a
-    wider record buffer; the output itself is bitwise the plain kernel's."""
+    """mmd_conv_gemm_stats: per (64-row record, quad of 4 columns) sum and sum of squares of the values AS STORED, written into a quad
+    slice of a wider record buffer; the output itself is bitwise the plain kernel's."""
     g = torch.Generator(device="cuda").manual_seed(M + Cout)
     taps, dims = (ops.TAPS_TEMPORAL, (4, M // 4, 1)) if taps3 else (ops.TAPS_1, (1, 1, 1))
     x = torch.randn(M, Cin, device="cuda", generator=g).to(dt)
@@ -129,17 +129,18 @@ def test_gemm_epilogue_statistics(ops, dt, tile, M, Cin, Cout, taps3, res):
     b = torch.randn(Cout, device="cuda", generator=g)
     r = torch.randn(M, Cout, device="cuda", generator=g).to(dt) if res else None
     y0 = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile)
-    wide = torch.full((M // 64, Cout + 40, 2), 7.0, device="cuda")
-    y1 = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile, stats=wide[:, 24:24 + Cout, :])
+    Q = Cout // 4                                            # one record per QUAD of channels (round 3)
+    wide = torch.full((M // 64, Q + 10, 2), 7.0, device="cuda")
+    y1 = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile, stats=wide[:, 6:6 + Q, :])
     assert torch.equal(y0, y1)
-    yf = y1.double().view(M // 64, 64, Cout)
-    ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
-    got = wide[:, 24:24 + Cout, :].double()
+    yf = y1.double().view(M // 64, 64, Q, 4)
+    ref = torch.stack([yf.sum((1, 3)), (yf * yf).sum((1, 3))], dim=-1)
+    got = wide[:, 6:6 + Q, :].double()
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
-    assert float((wide[:, :24] - 7).abs().max()) == 0 and float((wide[:, 24 + Cout:] - 7).abs().max()) == 0
+    assert float((wide[:, :6] - 7).abs().max()) == 0 and float((wide[:, 6 + Q:] - 7).abs().max()) == 0
 
 
-@pytest.mark.parametrize("S,Tn,C,film", [(4, 256, 128, True), (2, 1024, 64, False), (8, 64, 512, True)])
+@pytest.mark.parametrize("S,Tn,C,film", [(4, 256, 128, True), (2, 1024, 384, False), (8, 64, 512, True)])
 def test_gn_finalize_from_producer_statistics(ops, S, Tn, C, film):
     """mmd_gn_finalize_stats (affine from the producer GEMM's records) against mmd_gn_stats (statistics pass over the tensor)."""
     dt = torch.bfloat16
@@ -149,10 +150,10 @@ def test_gn_finalize_from_producer_statistics(ops, S, Tn, C, film):
     fm = torch.randn(S, 2 * C, device="cuda", generator=g) * 0.3 if film else None
     geom = ops.Geom.per_sample(S, Tn)
     a0, b0 = ops.gn_stats(x, gamma, beta, geom, film=fm)
-    xf = x.float().view(S * Tn // 64, 64, C)
-    rec = torch.zeros(S * Tn // 64, C + 16, 2, device="cuda")
-    rec[:, 8:8 + C, 0], rec[:, 8:8 + C, 1] = xf.sum(1), (xf * xf).sum(1)
-    a1, b1 = ops.gn_finalize_stats(rec[:, 8:8 + C, :], gamma, beta, geom, film=fm)
+    xf = x.float().view(S * Tn // 64, 64, C // 4, 4)
+    rec = torch.zeros(S * Tn // 64, C // 4 + 16, 2, device="cuda")
+    rec[:, 8:8 + C // 4, 0], rec[:, 8:8 + C // 4, 1] = xf.sum((1, 3)), (xf * xf).sum((1, 3))
+    a1, b1 = ops.gn_finalize_stats(rec[:, 8:8 + C // 4, :], gamma, beta, geom, film=fm)
     assert rel_l2(a1.cpu(), a0.cpu().numpy()) < 1e-5 and rel_l2(b1.cpu(), b0.cpu().numpy()) < 1e-5
 
 
@@ -170,7 +171,7 @@ def test_gn_conv1x1_statistics_feed_the_next_norm(ops):
     geom = ops.Geom.per_sample(S, Tn)
     a, b = ops.gn_stats(x, gamma, beta, geom)
     for tile in (64, 128):
-        rec = torch.zeros(S * Tn // 64, Cout, 2, device="cuda")
+        rec = torch.zeros(S * Tn // 64, Cout // 4, 2, device="cuda")
         y = ops.gn_conv1x1(x, a, b, geom, True, w, bias, residual=r, tile=tile, stats=rec)
         y0 = ops.gn_conv1x1(x, a, b, geom, True, w, bias, residual=r, tile=tile)
         assert torch.equal(y, y0)

@@ -61,8 +61,10 @@ def test_halo_fused_groupnorm(ops, act, N, F, H, W, Cin, Cout, cat):
 
 
 def test_engine_uses_the_fused_halo_norm_and_matches_the_unfused_plan(monkeypatch):
-    """The launch plan of the mid-size model with and without MMD_HALO_GN: same outputs bitwise (the fusion is a pure speed choice)
-    and the fused plan really carries gn_conv_gemm launches."""
+    """The launch plan of the mid-size model with and without MMD_HALO_GN: the fused plan really carries gn_conv_gemm launches, and the
+    outputs agree to bf16 rounding noise.  (The op itself is bitwise the two-launch form - test_halo_gn_* above; whole plans are not,
+    because the unfused plan is free to autotune another tile for the producer of a norm's records, and tiles sum a record's 64 rows
+    in different orders.)"""
     import importlib
     from helpers import flags, inputs
     from mm_diffusion import multimodal_script_util as msu, ops as o
@@ -84,7 +86,7 @@ def test_engine_uses_the_fused_halo_norm_and_matches_the_unfused_plan(monkeypatc
         outs.append((ov.clone(), oa.clone(), names.count("mmd_gn_conv_gemm"), names.count("mmd_gn_apply")))
         model.release_engines()
     assert outs[0][2] > 0 and outs[1][2] == 0 and outs[0][3] < outs[1][3]
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_l2(outs[0][0], outs[1][0]) < 5e-3 and rel_l2(outs[0][1], outs[1][1]) < 5e-3
 
 
 @pytest.mark.parametrize("dt", [torch.float32, BF])

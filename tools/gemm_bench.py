@@ -32,7 +32,7 @@ SHAPES = [  # name, M, Cin, taps, dims, Cout, residual
     ("qkv ds8 512->1536", 4096, 512, ops.TAPS_1, (1, 1, 1), 1536, False),
     ("audio qkv 256->768", 25600, 256, ops.TAPS_1, (1, 1, 1), 768, False),
 ]
-TILES = (64, 128, 129, 130)     # 130 = halo-tile 3x3 main loop (experimental; spatial taps only)
+TILES = (64, 129, 130, 131, 132, 133)     # 130 / 133 = halo tiles (spatial 3x3 only), 131 = row strip (K <= 512), 132 = four-slot ring
 
 
 def main():
@@ -52,8 +52,9 @@ def main():
         ref = None
         line = f"{name:26s} M={M:6d} K={Cin*len(taps):5d} N={Cout:4d}"
         for tile in TILES:
-            if tile == 130 and not (all(t[0] == 0 and abs(t[1]) <= 1 and abs(t[2]) <= 1 for t in taps) and len(taps) > 1
-                                    and dims[1] % 8 == 0 and dims[2] % 16 == 0 and Cin % 64 == 0):
+            if tile in (130, 133) and not (len(taps) == 9 and dims[1] % 16 == 0 and dims[2] % 16 == 0 and Cin % 64 == 0):
+                continue
+            if tile == 131 and not ops.strip_tile_ok(x, Cout, taps):
                 continue
             y = ops.conv_gemm(x, w, b, taps=taps, dims=dims, residual=r, tile=tile)
             if ref is None:
