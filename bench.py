@@ -384,6 +384,9 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="batch lanes of the sampling step (0 = the sampler's default; sampler.GraphStepper)")
     ap.add_argument("--breakdown-out", default="")
+    ap.add_argument("--as-rank", type=int, default=0,
+                    help="single-process run with the seeds of rank R of a multi-rank job (tests: rank r's trajectory is that of a lone process seeded 1234 + r)")
+    ap.add_argument("--dump-final", default="", help="directory: every rank saves its final sample as rank<r>.pt (sample mode)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring the ranks up, all-reduce a one per rank and print {n_gpus, ranks_seen, backend}: the self-launch / rendezvous "
                          "path without any GPU work (CPU test of `python bench.py --gpus N`)")
@@ -425,8 +428,9 @@ def main():
     fl, model, diff = build(args.dtype, args.respacing, args.batch, device)
     from mm_diffusion.sampler import GraphStepper
     import random
-    random.seed(1234 + rank)
-    torch.manual_seed(1234 + rank)
+    seed_rank = rank if world > 1 else args.as_rank
+    random.seed(1234 + seed_rank)
+    torch.manual_seed(1234 + seed_rank)
     stepper = GraphStepper(diff, model, args.batch, device, clip_denoised=True, lanes=args.lanes or None)
     stepper.load(torch.randn(args.batch, *fl["video_size"]).to(device), torch.randn(args.batch, *fl["audio_size"]).to(device))
     T = diff.num_timesteps
@@ -458,6 +462,9 @@ def main():
         elapsed = float(tt.item())
     cur = stepper.current()
     finite = bool(torch.isfinite(cur["video"]).all() and torch.isfinite(cur["audio"]).all())
+    if args.dump_final:
+        os.makedirs(args.dump_final, exist_ok=True)
+        torch.save({k: v.cpu() for k, v in cur.items()}, os.path.join(args.dump_final, f"rank{seed_rank}.pt"))
     gather_ms = None
     if world > 1:          # the ONE collective of batch-sharded sampling: the terminal all-gather of the samples (mtu:424-431), timed apart
         fence()

@@ -16,6 +16,14 @@ OUT = os.path.join(HERE, "lib", "libmmd.so")
 SOURCES = ["mmd_core.hip", "mmd_gemm.hip", "mmd_norm.hip", "mmd_attn.hip", "mmd_misc.hip", "mmd_bwd.hip", "mmd_attn_bwd.hip", "mmd_attn_bwd_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 FLAGS += os.environ.get("MMD_EXTRA_CXXFLAGS", "").split()      # ablation builds (tools/*_bench.py), never set for the product
+# The library is built WITHOUT the packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32).  Measured on MI355X
+# (round 3, tools/determinism_mini.py): gn_small_kernel's packed accumulations came out slightly wrong in lanes 48-63 (high register of
+# the pair) whenever its waves shared a SIMD with the OTHER stream's GroupNorm+SiLU-in-the-loader GEMM (v_exp / v_rcp heavy) - 200 of
+# 200 concurrent graph replays differed, 0 of 900 with the kernel compiled without packed fp32; nothing in the kernel's own ISA is
+# wrong.  Library-wide the switch costs nothing (denoising step 12.07 -> 12.02 ms: the hot loops are MFMA / LDS / issue bound), so no
+# kernel is left exposed.  tests/test_round3_gpu.py::test_graph_replays_are_bitwise_repeatable_* guards it.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS += NO_PACKED_F32
 
 
 def _stale():

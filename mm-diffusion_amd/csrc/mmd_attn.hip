@@ -14,7 +14,7 @@
 //   so running max / sum / rescale are lane-local plus one lane^32 exchange), P stays in registers and is
 //   the B operand of O^T = V^T P^T (the 32x32 C layout of S^T is exactly the k-slot order we feed, with V^T
 //   staged key-permuted to match), K row-major / V transposed in LDS with conflict-free strides.
-// attn_generic_kernel (fp32 math, any ch <= 128): LDS-tiled VALU flash attention - fp32 mode and odd shapes.
+// attn_generic_kernel (fp32 math, any ch <= 192): LDS-tiled VALU flash attention - fp32 mode and odd shapes.
 // attn_small_kernel: one wave per (slice, head) for short sequences (temporal attention, T = F <= 32).
 #include "mmd_common.h"
 #include <type_traits>
@@ -921,16 +921,19 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
 }
 
 // ============================================================================= generic VALU flash attention
-template <typename T>
+// KT keys per tile, OB output columns per lane (16 lanes across a row): <64, 8> up to head width 128; <32, 12> up to 192 (the SR
+// U-Net's 768 channels / 4 heads in fp32 mode) - half the key tile so Q, K, V and S still fit the CU's LDS.
+template <typename T, int KT, int OB>
 __global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
+  constexpr int KB = KT / 16, SS = KT + 1, KP = KT / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ch = p.ch;
   const int LQ = ch + 1;
   float* sQ = (float*)smem;            // [64][ch+1]  (pre-scaled)
-  float* sK = sQ + 64 * LQ;            // [64][ch+1]
-  float* sV = sK + 64 * LQ;            // [64][ch]
-  float* sS = sV + 64 * ch;            // [64][65]
-  float* sM = sS + 64 * 65;            // [64] running max
+  float* sK = sQ + 64 * LQ;            // [KT][ch+1]
+  float* sV = sK + KT * LQ;            // [KT][ch]
+  float* sS = sV + KT * ch;            // [64][KT+1]
+  float* sM = sS + 64 * SS;            // [64] running max
   float* sL = sM + 64;                 // [64] running sum
   float* sAl = sL + 64;                // [64] rescale of this tile
 
@@ -949,20 +952,20 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
     sQ[r * LQ + d] = v;
   }
   if (tid < 64) { sM[tid] = -1e30f; sL[tid] = 0.f; }
-  float oacc[4][8];
+  float oacc[4][OB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) oacc[a][b] = 0.f;
+    for (int b = 0; b < OB; ++b) oacc[a][b] = 0.f;
 
-  const int ntiles = (gi.k_count + 63) >> 6;
+  const int ntiles = (gi.k_count + KT - 1) / KT;
   for (int t = 0; t < ntiles; ++t) {
     __syncthreads();
-    for (int i = tid; i < 64 * ch; i += 256) {
+    for (int i = tid; i < KT * ch; i += 256) {
       const int r = i / ch, d = i % ch;
       float kv = 0.f, vv = 0.f;
-      if (t * 64 + r < gi.k_count) {
-        const int64_t row = key_row(gi, t * 64 + r);
+      if (t * KT + r < gi.k_count) {
+        const int64_t row = key_row(gi, t * KT + r);
         kv = Elt<T>::ld(p.KV, row * p.ldkv + p.k_off + h * ch + d);
         vv = Elt<T>::ld(p.KV, row * p.ldkv + p.v_off + h * ch + d);
       }
@@ -970,44 +973,44 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
       sV[r * ch + d] = vv;
     }
     __syncthreads();
-    // S block: rows ty*4.., keys tx*4..
-    float sacc[4][4];
+    // S block: rows ty*4.., keys tx*KB..
+    float sacc[4][KB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) sacc[a][b] = 0.f;
+      for (int b = 0; b < KB; ++b) sacc[a][b] = 0.f;
     for (int d = 0; d < ch; ++d) {
-      float qa[4], kb[4];
+      float qa[4], kb[KB];
 #pragma unroll
       for (int a = 0; a < 4; ++a) qa[a] = sQ[(ty * 4 + a) * LQ + d];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) kb[b] = sK[(tx * 4 + b) * LQ + d];
+      for (int b = 0; b < KB; ++b) kb[b] = sK[(tx * KB + b) * LQ + d];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) sacc[a][b] += qa[a] * kb[b];
+        for (int b = 0; b < KB; ++b) sacc[a][b] += qa[a] * kb[b];
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int kk = t * 64 + tx * 4 + b;
-        sS[(ty * 4 + a) * 65 + tx * 4 + b] = kk < gi.k_count ? sacc[a][b] : -1e30f;
+      for (int b = 0; b < KB; ++b) {
+        const int kk = t * KT + tx * KB + b;
+        sS[(ty * 4 + a) * SS + tx * KB + b] = kk < gi.k_count ? sacc[a][b] : -1e30f;
       }
     __syncthreads();
     // row softmax update: 4 threads per row
     {
       const int r = tid >> 2, part = tid & 3;
       float mx = -1e30f;
-      for (int k = part * 16; k < part * 16 + 16; ++k) mx = fmaxf(mx, sS[r * 65 + k]);
+      for (int k = part * KP; k < part * KP + KP; ++k) mx = fmaxf(mx, sS[r * SS + k]);
       mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
       const float m_old = sM[r];
       const float m_new = fmaxf(m_old, mx);
       float sum = 0.f;
-      for (int k = part * 16; k < part * 16 + 16; ++k) {
-        const float e = __expf(sS[r * 65 + k] - m_new);
-        sS[r * 65 + k] = e;
+      for (int k = part * KP; k < part * KP + KP; ++k) {
+        const float e = __expf(sS[r * SS + k] - m_new);
+        sS[r * SS + k] = e;
         sum += e;
       }
       sum += __shfl_xor(sum, 1, 64);
@@ -1026,14 +1029,14 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
     for (int a = 0; a < 4; ++a) {
       const float al = sAl[ty * 4 + a];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) oacc[a][b] *= al;
+      for (int b = 0; b < OB; ++b) oacc[a][b] *= al;
     }
-    for (int k = 0; k < 64; ++k) {
+    for (int k = 0; k < KT; ++k) {
       float pv[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) pv[a] = sS[(ty * 4 + a) * 65 + k];
+      for (int a = 0; a < 4; ++a) pv[a] = sS[(ty * 4 + a) * SS + k];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
+      for (int b = 0; b < OB; ++b) {
         const int d = tx + 16 * b;
         if (d < ch) {
           const float vv = sV[k * ch + d];
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const AttnParams p) {
     if (q0 + r < gi.q_count) {
       const float inv = 1.f / sL[r];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
+      for (int b = 0; b < OB; ++b) {
         const int d = tx + 16 * b;
         if (d < ch) Elt<T>::st(p.O, (gi.q_row0 + q0 + r) * p.ldo + h * ch + d, oacc[a][b] * inv);
       }
@@ -1308,19 +1311,24 @@ static int launch_stage(const AttnParams& p, int qmax, hipStream_t st) {
   return mmd_check_launch("attn_stage");
 }
 
-template <typename T>
-static int launch_generic(const AttnParams& p, int qmax, hipStream_t st) {
-  const size_t lds = (size_t)(64 * (p.ch + 1) * 2 + 64 * p.ch + 64 * 65 + 192) * sizeof(float);
+template <typename T, int KT, int OB>
+static int launch_generic_as(const AttnParams& p, int qmax, hipStream_t st) {
+  const size_t lds = (size_t)(64 * (p.ch + 1) + KT * (p.ch + 1) + KT * p.ch + 64 * (KT + 1) + 192) * sizeof(float);
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_generic_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_generic_kernel<T, KT, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_generic: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   dim3 grid(cdiv(qmax, 64), p.heads, p.nb * p.G);
-  hipLaunchKernelGGL(attn_generic_kernel<T>, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_generic_kernel<T, KT, OB>), grid, dim3(256), lds, st, p);
   return mmd_check_launch("attn_generic");
+}
+
+template <typename T>
+static int launch_generic(const AttnParams& p, int qmax, hipStream_t st) {
+  return p.ch <= 128 ? launch_generic_as<T, 64, 8>(p, qmax, st) : launch_generic_as<T, 32, 12>(p, qmax, st);
 }
 
 static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off,
@@ -1330,7 +1338,6 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "attn_fwd: bad dtype %d", dtype);
   MMD_REQUIRE(Q && KV && O, "attn_fwd: null pointer");
   MMD_REQUIRE(heads > 0 && ch > 0 && ch <= 192 && nb > 0 && G > 0, "attn_fwd: bad heads/ch/nb/G (%d,%d,%d,%d)", heads, ch, nb, G);
-  MMD_REQUIRE(ch <= 128 || (dtype == MMD_BF16 && ch == 192 && impl == 0), "attn_fwd: head width %d needs the bf16 MFMA path (16..128 or 192)", ch);
   MMD_REQUIRE(q_per_group > 0 && (int64_t)(G - 1) * q_per_group < q_rows_per_batch, "attn_fwd: bad query grouping");
   MMD_REQUIRE(k_per_group > 0 && win > 0 && (int64_t)win * k_per_group <= k_rows_per_batch, "attn_fwd: key window exceeds the key rows");
   AttnParams p;

@@ -44,22 +44,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
                                                          float* __restrict__ a_out, float* __restrict__ b_out, float* __restrict__ mr_out) {
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
-  __shared__ float s_sum[256 * EPV];
-  __shared__ float s_sq[256 * EPV];
+  __shared__ float s_sum[2048];           // [rows per pass][C], C <= 2048
+  __shared__ float s_sq[2048];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int CV = C / EPV;                 // vecs per row (<= 256)
-  const int RPP = 256 / CV;               // rows per pass
-  const int col = tid % CV, rl = tid / CV;
-  float sum[EPV], sq[EPV];
-#pragma unroll
-  for (int j = 0; j < EPV; ++j) sum[j] = sq[j] = 0.f;
+  const int CV = C / EPV;                 // vecs per row; more than 256 (fp32 rows wider than 1024 channels - the SR U-Net's 1536-channel
+  const int CVB = min(CV, 256);           // skip concatenations in fp32 mode) are walked in column passes of 256 vectors, one row lane
+  const int RPP = 256 / CVB;              // rows per pass
+  const int col0 = tid % CVB, rl = tid / CVB;
   const int j0 = chunk * R;
   const int j1 = min(j0 + R, g.Tn);
   const int64_t base = slice_base(g, s);
   // shifted-data sums: pivot = first element of the group in the slice's first row (kills the
   // E[x^2]-E[x]^2 cancellation when a group carries a large common offset)
   const int cpg = C / GN_GROUPS;
+  for (int cp = 0; cp < CV; cp += 256) {
+  const int col = col0 + cp;
+  if (col >= CV) break;
+  float sum[EPV], sq[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) sum[j] = sq[j] = 0.f;
   float piv[EPV];
   {
     const int c0 = col * EPV;
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const char* __restrict_
       s_sum[rl * C + col * EPV + e] = sum[e];
       s_sq[rl * C + col * EPV + e] = sq[e];
     }
+  }
   }
   __syncthreads();
   // Group combine straight from the per-thread fp32 sums: a group owns RPP*cpg <= 64 of them (RPP*C/32 <= 8*EPV), eight
@@ -238,9 +243,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const char* __restrict__ 
   constexpr int EPV = Elt<T>::EPV;
   constexpr int ES = 16 / EPV;
   const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int CV = C / EPV, RPP = 256 / CV;
-  const int col = tid % CV, rl = tid / CV;
+  const int CV = C / EPV, CVB = min(CV, 256), RPP = 256 / CVB;      // CV > 256: column passes (see gn_partial_kernel)
+  const int col0 = tid % CVB, rl = tid / CVB;
   if (rl >= RPP) return;
+  for (int cp = 0; cp < CV; cp += 256) {
+  const int col = col0 + cp;
+  if (col >= CV) break;
   float av[EPV], bv[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; e += 4) {
@@ -274,6 +282,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const char* __restrict__ 
         *(u32x4*)(yp + (int64_t)j * ys) = Elt<T>::pack(f);
       }
     }
+  }
   }
 }
 
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(256) void add_rowbias_kernel(char* __restrict__ x, 
 static int check_geom(const char* who, int dtype, int C, int S, int Tn, int inner) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "%s: bad dtype %d", who, dtype);
-  MMD_REQUIRE(C % GN_GROUPS == 0 && C % epv == 0 && C / epv <= 256 && C <= 2048, "%s: unsupported channel count %d", who, C);
+  MMD_REQUIRE(C % GN_GROUPS == 0 && C % epv == 0 && C <= 2048, "%s: unsupported channel count %d", who, C);
   MMD_REQUIRE(S > 0 && Tn > 0 && inner > 0, "%s: empty slice geometry", who);
   return MMD_OK;
 }
@@ -577,6 +586,7 @@ extern "C" int mmd_gn_small(int dtype, const void* x, int64_t ldx, void* y, int6
                             float eps, int act, void* stream) {
   int rc = check_geom("gn_small", dtype, C, S, Tn, inner);
   if (rc) return rc;
+  MMD_REQUIRE(C / (dtype == MMD_BF16 ? 8 : 4) <= 256, "gn_small: rows of at most 256 16-byte vectors (C = %d)", C);
   MMD_REQUIRE(x && y && gamma && beta, "gn_small: null pointer");
   MMD_REQUIRE(Tn <= 16 && (C / GN_GROUPS) % 4 == 0, "gn_small: slices of at most 16 rows, groups of whole channel quads (got Tn=%d C=%d)", Tn, C);
   SliceGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};

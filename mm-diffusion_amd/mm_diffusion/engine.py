@@ -21,6 +21,9 @@ from . import ops
 from .ops import Geom
 
 
+_POOL_NOREUSE = os.environ.get("MMD_POOL_NOREUSE") == "1"      # diagnostics (tools/determinism_graph.py): every tensor keeps its own buffer
+
+
 class _Pool:
     """Plan-time buffer pool with reuse by liveness (run-time order == plan order on one stream)."""
 
@@ -43,7 +46,8 @@ class _Pool:
         return raw
 
     def put(self, raw):
-        self.free.append(raw)
+        if not _POOL_NOREUSE:
+            self.free.append(raw)
 
     def total_bytes(self):
         return sum(r.numel() for r in self.all)

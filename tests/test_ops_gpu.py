@@ -529,10 +529,12 @@ def test_gn_fused_into_conv1x1(ops, dt, N, C, F, H, W, Cout, film_on):
 
 
 @pytest.mark.parametrize("dt,C,R", [(torch.float32, 128, 1500), (torch.float32, 1024, 700), (torch.bfloat16, 64, 5000), (torch.bfloat16, 384, 1500),
-                                    (torch.bfloat16, 896, 900), (torch.bfloat16, 2048, 300)])
+                                    (torch.bfloat16, 896, 900), (torch.bfloat16, 2048, 300), (torch.float32, 1536, 300), (torch.float32, 2048, 37),
+                                    (torch.float32, 1536, 3)])
 def test_groupnorm_two_stage_path(ops, dt, C, R):
     """Slices longer than one block's share take the partial + finalize route (channel counts whose vectors do not tile the
-    256-thread block, and the 2048-channel SR width, included)."""
+    256-thread block, the 2048-channel SR width, and fp32 rows wider than 256 16-byte vectors - the SR U-Net's 1536-channel skip
+    concatenations in fp32 mode, walked in column passes - included; R = 3 / 37: the one-block route at those widths)."""
     N = 2
     x = (rnd(N * R, C, seed=67) * 1.5 - 0.3).to(dt).float()
     g, b, film = 1 + 0.1 * rnd(C, seed=68), rnd(C, seed=69), rnd(N, 2 * C, seed=70, scale=0.3)

@@ -86,7 +86,7 @@ def test_engine_uses_the_fused_halo_norm_and_matches_the_unfused_plan(monkeypatc
         outs.append((ov.clone(), oa.clone(), names.count("mmd_gn_conv_gemm"), names.count("mmd_gn_apply")))
         model.release_engines()
     assert outs[0][2] > 0 and outs[1][2] == 0 and outs[0][3] < outs[1][3]
-    assert rel_l2(outs[0][0], outs[1][0]) < 5e-3 and rel_l2(outs[0][1], outs[1][1]) < 5e-3
+    assert rel_l2(outs[0][0].cpu(), outs[1][0].cpu().numpy()) < 5e-3 and rel_l2(outs[0][1].cpu(), outs[1][1].cpu().numpy()) < 5e-3
 
 
 @pytest.mark.parametrize("dt", [torch.float32, BF])
@@ -124,11 +124,11 @@ def test_deep_ring_tile_statistics(ops):
     b = torch.randn(Cout, device="cuda", generator=g)
     recs = []
     for tile in (129, 132):
-        rec = torch.zeros(M // 64, Cout, 2, device="cuda")
+        rec = torch.zeros(M // 64, Cout // 4, 2, device="cuda")
         y = ops.conv_gemm(x, w, b, taps=ops.TAPS_TEMPORAL, dims=(16, 64, 1), tile=tile, stats=rec)
         recs.append((y.clone(), rec))
     assert torch.equal(recs[0][0], recs[1][0]) and torch.equal(recs[0][1], recs[1][1])
-    ysum = recs[0][0].float().reshape(M // 64, 64, Cout).sum(1)
+    ysum = recs[0][0].float().reshape(M // 64, 64, Cout // 4, 4).sum((1, 3))
     assert rel_l2(recs[1][1][:, :, 0].cpu(), ysum.cpu().numpy()) < 1e-5
 
 
@@ -273,7 +273,7 @@ def test_engine_tails_match_the_record_path(monkeypatch):
             res.append((ov.clone(), oa.clone()))
         names = [e[2] for e in next(iter(model._engines.values())).plan]
         assert ("mmd_gn_finalize_stats" in names) == (mode == "0")
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), f"mode {mode}: not repeatable"
         assert torch.equal(res[0][0][:1], res[2][0]) and torch.equal(res[0][0][1:], res[3][0]) and torch.equal(res[0][1][1:], res[3][1])
         outs[mode] = res[0]
         model.release_engines()
@@ -325,3 +325,29 @@ def test_attn_dma_kernel_is_bitwise_the_mfma_kernel(ops, name, N, F, qr, qg, kr,
         ops.attn(q, kv, o4, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=4)
         torch.cuda.synchronize()
         assert torch.equal(o2, o4), f"{name} shift {shift}: rel-L2 {rel_l2(o4.float().cpu(), o2.float().cpu().numpy()):.3e}"
+
+
+def test_graph_replays_are_bitwise_repeatable_under_two_stream_concurrency():
+    """400 replays of the mid-size plan (video and audio chains concurrent inside the hipGraph) on the same inputs: every replay bitwise
+    equal to the first.  Round 3 found 1 replay in ~130 off by 1e-2 rel-L2: gn_small_kernel's packed-fp32 accumulations went wrong in
+    lanes 48-63 when its waves shared a SIMD with the other stream's GroupNorm+SiLU-in-the-loader GEMM; the library is built without
+    packed fp32 since (build.py).  tools/determinism_*.py are the instruments that located it."""
+    import random
+    from helpers import flags, inputs
+    from mm_diffusion import multimodal_script_util as msu
+    from mm_diffusion.synth import synth_init_
+    fl = flags("mid", use_fp16=True)
+    model, _ = msu.create_model_and_diffusion(**fl)
+    synth_init_(model)
+    model.cuda().eval()
+    v, a = inputs(fl, 2, 3)
+    v, a, t = v.cuda(), a.cuda(), torch.tensor([17, 400]).cuda()
+
+    def run():
+        random.seed(5)
+        with torch.no_grad():
+            return model(v, a, t)
+    ref = run()
+    bad = [i for i in range(400) if not all(torch.equal(x, y) for x, y in zip(run(), ref))]
+    model.release_engines()
+    assert not bad, f"{len(bad)} of 400 replays differ from the first: {bad[:8]}"

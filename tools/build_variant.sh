@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../mm-diffusion_amd"
 NAME=$1; SRC=$2; FLAGS=$3
 mkdir -p lib/variants
 OBJ=lib/variants/${SRC%.hip}_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result $FLAGS -c csrc/$SRC -o $OBJ
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops $FLAGS -c csrc/$SRC -o $OBJ
 OTHERS=$(ls lib/mmd_*.o | grep -v "lib/${SRC%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/variants/libmmd_$NAME.so $OBJ $OTHERS
 rm -f $OBJ

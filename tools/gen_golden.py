@@ -273,6 +273,35 @@ def gen_train_loss(name, B, seed, **over):
          **{k: v for k, v in losses.items()}, **grads)
 
 
+def gen_train_grads_full(seed=71, stride=997):
+    """configs[3] at the shipped size, batch 1: loss terms, the L2 norm of EVERY parameter's gradient, and a strided subsample
+    (every `stride`-th element, flat order) of every gradient - the whole backward of multimodal_training_losses
+    (multimodal_gaussian_diffusion.py:1114-1203) at full size in ~2 MB."""
+    f = flags("full")
+    model, diff = msu.create_model_and_diffusion(**f)
+    synth_init(model).train()  # dropout p=0 -> deterministic
+    g = th.Generator().manual_seed(seed)
+    x0 = {"video": th.rand(1, *f["video_size"], generator=g) * 2 - 1, "audio": th.rand(1, *f["audio_size"], generator=g) * 2 - 1}
+    noise = {"video": th.randn(1, *f["video_size"], generator=g), "audio": th.randn(1, *f["audio_size"], generator=g)}
+    t = th.tensor([412], dtype=th.int64)
+    random.seed(seed)
+    with ShiftRecorder() as rec:
+        losses = diff.multimodal_training_losses(model, x0, t, noise=noise)
+    nfwd = len(rec.draws)
+    with ShiftRecorder() as rec2:
+        losses["loss"].mean().backward()
+    names, norms, subs, offs = [], [], [], [0]
+    for k, p in model.named_parameters():
+        gr = p.grad.detach().flatten()
+        names.append(k)
+        norms.append(float(gr.double().norm()))
+        subs.append(gr[::stride].clone())
+        offs.append(offs[-1] + subs[-1].numel())
+    save("full_train_grads", seed=seed, B=1, t=t, stride=stride, shifts_fwd=np.asarray(rec.draws[:nfwd]), shifts_bwd=np.asarray(rec2.draws),
+         names=np.asarray(names), norms=np.asarray(norms), sub=th.cat(subs), sub_off=np.asarray(offs),
+         **{k: v for k, v in losses.items()})
+
+
 def gen_ddim(name, B, seed, respacing, eta):
     """ddim_sample_loop (gd:955-1046) final sample; the loop draws x_T and per-step noise even with eta = 0."""
     f = flags(name, timestep_respacing=respacing)
@@ -415,6 +444,7 @@ ALL = {
                                         denoise=True),
     "dpmpp_adaptive2": lambda: gen_dpm("tiny_dpmpp_adaptive2", 65, True, True, steps=20, order=2, skip_type="logSNR", method="adaptive"),
     "dpm_adaptive3": lambda: gen_dpm("tiny_dpm_adaptive3", 66, False, False, order=3, method="adaptive", atol=0.05, rtol=0.1),
+    "full_train_grads": gen_train_grads_full,
     "tiny_train_loss": lambda: gen_train_loss("tiny", 2, 31),
     "tiny_ls_train_loss": lambda: gen_train_loss("tiny", 2, 32, learn_sigma=True),
     # non-FiLM ResBlocks (use_scale_shift_norm=False, unet:473-477): h + emb_out, then the plain norm
