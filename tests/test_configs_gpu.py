@@ -22,10 +22,10 @@ from helpers import flags, gold, rel_l2, synth_sd
 pytestmark = pytest.mark.gpu
 
 DRIFT_50 = 3e-2       # bf16 vs fp32-mode after 50 ancestral steps on identical noise; measured 1.4e-3 after 25 steps, 6.9e-3 / 5.0e-3 (video / audio) at the end
-DRIFT_250 = 5e-2      # the same over the 250 steps of configs[1], batch 1 (measured: see the test's printout in profiles/r03_parity.txt)
-GRAD_FP32 = 2e-3      # full-size gradients, fp32 mode vs the reference's CPU autograd (subsample rel-L2 and per-tensor norm)
-GRAD_BF16 = 8e-2      # the same in bf16
-SR_BF16 = 3e-2        # one full-size SR U-Net evaluation, bf16 vs fp32 mode (head width 192)
+DRIFT_250 = 2e-2      # the same over the 250 steps of configs[1], batch 1; measured 2.7e-4 / 9.5e-4 / 3.2e-3 / 6.9e-3 video (2.0e-4 ... 4.8e-3 audio) after 50 / 125 / 200 / 250 steps
+GRAD_FP32 = 1e-4      # full-size gradients, fp32 mode vs the reference's CPU autograd (subsample rel-L2 and per-tensor norm); measured 4.2e-6 / 3.9e-6
+GRAD_BF16 = 3e-2      # the same in bf16; measured 8.0e-3 / 8.2e-3
+SR_BF16 = 3e-2        # one full-size SR U-Net evaluation, bf16 vs fp32 mode (head width 192); measured 9.5e-3
 DPM_50 = 2e-2         # bf16 vs fp32-mode after 50 DPM-Solver++ evaluations with dynamic thresholding; measured 3.1e-3 / 2.7e-3
 
 
