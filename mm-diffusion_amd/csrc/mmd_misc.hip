@@ -468,6 +468,105 @@ extern "C" int mmd_copy2d(const void* x, int64_t ldx_bytes, void* y, int64_t ldy
   return mmd_check_launch("copy2d");
 }
 
+
+// MFMA stem conv (bf16 rows out; ntaps * Cin <= 28, Cout = 32 NB <= 128, W % 32 == 0): the 27-term dot products of the video stem on
+// the fp32 matrix pipe (v_mfma_f32_32x32x2f32: exact fp32 products, fp32 accumulation) instead of 0.9 G scalar FMAs - the strip kernel
+// above runs at 17 TFLOP/s of VALU (107 us for the 16 x 64 x 64 stem against an 8 us output write).  D[cout][pixel] = W[cout][k] X[k][pixel]:
+// a wave owns 32 consecutive pixels of one image row; lane (n = lane % 32, kk = lane / 32) gathers x for k = 2 s + kk straight from the
+// API-layout input (coalesced along w; padding reads as zero), the weights of the lane's output channel sit in registers for the whole
+// kernel, and the epilogue is the row-strip GEMM's: half-wave swap -> 8 consecutive channels per lane -> bias -> one 16-byte store.
+template <int NB>
+__global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const EdgeConvParams p) {
+  constexpr int MAXS = 14;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int K = p.ntaps * p.Cin, KS = (K + 1) >> 1;
+  float wreg[MAXS][NB];
+  int kd[MAXS];                                          // per step: this lane's (df, dh, dw, ci), or -1 past K
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const int k = 2 * s + half;
+    const bool kv = s < KS && k < K;
+    const int kc = kv ? k : 0, t = kc / p.Cin, ci = kc - t * p.Cin;
+    kd[s] = kv ? ((p.taps[t * 3] + 1) | ((p.taps[t * 3 + 1] + 1) << 2) | ((p.taps[t * 3 + 2] + 1) << 4) | (ci << 6)) : -1;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) wreg[s][b] = kv ? p.w[(int64_t)kc * p.Cout + b * 32 + l31] : 0.f;
+  }
+  const int HW = p.H * p.W, WG = p.W >> 5;
+  const int64_t groups = (int64_t)p.N * p.F * p.H * WG;
+  const int64_t nwave = (int64_t)gridDim.x * 4, wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  auto gather = [&](int64_t g, float (&xv)[MAXS]) {
+    const int w = (int)(g % WG) * 32 + l31;
+    int64_t r = g / WG;
+    const int h = (int)(r % p.H);
+    r /= p.H;
+    const int f = (int)(r % p.F);
+    const int64_t n = r / p.F;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      const int d = kd[s];
+      const int df = (d & 3) - 1, dh = ((d >> 2) & 3) - 1, dw = ((d >> 4) & 3) - 1, ci = (d >> 6) & 3;
+      const bool ok = d >= 0 && (unsigned)(f + df) < (unsigned)p.F && (unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w + dw) < (unsigned)p.W;
+      const int64_t src = (((n * p.F + (f + df)) * p.Cin + ci) * p.H + (h + dh)) * (int64_t)p.W + (w + dw);
+      xv[s] = ok ? p.x[src] : 0.f;
+    }
+  };
+  float xcur[MAXS], xnext[MAXS];
+  if (wave_id < groups) gather(wave_id, xcur);
+  for (int64_t g = wave_id; g < groups; g += nwave) {
+    if (g + nwave < groups) gather(g + nwave, xnext);    // the next group's gather flies under this group's MFMAs
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[s][b], xcur[s], acc[b], 0, 0, 0);
+    // acc[b][4 q + j] = channel 32 b + 8 q + 4 half + j of pixel l31: pair q = 2 j2 with q = 2 j2 + 1 across the half-waves
+    const int64_t m = g * 32 + l31;                      // groups walk the rows in order: 32 consecutive pixels of one image row
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[b][8 * j2 + j]), __float_as_uint(acc[b][8 * j2 + 4 + j]), false, false);
+          v[j] = __uint_as_float(sw[0]);
+          v[4 + j] = __uint_as_float(sw[1]);
+        }
+        const int col = b * 32 + 16 * j2 + 8 * half;
+        if (p.bias) {
+          const f32x4 b0 = *(const f32x4*)(p.bias + col), b1 = *(const f32x4*)(p.bias + col + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+        }
+        *(u32x4*)(p.y + (m * p.ldy + col) * 2) = Elt<__bf16>::pack(v);
+      }
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) xcur[s] = xnext[s];
+  }
+}
+
+static bool stem_mfma_ok(int dtype, const EdgeConvParams& p) {
+  static const bool on = [] { const char* e = getenv("MMD_STEM_MFMA"); return !(e && e[0] == '0'); }();
+  return on && dtype == MMD_BF16 && p.W % 32 == 0 && p.ntaps * p.Cin <= 28 && p.Cin <= 3 && p.Cout % 32 == 0 && p.Cout <= 128 && p.ldy % 8 == 0 &&
+         ((uintptr_t)p.y) % 16 == 0 && (!p.bias || ((uintptr_t)p.bias) % 16 == 0);
+}
+
+static int launch_stem_mfma(const EdgeConvParams& p, hipStream_t st) {
+  const int64_t groups = (int64_t)p.N * p.F * p.H * (p.W / 32);
+  const int grid = (int)min((int64_t)2048, (groups + 3) / 4);
+  switch (p.Cout / 32) {
+    case 1: hipLaunchKernelGGL(stem_conv_mfma_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL(stem_conv_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL(stem_conv_mfma_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL(stem_conv_mfma_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+  }
+  return mmd_check_launch("stem_conv_mfma");
+}
+
 extern "C" int mmd_stem_conv(int dtype, const float* x, const float* w, const float* bias, void* y, int64_t ldy, int N, int F,
                              int Cin, int H, int W, int Cout, int ntaps, const int* taps, void* stream) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
@@ -481,6 +580,7 @@ extern "C" int mmd_stem_conv(int dtype, const float* x, const float* w, const fl
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   const int64_t total = (int64_t)N * F * H * W * (Cout / epv);
   hipStream_t st = (hipStream_t)stream;
+  if (stem_mfma_ok(dtype, p)) return launch_stem_mfma(p, st);
   if (W % 4 == 0 && (Cin == 1 || Cin == 3) && Cout % 4 == 0) {
     const dim3 grid(ew_grid(total / 4));
     if (dtype == MMD_BF16 && Cin == 3) hipLaunchKernelGGL((stem_conv_strip_kernel<__bf16, 3>), grid, dim3(256), lds, st, p);
@@ -717,6 +817,12 @@ static int launch_head_coop(const HeadConvParams& p, int lpr, hipStream_t st) {
 #undef MMD_HEAD_LAUNCH
   return mmd_check_launch("head_conv_coop");
 }
+
+
+// (Round 3 tried the head as a GEMM on 32x32x16 MFMAs with the X fragments read straight from global memory - the output channels as
+// the mostly empty M side, fp32 weights split into two bf16 parts.  Correct, and slower: 270 us against the strip kernel's 160 us.  All
+// 27 taps re-read the tensor through the texture path, 1.8 GB per launch at the ~8 TB/s that 16-byte-per-lane row reads sustain; a
+// version that pays would stage a three-frame halo in LDS like the 3x3 conv tiles do.  Not built: the head is 1.3 % of the step.)
 
 template <typename T>
 static int launch_head(const HeadConvParams& p, hipStream_t st) {

@@ -21,6 +21,7 @@ from . import ops
 from .ops import Geom
 
 
+_EMB_ON_AUDIO_STREAM = os.environ.get("MMD_EMB_AUX", "1") != "0"
 _POOL_NOREUSE = os.environ.get("MMD_POOL_NOREUSE") == "1"      # diagnostics (tools/determinism_graph.py): every tensor keeps its own buffer
 
 
@@ -553,11 +554,19 @@ class UNetEngine:
     def _record(self, t_tensor, arch_in, arch_mid, arch_out):
         m, N, F, dt = self.model, self.N, self.F, self.dtype
         mc = self.mc
+        # fork first: the audio stream (which has ~3x less work per step than the video stream) computes the timestep embedding and the
+        # FiLM table of every ResBlock, while the video stream starts on its stem convs at once; the video stream picks the table up
+        # behind its stem (the first consumer is the first ResBlock's out-norm) - ~30 us off the step's critical path
         ops.cur_sid = 0
+        ops.record_sync(0, 1)      # the audio stream starts behind the host-side input copies
+        ops.cur_sid = 1 if _EMB_ON_AUDIO_STREAM else 0
         ops.temb(t_tensor, mc, self._f32("time_embed.0.weight"), self._f32("time_embed.0.bias"),
                  self._f32("time_embed.2.weight"), self._f32("time_embed.2.bias"), self.emb_silu)
         ops.linear(self.emb_silu, self.emb_W, self.emb_b, self.emb_all)
-        ops.record_sync(0, 1)      # fork: the audio stream starts once the FiLM table (and the host-side input copies) exist
+        ops.cur_sid = 0
+        film_joined = not _EMB_ON_AUDIO_STREAM
+        if not _EMB_ON_AUDIO_STREAM:
+            ops.record_sync(0, 1)  # (A/B switch: embedding on the video stream, the audio stream waits for the table)
 
         # consumer channel split of every skip: output block k reads [h (ch_prev) | skip (ich)]
         skip_cols = []
@@ -600,6 +609,8 @@ class UNetEngine:
                                   self._f32(p + ".video_conv.video_conv_temporal.bias"), **self._temporal(Hh), out=nv,
                                   **self._stats_kw(nv))
                     self._release(s1)
+                    ops.record_sync(1, 0)      # the FiLM table is ready (recorded behind the two embedding launches only)
+                    film_joined = True
                     ops.cur_sid = 1
                     na = ta if ta is not None else self._alloc(N * L, C0)
                     ops.stem_conv(self.x_audio, self._edge_w(p + ".audio_conv.audio_conv.weight"),
@@ -607,6 +618,9 @@ class UNetEngine:
                                   [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
                     ops.cur_sid = 0
                 elif layer["kind"] == "res":
+                    if not film_joined:        # (an architecture without an init layer in front of its first ResBlock)
+                        ops.record_sync(1, 0)
+                        film_joined = True
                     nv, na, Hh, L = self._res(v, a, layer, Hh, L, tv, ta)
                 else:
                     nv, na = self._cross(v, a, layer, Hh, L, tv, ta)

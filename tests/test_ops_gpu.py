@@ -452,9 +452,10 @@ def test_temb_and_linear(ops):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("H,W,L,C", [(8, 6, 50, 64), (4, 8, 52, 128), (5, 12, 8, 32)])
+@pytest.mark.parametrize("H,W,L,C", [(8, 6, 50, 64), (4, 8, 52, 128), (5, 12, 8, 32), (5, 32, 40, 128), (3, 64, 36, 64)])
 def test_stem_and_head(ops, dt, H, W, L, C):
-    """Per-pixel kernels (W, L not multiples of 4) and the four-pixel strip kernels (W % 4 == 0)."""
+    """Per-pixel kernels (W, L not multiples of 4), the four-pixel strip kernels (W % 4 == 0) and, in bf16 at W % 32 == 0, the stem on
+    the fp32 MFMA (fp32 x fp32 products, fp32 accumulation)."""
     N, F = 2, 3
     xv = rnd(N, F, 3, H, W, seed=39)
     ws, bs = rnd(C, 3, 3, 3, seed=40, scale=27 ** -0.5), rnd(C, seed=41)
