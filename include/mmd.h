@@ -242,7 +242,9 @@ int mmd_loss_terms(const float* x0, const float* xt, const float* model_out, con
 
 /* ---------------------------------------------------------------- training step: backward kernels (gd:1114-1203 backward)
  * conv wgrad: dW fp32 [Cout][ntaps*Cin] += dY^T gather(X) (same tap semantics as mmd_conv_gemm; caller zeroes dW), db
- * (nullable, fp32 [Cout]) += column sums of dY.  conv dgrad = mmd_conv_gemm(dY, W^T-packed, taps negated). */
+ * (nullable, fp32 [Cout]) += column sums of dY.  conv dgrad = mmd_conv_gemm(dY, W^T-packed, taps negated).  bf16 with >= 64 channels on
+ * both sides: 128 x 128 MFMA tiles split over M with fp32 atomics (the accumulation order - and the last bit - varies from run to run,
+ * like the reference's autograd); 9-tap convs stage row-major by descriptor DMA and read both operands with transposing LDS reads. */
 int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, float* db, int M, int Cout, int Cin,
                    int ntaps, const int* taps, int D0, int D1, int D2, int torch_layout, void* stream);
 /* Re-pack every conv weight in ONE launch after an optimizer step.  descs_dev: device array of n records

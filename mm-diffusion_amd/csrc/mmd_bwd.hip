@@ -232,6 +232,153 @@ __global__ __launch_bounds__(256, 2) void wgrad128_bf16_kernel(const WgradParams
     }
 }
 
+
+// bf16 weight gradient, round 3: the same 128 (co) x 128 (ci of ONE tap) tile per block, 4 waves each 64 x 64, but nothing is transposed
+// by the kernel.  The reduction index is the row m, so both MFMA operands want 8 consecutive ROWS of one channel per lane - exactly what
+// ds_read_b64_tr_b16 returns from a ROW-MAJOR tile.  A 64-row chunk of dY and of X therefore goes global -> LDS by buffer-descriptor DMA
+// (no VGPR staging, no ds_write; a padding row or a row past the split is an out-of-range offset and lands as zeros), in the tile format
+// of the attention kernel's V ([plane of 64 channels][64 rows][128 B], 16-byte chunk ^ (((row >> 1) & 1) << 2)), double buffered with one
+// barrier per chunk; a fragment is two transposing reads.  wgrad128_bf16_kernel above spent 64 ds_write_b16 + 12 integer divisions per
+// thread and chunk on what the DMA and two float reciprocals do here.  The column sums (bias gradient) take the colsum launch.
+__device__ __forceinline__ int wg_fdiv(int n, int d, float rd) {       // n / d for 0 <= n < 2^24 (the launcher checks M)
+  int q = (int)((float)n * rd);
+  const int r = n - q * d;
+  q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(const WgradParams p) {
+  constexpr int PLANE_B = 64 * 128, OP_B = 2 * PLANE_B, STAGE_B = 2 * OP_B;
+  extern __shared__ __attribute__((aligned(16))) char smem_w[];        // [2 stages][dY | X][2 planes][64 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 1, wj = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = (p.Cin + 127) / 128;
+  const int kt_blk = blockIdx.y;
+  const int tap = kt_blk / ci_tiles, ci0 = (kt_blk % ci_tiles) * 128;
+  const int co0 = blockIdx.x * 128;
+  const int o0 = p.taps[tap * 3], o1 = p.taps[tap * 3 + 1], o2 = p.taps[tap * 3 + 2];
+  const int D12 = p.D1 * p.D2;
+  const int roff = o0 * D12 + o1 * p.D2 + o2;
+  const bool shifted = (o0 | o1 | o2) != 0;
+  const float rD2 = 1.f / (float)p.D2, rD1 = 1.f / (float)p.D1, rD0 = 1.f / (float)p.D0;
+  const int m_begin = blockIdx.z * p.rows_per_split;
+  const int m_end = min(m_begin + p.rows_per_split, p.M);
+
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const auto rsrcY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, (int)((int64_t)p.M * p.lddy * 2), 0x00020000);
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((int64_t)p.M * p.ldx * 2), 0x00020000);
+  // DMA: wave w stages row groups {w, w + 4} of every plane; lane L of a group covers row 8 g + L / 8, physical chunk L % 8
+  const int lrow = lane >> 3, pc = lane & 7;
+  int drow[2];
+  uint32_t ycol[2][2], xcol[2][2];            // [row group][plane]: byte column of the lane's (logical) chunk, or ~0 past the channel count
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + 4 * i) + lrow;
+    drow[i] = row;
+    const int lc = pc ^ (((row >> 1) & 1) << 2);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int co = co0 + 64 * pl + 8 * lc, ci = ci0 + 64 * pl + 8 * lc;
+      ycol[i][pl] = co < p.Cout ? (uint32_t)(co * 2) : 0xffffffffu;
+      xcol[i][pl] = ci < p.Cin ? (uint32_t)(ci * 2) : 0xffffffffu;
+    }
+  }
+  const uint32_t ldyb = (uint32_t)(p.lddy * 2), ldxb = (uint32_t)(p.ldx * 2);
+  auto issue = [&](int stage, int mc) {
+    char* sb = smem_w + stage * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mc + drow[i];
+      const bool okm = m < m_end;
+      bool okx = okm;
+      if (shifted) {
+        const int q1 = wg_fdiv(m, p.D2, rD2), p2 = m - q1 * p.D2;
+        const int q2 = wg_fdiv(q1, p.D1, rD1), p1 = q1 - q2 * p.D1;
+        const int q3 = wg_fdiv(q2, p.D0, rD0), p0 = q2 - q3 * p.D0;
+        okx = okm && (unsigned)(p0 + o0) < (unsigned)p.D0 && (unsigned)(p1 + o1) < (unsigned)p.D1 && (unsigned)(p2 + o2) < (unsigned)p.D2;
+      }
+      const uint32_t yrow = (uint32_t)m * ldyb, xrow = (uint32_t)(m + roff) * ldxb;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const uint32_t yo = okm && ycol[i][pl] != 0xffffffffu ? yrow + ycol[i][pl] : 0xfffffff0u;
+        const uint32_t xo = okx && xcol[i][pl] != 0xffffffffu ? xrow + xcol[i][pl] : 0xfffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lptr_t)(sb + pl * PLANE_B + (wave + 4 * i) * 1024), 16, yo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lptr_t)(sb + OP_B + pl * PLANE_B + (wave + 4 * i) * 1024), 16, xo, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // transposing reads: this lane supplies row base + 4 half + (lane & 15) / 4, byte column 32 ((lane >> 4) & 1) + 8 (lane & 3) of a 64-byte
+  // channel tile, and receives the four rows base + 4 half + [0, 4) of channel l31 of that tile
+  const int vrow0 = 4 * half + ((lane & 15) >> 2);
+  const int vcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lp4;
+  auto frag = [&](const char* plane, int rbase, int ct) -> bf16x8 {
+    s16x4 lo, hi;
+    {
+      const int row = rbase + vrow0;
+      const int ch = ((vcolb >> 4) + 4 * ct) ^ (((row >> 1) & 1) << 2);
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(plane + row * 128 + ch * 16 + (vcolb & 15)));
+    }
+    {
+      const int row = rbase + 8 + vrow0;
+      const int ch = ((vcolb >> 4) + 4 * ct) ^ (((row >> 1) & 1) << 2);
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(plane + row * 128 + ch * 16 + (vcolb & 15)));
+    }
+    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, both);
+  };
+
+  int stage = 0;
+  if (m_begin < m_end) issue(0, m_begin);
+  for (int mc = m_begin; mc < m_end; mc += 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this chunk's DMA (the only one in flight) has landed
+    __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is past its reads of the other stage
+    asm volatile("" ::: "memory");
+    if (mc + 64 < m_end) issue(stage ^ 1, mc + 64);         // in flight under this chunk's MFMAs
+    const char* pa = smem_w + stage * STAGE_B + wi * PLANE_B;
+    const char* pb = smem_w + stage * STAGE_B + OP_B + wj * PLANE_B;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                        // 16 rows per k-step
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = frag(pa, 16 * ks, a);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = frag(pb, 16 * ks, b);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    stage ^= 1;
+  }
+  // D[row = co][col = ci]: lane holds ci = l31, co = (r&3) + 8*(r>>2) + 4*half of its 32x32 tile
+  const int64_t K = (int64_t)p.Cin * p.ntaps;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ci = ci0 + wj * 64 + b * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < p.Cout && ci < p.Cin)
+          atomicAdd(p.dW + (int64_t)co * K + (p.torch_layout ? (int64_t)ci * p.ntaps + tap : (int64_t)tap * p.Cin + ci), acc[a][b][r]);
+      }
+    }
+}
+
 // db[c] += sum over rows of dY[m, c]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const char* __restrict__ dy, int64_t ld, int M, int C, float* __restrict__ out,
@@ -530,9 +677,25 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
     int splits = max(1, min(cdiv(M, 256), target / max(tiles, 1)));
     p.rows_per_split = cdiv(cdiv(M, splits), 64) * 64;
     splits = cdiv(M, p.rows_per_split);
-    p.db = db;                                                   // column sums ride in the (tap 0, ci tile 0) blocks: no colsum launch
-    hipLaunchKernelGGL(wgrad128_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), 0, st, p);
-    return mmd_check_launch("conv_wgrad");
+    // DMA-staged kernel (round 3; MMD_WGRAD_TR=0: the transposed-staging kernel): 32-bit byte offsets, float-reciprocal row positions
+    static const bool use_tr = [] { const char* e = getenv("MMD_WGRAD_TR"); return !(e && e[0] == '0'); }();
+    // measured (tools/wgrad_bench.py, batch 8): 3x3 ds1 128->128 436 -> 372 us, ds2 256->256 405 -> 251, ds4 384->384 240 -> 180, ds8 130 -> 110;
+    // the 1x1 / k=3 convs lose what the separate colsum launch costs (1x1 ds1: 82 -> 127 us), so they stay on the older kernel
+    if (use_tr && ntaps >= 9 && M < (1 << 24) && (int64_t)M * lddy * 2 < 0x7fffffffLL && (int64_t)M * ldx * 2 < 0x7fffffffLL) {
+      const size_t lds = 2 * 4 * 64 * 128;
+      static bool attr_done[MMD_MAX_DEVICES] = {};
+      bool& attr_set = attr_done[mmd_device_slot()];
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_tr_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_wgrad: set LDS attr: %s", hipGetErrorString(e));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(wgrad_tr_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), lds, st, p);
+    } else {
+      p.db = db;                                                 // column sums ride in the (tap 0, ci tile 0) blocks: no colsum launch
+      hipLaunchKernelGGL(wgrad128_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), 0, st, p);
+      return mmd_check_launch("conv_wgrad");
+    }
   } else {
     const int tiles = cdiv(Cout, 64) * cdiv(Cin, 64) * ntaps;
     int splits = max(1, min(cdiv(M, 256), 2048 / max(tiles, 1)));
