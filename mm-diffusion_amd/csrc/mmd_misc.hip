@@ -476,7 +476,7 @@ extern "C" int mmd_copy2d(const void* x, int64_t ldx_bytes, void* y, int64_t ldy
 // API-layout input (coalesced along w; padding reads as zero), the weights of the lane's output channel sit in registers for the whole
 // kernel, and the epilogue is the row-strip GEMM's: half-wave swap -> 8 consecutive channels per lane -> bias -> one 16-byte store.
 template <int NB>
-__global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const EdgeConvParams p) {
+__global__ __launch_bounds__(256, 2) void stem_conv_mfma_kernel(const EdgeConvParams p) {
   constexpr int MAXS = 14;
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int K = p.ntaps * p.Cin, KS = (K + 1) >> 1;
@@ -503,14 +503,16 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const EdgeConvParam
     const int64_t n = r / p.F;
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-      const int d = kd[s];
-      const int df = (d & 3) - 1, dh = ((d >> 2) & 3) - 1, dw = ((d >> 4) & 3) - 1, ci = (d >> 6) & 3;
-      const bool ok = d >= 0 && (unsigned)(f + df) < (unsigned)p.F && (unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w + dw) < (unsigned)p.W;
-      const int64_t src = (((n * p.F + (f + df)) * p.Cin + ci) * p.H + (h + dh)) * (int64_t)p.W + (w + dw);
-      xv[s] = ok ? p.x[src] : 0.f;
+      if (s < KS) {                                        // uniform: the audio stem (3 taps x 1 channel) has two steps, not fourteen
+        const int d = kd[s];
+        const int df = (d & 3) - 1, dh = ((d >> 2) & 3) - 1, dw = ((d >> 4) & 3) - 1, ci = (d >> 6) & 3;
+        const bool ok = d >= 0 && (unsigned)(f + df) < (unsigned)p.F && (unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w + dw) < (unsigned)p.W;
+        const int64_t src = (((n * p.F + (f + df)) * p.Cin + ci) * p.H + (h + dh)) * (int64_t)p.W + (w + dw);
+        xv[s] = ok ? p.x[src] : 0.f;
+      }
     }
   };
-  float xcur[MAXS], xnext[MAXS];
+  float xcur[MAXS] = {}, xnext[MAXS] = {};
   if (wave_id < groups) gather(wave_id, xcur);
   for (int64_t g = wave_id; g < groups; g += nwave) {
     if (g + nwave < groups) gather(g + nwave, xnext);    // the next group's gather flies under this group's MFMAs
@@ -520,9 +522,12 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const EdgeConvParam
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s)
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < KS) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[s][b], xcur[s], acc[b], 0, 0, 0);
+        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[s][b], xcur[s], acc[b], 0, 0, 0);
+      }
+    }
     // acc[b][4 q + j] = channel 32 b + 8 q + 4 half + j of pixel l31: pair q = 2 j2 with q = 2 j2 + 1 across the half-waves
     const int64_t m = g * 32 + l31;                      // groups walk the rows in order: 32 consecutive pixels of one image row
 #pragma unroll
@@ -545,12 +550,14 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const EdgeConvParam
         *(u32x4*)(p.y + (m * p.ldy + col) * 2) = Elt<__bf16>::pack(v);
       }
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) xcur[s] = xnext[s];
+    for (int s = 0; s < MAXS; ++s) xcur[s] = s < KS ? xnext[s] : 0.f;
   }
 }
 
 static bool stem_mfma_ok(int dtype, const EdgeConvParams& p) {
   static const bool on = [] { const char* e = getenv("MMD_STEM_MFMA"); return !(e && e[0] == '0'); }();
+  for (int i = 0; i < p.ntaps * 3; ++i)
+    if (p.taps[i] < -1 || p.taps[i] > 1) return false;          // the kernel packs a tap offset + 1 into two bits
   return on && dtype == MMD_BF16 && p.W % 32 == 0 && p.ntaps * p.Cin <= 28 && p.Cin <= 3 && p.Cout % 32 == 0 && p.Cout <= 128 && p.ldy % 8 == 0 &&
          ((uintptr_t)p.y) % 16 == 0 && (!p.bias || ((uintptr_t)p.bias) % 16 == 0);
 }
