@@ -158,6 +158,48 @@ def cpu_baseline(fl, seconds_budget=30.0):
                       f" of the Landscape base model, fp32, oracle/unet_ref.py on {cores} host threads (of {ncpu}); value = the better of the two"}
 
 
+def wgrad_roofline(B, device):
+    """The training step's dominant kernel family - the conv weight gradients (22 % of the step's kernel time, profiles/r02_train_step_
+    kernel_stats.txt) - measured live with HIP events on the launch stream, on the video 3x3 / k=3 / 1x1 layer shapes of the step at this
+    batch size: algorithmic flops (2 M Cout Cin taps) / average launch time against the dense bf16 MFMA peak."""
+    import ctypes
+    from mm_diffusion import _hip as H, ops
+    F, HW = 16, 64
+    shapes = [("3x3 ds1 128->128", B * F * HW * HW, 128, 128, ops.TAPS_SPATIAL, (B * F, HW, HW)), ("k3t ds1 128->128", B * F * HW * HW, 128, 128, ops.TAPS_TEMPORAL, (F, HW * HW, 1)),
+              ("1x1 ds1 128->128", B * F * HW * HW, 128, 128, ops.TAPS_1, (1, 1, 1)), ("3x3 ds2 256->256", B * F * HW * HW // 4, 256, 256, ops.TAPS_SPATIAL, (B * F, HW // 2, HW // 2)),
+              ("3x3 ds4 384->384", B * F * HW * HW // 16, 384, 384, ops.TAPS_SPATIAL, (B * F, HW // 4, HW // 4)), ("3x3 ds8 512->512", B * F * HW * HW // 64, 512, 512, ops.TAPS_SPATIAL, (B * F, HW // 8, HW // 8))]
+    ev = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for e in ev:
+        H.call("mmd_event_create", ctypes.byref(e))
+    st = H.stream_handle()
+    per, flops, us = {}, 0.0, 0.0
+    g = torch.Generator(device=device).manual_seed(0)
+    for name, M, Cin, Cout, taps, dims in shapes:
+        x = torch.randn(M, Cin, device=device, generator=g).to(torch.bfloat16)
+        dy = torch.randn(M, Cout, device=device, generator=g).to(torch.bfloat16)
+        dW, db = torch.zeros(Cout, Cin * len(taps), device=device), torch.zeros(Cout, device=device)
+        ops.conv_wgrad(dy, x, dW, db, taps, dims)
+        H.call("mmd_event_record", ev[0], st)
+        for _ in range(3):
+            ops.conv_wgrad(dy, x, dW, db, taps, dims)
+        H.call("mmd_event_record", ev[1], st)
+        torch.cuda.synchronize()
+        ms = ctypes.c_float()
+        H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
+        t = ms.value / 3 * 1e3
+        fl = 2.0 * M * Cout * Cin * len(taps)
+        per[name] = {"us": round(t, 1), "TFLOPs": round(fl / t / 1e6, 1)}
+        flops += fl
+        us += t
+        del x, dy, dW, db
+    for e in ev:
+        H.lib().mmd_event_destroy(e)
+    ach = flops / us / 1e6
+    return {"kernel": "conv_wgrad (wgrad_tr_bf16 / wgrad128_bf16 + colsum)", "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "per_shape": per,
+            "note": "launch-weighted over six layer shapes of the step at this batch size, HIP events on the launch stream"}
+
+
 def train_bench(args, world, rank, device):
     """BASELINE configs[3]: multimodal_training_losses step (forward + backward + flat AdamW/EMA, gradient all-reduce when
     world > 1) of the AIST++/Landscape base model, per-GPU batch --batch, bf16 activations, dropout 0.1, t ~ U{0..999}."""
@@ -217,6 +259,9 @@ def train_bench(args, world, rank, device):
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    roof = None
+    if rank == 0 and not args.no_breakdown:
+        roof = wgrad_roofline(B, device)
     if rank == 0:
         print(json.dumps({
             "metric": "training steps/sec (multimodal_training_losses fwd+bwd+AdamW, video+audio pairs)", "value": args.steps * B * world / elapsed,
@@ -225,7 +270,7 @@ def train_bench(args, world, rank, device):
             "config": {"workload": f"BASELINE configs[3]: base model training step, per-GPU batch {B}, dropout 0.1, flat-buffer gradient all-reduce, "
                                    f"{'eager' if gstep is None else 'graph-captured forward+backward'}",
                        "global_batch": B * world, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9},
-            "host_ms_per_step": 1000 * host_elapsed / args.steps,
+            "host_ms_per_step": 1000 * host_elapsed / args.steps, "roofline": roof,
             "model_tflops": 3 * MODEL_FLOPS_PER_PAIR * B * args.steps / elapsed / 1e12}))
     if world > 1:
         dist.barrier()
