@@ -322,3 +322,15 @@ def test_retired_handles_are_only_destroyed_by_reap():
     _hip.retire("event", 1234)
     assert _hip._retired[-1] == ("event", 1234)
     _hip._retired.pop()
+
+
+def test_transposing_read_tile_model():
+    """tools/tr_read_model.py: the row-major, two-row-swizzled LDS plane written by the descriptor DMA and read with ds_read_b64_tr_b16
+    (attention V operand, both operands of the 9-tap weight gradient): every lane of every fragment receives exactly the eight rows of
+    its channel that the MFMA k-slots stand for, and the two half-waves cover the sixteen rows of a k-step once."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("tr_read_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tr_read_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.check()
