@@ -15,8 +15,15 @@ from helpers import flags, gold, inputs, rel_l2, synth_sd
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
-LOOP_TOL = {torch.float32: 5e-4, torch.bfloat16: 1e-1}
+# Stated bounds = ~1.5x the distances measured on the MI355X at the round-3 build (profiles/r03_parity_model_tests.txt; the outputs are
+# bitwise repeatable, so the margin is for future kernel changes, not for noise).  Forward: fp32 1.8e-6 ... 2.4e-6, bf16 1.3e-2 ... 1.6e-2.
+FWD_TOL = {torch.float32: 2e-5, torch.bfloat16: 2.5e-2}
+# Loops, per fixture (video / audio measured): the epsilon -> x0 map multiplies the model error by sqrt(1 / abar_t - 1) ~ 157 at t = 999, so
+# the 2-step loops (t = 999, 499) sit far above the 4-step one; learn_sigma adds the interpolated log-variance of a bf16 output.
+LOOP_TOL = {torch.float32: 1e-4, torch.bfloat16: 7.5e-2}      # full-size 2-step: fp32 2.4e-5 / 1.5e-5, bf16 4.9e-2 / 4.8e-2
+LOOP_TOL_BF16 = {"tiny_psample2": 9e-2,                      # 5.4e-2 / 6.4e-2
+                 "tiny_psample4": 3e-2,                      # 1.7e-2 / 1.6e-2
+                 "tiny_ls_psample2": 1.2e-1}                 # 7.9e-2 / 8.5e-2   (fp32, all three: 3e-6 ... 1.7e-5)
 
 
 def build(cfgname, keyset, dt, **over):
@@ -97,11 +104,7 @@ def test_psample_loop_matches_reference(use_graph, dt, tag, cfgname, keyset, res
         final = s
     ev, ea = rel_l2(final["video"].cpu(), g["video"]), rel_l2(final["audio"].cpu(), g["audio"])
     print(f"{tag} {dt} graph={use_graph}: rel-L2 video {ev:.3e} audio {ea:.3e}")
-    tol = LOOP_TOL[dt] * (2 if resp == "4" else 1)
-    if dt == torch.bfloat16 and over.get("learn_sigma"):
-        # x_{t-1} = mean + exp(logvar/2) z with logvar interpolated from a bf16 network output: the bf16-vs-fp32-oracle distance of
-        # this 2-step loop sits at 0.07-0.10 depending on fp32 summation order inside the kernels (no low-precision oracle exists)
-        tol *= 1.5
+    tol = LOOP_TOL[dt] if dt == torch.float32 else LOOP_TOL_BF16[tag]
     assert ev < tol and ea < tol
 
 

@@ -5,7 +5,11 @@ import pytest
 import torch
 
 from helpers import flags, gold, rel_l2
-from test_model_gpu import LOOP_TOL, build, cpu_noise_source, replay
+from test_model_gpu import build, cpu_noise_source, replay
+
+# 4-step DDIM / replacement / gradient-guided loops of the tiny config vs the reference fixtures; measured (MI355X, round 3,
+# profiles/r03_parity_model_tests.txt): fp32 4e-8 ... 1.3e-5, bf16 1.4e-2 ... 2.6e-2
+API_TOL = {torch.float32: 1e-4, torch.bfloat16: 4e-2}
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +33,7 @@ def test_ddim_loop_matches_reference(use_graph, dt, tag, eta):
         final = s
     ev, ea = rel_l2(final["video"].cpu(), g["video"]), rel_l2(final["audio"].cpu(), g["audio"])
     print(f"{tag} {dt} graph={use_graph}: rel-L2 video {ev:.3e} audio {ea:.3e}")
-    assert ev < 2 * LOOP_TOL[dt] and ea < 2 * LOOP_TOL[dt]
+    assert ev < API_TOL[dt] and ea < API_TOL[dt]
 
 
 def test_ddim_reverse_then_forward_round_trip():
@@ -63,7 +67,7 @@ def test_conditional_replacement_matches_reference(use_graph, dt):
         final = s
     ev, ea = rel_l2(final["video"].cpu(), g["video"]), rel_l2(final["audio"].cpu(), g["audio"])
     print(f"cond replace {dt} graph={use_graph}: rel-L2 video {ev:.3e} audio {ea:.3e}")
-    assert ev < 2 * LOOP_TOL[dt] and ea < 2 * LOOP_TOL[dt]
+    assert ev < API_TOL[dt] and ea < API_TOL[dt]
 
 
 @pytest.mark.parametrize("tag,which,resp", [("tiny_cond_video_guided4", "video", "4"), ("tiny_cond_audio_guided2", "audio", "2")])
@@ -80,7 +84,7 @@ def test_gradient_guided_sampling_matches_reference(tag, which, resp):
                                        device=torch.device("cuda"), progress=False, class_scale=float(g["class_scale"]))
     ev, ea = rel_l2(x["video"].cpu(), g["video"]), rel_l2(x["audio"].cpu(), g["audio"])
     print(f"{tag}: rel-L2 video {ev:.3e} audio {ea:.3e}")
-    assert ev < LOOP_TOL[torch.float32] * 2 and ea < LOOP_TOL[torch.float32] * 2
+    assert ev < API_TOL[torch.float32] and ea < API_TOL[torch.float32]
     assert all(p.requires_grad for p in model.parameters())          # the temporary freeze is undone
 
 
