@@ -188,6 +188,21 @@ int mmd_gn_conv_gemm(int dtype, const void* A, int64_t lda, const float* gn_a, c
                      int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                      int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile, void* stream);
 
+/* VideoConv '2d+1d' in ONE launch (round 4): Y = conv1d_t(conv2d_s(act(X * gn_a[s] + gn_b[s]))) - the per-frame 3x3 conv, then the
+ * per-pixel k=3 conv along the 16 frames (unet:83-99), with the ResBlock in_layers GroupNorm32 + SiLU applied to the staged input
+ * (unet:339-340,457-458; nn.py:16-33; gn_a == NULL: plain conv) and, optionally, the statistics of Y for the out_layers norm
+ * (quad records as mmd_conv_gemm_stats writes them; 4 records per block: record (n * H * W / 16 + patch) * 4 + frame group, i.e.
+ * records are only meaningful to norms whose slices are whole samples).  bf16; X rows [N * 16 * H * W, Cin] (row stride ldx), Y rows
+ * [.., 128]; F == 16, Cout == 128, Cin % 32 == 0, H % 4 == 0, W % 4 == 0; norm slices = whole samples.  The spatial result is rounded
+ * to bf16 with its bias before the temporal conv (what a two-launch path stores); zero padding pads the NORMALISED activation.
+ * Wf: the weight image of mmd_vconv2d1d_pack (mmd_vconv2d1d_weight_bytes(Cin) bytes) built from the packed spatial [128][9 * Cin]
+ * and temporal [128][3 * 128] matrices (K index = tap * C + ci). */
+int64_t mmd_vconv2d1d_weight_bytes(int Cin);
+int mmd_vconv2d1d_pack(const void* Ws, const void* Wt, void* out, int Cin, int Cout, void* stream);
+int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, const float* gn_b, int act, int S, int64_t rows_per_slice,
+                  const void* Wf, const float* bias_s, const float* bias_t, void* Y, int64_t ldy, int N, int F, int H, int W,
+                  int Cin, int Cout, float* stats, int64_t stats_ld, void* stream);
+
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).
  * For batch n, group g (< G): queries = Q rows n*q_rows_per_batch + g*q_per_group + [0, q_per_group) (the last

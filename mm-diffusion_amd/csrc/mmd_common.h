@@ -105,6 +105,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum over the 32 lanes of each half-wave without LDS traffic or selects: four DPP row rotations give every lane of a 16-lane row the
+// row total, row_bcast:15 then adds the total of rows 0 / 2 into rows 1 / 3.  Valid in lanes 16-31 (half 0) and 48-63 (half 1).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float halfwave_total(float v) {
+  v = dpp_add<0x128, 0xf>(v);      // row_ror:8
+  v = dpp_add<0x124, 0xf>(v);      // row_ror:4
+  v = dpp_add<0x122, 0xf>(v);      // row_ror:2
+  v = dpp_add<0x121, 0xf>(v);      // row_ror:1
+  return dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+}
+
+
 // ----------------------------------------------------------------------------- in-launch GroupNorm statistics ("tail", include/mmd.h)
 // A partial sum p (fp32) enters a 64-bit integer accumulator pair exactly: hi = rint(p 2^H), lo = rint((p - hi 2^-H) 2^(H+24)) - both
 // exact in fp32 arithmetic for |p| < 2^(31-H) - so the accumulated total hi 2^-H + lo 2^-(H+24) is the EXACT sum of the partials,

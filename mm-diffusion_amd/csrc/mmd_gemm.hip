@@ -1368,21 +1368,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 // recursive-halving butterfly over the 32 lanes of a half-wave), so launches that emit statistics are chosen by layer geometry,
 // never by timing (ops.strip_tile_pinned).
 // Grid = row strips x nsplit column ranges (nsplit fills the chip when M is small; results do not depend on it).
-// Sum over the 32 lanes of each half-wave without LDS traffic or selects (round 3: the shuffle butterfly above compiled to 64
-// ds_bpermute + 121 v_cndmask per chunk): four DPP row rotations give every lane of a 16-lane row the row total, row_bcast:15 then
-// adds the total of rows 0 / 2 into rows 1 / 3.  Valid in lanes 16-31 (half 0) and 48-63 (half 1).
-template <int CTRL, int ROWS>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, false));
-}
-__device__ __forceinline__ float halfwave_total(float v) {
-  v = dpp_add<0x128, 0xf>(v);      // row_ror:8
-  v = dpp_add<0x124, 0xf>(v);      // row_ror:4
-  v = dpp_add<0x122, 0xf>(v);      // row_ror:2
-  v = dpp_add<0x121, 0xf>(v);      // row_ror:1
-  return dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-}
-
+// (halfwave_total - the DPP fold of the quad statistics - lives in mmd_common.h: the fused VideoConv kernel shares it.)
 __device__ __forceinline__ float halfwave_sum16(const float (&u)[16], int l31) {
   // sum of u[i] over the 32 lanes of a half-wave for all sixteen i at once: each xor step halves what a lane carries; the lane
   // ends with the total of u[l31 >> 1] (the xor-1 step completes it in both lanes of a pair)

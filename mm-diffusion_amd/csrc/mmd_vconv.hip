@@ -1,0 +1,501 @@
+// Fused VideoConv '2d+1d' (reference multimodal_unet.py:83-99: video_conv_spatial 3x3 per frame, then video_conv_temporal k=3 per
+// pixel) with the GroupNorm32(+SiLU) of the ResBlock in_layers in front of it (unet:339-340,457-458; nn.py:16-33) and the statistics
+// of its output for the out_layers norm behind it - one launch instead of {gn_apply | 3x3 conv | k=3 conv} and no intermediate in HBM.
+//
+// Block = a 4 x 4 pixel patch of ALL 16 frames of one sample: 256 output rows x 128 channels, 8 waves (4 frame groups x 2 column
+// halves, a 64 x 64 output tile each, 2 x 2 v_mfma_f32_32x32x16_bf16 accumulators).  Because every frame of the patch lives in the
+// block the temporal conv needs no halo in time and recomputes nothing:
+//   phase 1 (spatial, K = 9 Cin): per 32-channel chunk the 6 x 6 x 16-frame halo of the patch is staged ONCE (36 KB, double-buffered,
+//     rows of 64 bytes, row index hh * 96 + f * 6 + ww so that a tap is a uniform row shift dh * 96 + dw) and the nine taps read
+//     shifted windows of it; a step = one tap ROW (three taps x 32 channels: 24 MFMAs per wave) whose 24 KB of weights arrive in a
+//     three-slot ring two steps ahead.  GroupNorm(+SiLU) of the input is applied to the staged halo in place (the zero padding pads
+//     the NORMALISED activation, so padding slots stay zero), interleaved with the MFMAs of the steps that do not read those rows:
+//     halo rows hh 0..3 of chunk c + 1 are fetched at step 0 of chunk c and transformed during its step 2, rows hh 4..5 are fetched
+//     at step 1 and transformed during step 0 of chunk c + 1, whose taps (dh = -1) only read rows hh 0..3.
+//   transition: the 256 x 128 tile + spatial bias is rounded to bf16 (what the two-launch path stores) and written to LDS as the
+//     temporal GEMM's operand image T[plane of 64 channels][18 frames x 16 pixels][128 B] (frames -1 and 16 = zero rows), aliasing
+//     the halo stages.
+//   phase 2 (temporal, K = 3 x 128): six steps (tap, 64-channel plane) of 16 MFMAs per wave, operand rows = T rows shifted by 16 per
+//     frame; weights keep streaming through the same ring.
+//   epilogue: straight from the accumulators (v_permlane32_swap pairs -> 16-byte row stores), quad statistics records folded by DPP.
+// Every DMA is a buffer_load ... lds through a wave-uniform descriptor; the weights are read from an image packed once per layer
+// (mmd_vconv2d1d_pack: step-major slabs, pre-swizzled) so a weight piece is a linear 1 KB copy.  Every step issues a static number
+// of DMA instructions (dummies where there is nothing to fetch), so the waits are counted s_waitcnt vmcnt(N) + one raw s_barrier.
+// K order: spatial (32-channel chunk, tap, k) - not the (64-channel chunk, tap, k) of tiles 130 / 133, so T may differ from their
+// output in the last bf16 bit of a few elements; temporal (tap, channel) like every other main loop.  The layer that runs here is
+// chosen by its geometry alone (ops.vconv_fused_ok), never by timing.
+#include "mmd_common.h"
+#include <type_traits>
+
+struct VConvParams {
+  const char* X; int64_t ldx;            // [N * 16 * H * W, Cin] bf16 rows
+  const char* Wf; int wf_bytes;          // packed weight image: nchunk * 3 spatial slabs of 24 KB, then 6 temporal slabs of 16 KB
+  const float* bias_s; const float* bias_t;
+  char* Y; int64_t ldy;                  // [N * 16 * H * W, 128]
+  int N, H, W, Cin;
+  const float* gn_a; const float* gn_b;  // [S, Cin] fused affine of the input norm (nullptr: plain conv)
+  int gn_act; int gn_S; int64_t gn_rows;
+  float* stats; int64_t stats_ld;        // quad records of Y (nullptr: none): 4 records per block, index (n * H * W / 16 + patch) * 4 + frame group
+};
+
+#define VC_STAGE_B 36864                 // 576 halo rows x 64 B
+#define VC_WSLOT_B 24576                 // 3 taps x 128 rows x 64 B
+#define VC_WT_B 16384                    // 128 rows x 128 B
+#define VC_TPLANE_B 36864                // 288 T rows x 128 B
+
+__device__ __attribute__((aligned(16))) uint32_t g_vc_zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ uint32_t vc_pack2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 t = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, t);
+}
+
+template <int GNM>                                           // 0: plain conv, 1: fused input affine, 2: affine + SiLU
+__global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr bool GN = GNM != 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                                   // phase 1: [2 stages][576 rows][64 B]; phase 2: T [2 planes][288 rows][128 B]
+  char* sW = smem + 2 * VC_STAGE_B;                  // [3 slots][24 KB]
+  float* sGN = (float*)(smem + 2 * VC_STAGE_B + 3 * VC_WSLOT_B);   // [2 chunk parities][a (32) | b (32)]
+  float* sBias = sGN + 128;                          // [bias_s (128) | bias_t (128)]
+  char* sDummy = (char*)(sBias + 256);               // 256 B: target of the DMA instructions that only keep the per-step count static
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // XCD-aware order: consecutive patches (sharing halos) stay on one L2
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int PWc = p.W >> 2, ppf = PWc * (p.H >> 2);
+  const int n = wgid / ppf, patch = wgid - n * ppf;
+  const int h0 = (patch / PWc) * 4, w0 = (patch % PWc) * 4;
+  const int HW = p.H * p.W;
+  const int nchunk = p.Cin >> 5;
+
+  // ---- DMA descriptors (wave-uniform) and lane-constant offsets
+  const uint32_t OOB = 0xfffffff0u;
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (int64_t)n * 16 * HW * p.ldx * 2), 0,
+                                                       (int)(((int64_t)16 * HW - 1) * p.ldx * 2 + (int64_t)p.Cin * 2), 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wf, 0, p.wf_bytes, 0x00020000);
+  // halo pieces of this wave: j = 0..2 rows hh 0..3 (pieces w, w + 8, w + 16), j = 3: piece 24 + w, j = 4: piece 32 + w (waves 0-3)
+  uint32_t h_off[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int g = j < 3 ? wave + 8 * j : (j == 3 ? 24 + wave : 32 + wave);
+    const int row = 16 * g + (lane >> 2), pc = lane & 3;
+    const int hh = row / 96, rem = row - hh * 96, f = rem / 6, ww = rem - f * 6;
+    const int y = h0 - 1 + hh, x = w0 - 1 + ww;
+    const bool ok = g < 36 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    const int logical = pc ^ (hh & 3);
+    h_off[j] = ok ? (uint32_t)((((int64_t)f * p.H + y) * p.W + x) * p.ldx * 2 + logical * 16) : OOB;
+  }
+  // ---- in-place GroupNorm slots: slot i of this thread = 16 bytes at tid * 16 + i * 8192 of a stage (i = 4: waves 0-3 only)
+  unsigned gvalid = 0, glc = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int s = tid + 512 * i, row = s >> 2, pc = s & 3;
+    const int hh = row / 96, rem = row - hh * 96, f = rem / 6, ww = rem - f * 6;
+    (void)f;
+    const bool ok = (unsigned)(h0 - 1 + hh) < (unsigned)p.H && (unsigned)(w0 - 1 + ww) < (unsigned)p.W;
+    gvalid |= (ok ? 1u : 0u) << i;
+    glc |= (unsigned)(pc ^ (hh & 3)) << (2 * i);
+  }
+  // padding slots of both stages are zeroed ONCE (an out-of-range DMA lane may or may not write its zero, the transform leaves them alone)
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    if ((i < 4 || wave < 4) && !((gvalid >> i) & 1u)) {
+      *(u32x4*)(sA + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)(sA + VC_STAGE_B + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
+    }
+  if (tid < 256) sBias[tid] = tid < 128 ? (p.bias_s ? p.bias_s[tid] : 0.f) : (p.bias_t ? p.bias_t[tid - 128] : 0.f);
+  const float* gn_src = nullptr;
+  if (GN) {
+    const int sidx = min((int)(((int64_t)n * 16 * HW) / p.gn_rows), p.gn_S - 1);
+    gn_src = (lane < 32 ? p.gn_a : p.gn_b) + (int64_t)sidx * p.Cin + (lane & 31);
+  }
+
+  auto dma_dummy = [&]() { __builtin_amdgcn_global_load_lds((gptr_t)g_vc_zero, (lptr_t)sDummy, 4, 0, 0); };
+  auto issue_h = [&](int stage, int c, int j) {            // one DMA instruction (j is a literal at every call site)
+    const int g = j < 3 ? wave + 8 * j : (j == 3 ? 24 + wave : 32 + wave);
+    if (j < 4 || wave < 4)                                   // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lptr_t)(sA + stage * VC_STAGE_B + g * 1024), 16, h_off[j], c * 64, 0, 0);
+    else
+      dma_dummy();
+  };
+  auto issue_ws = [&](int slot, int s1) {                  // spatial step s1 = chunk * 3 + tap row: three linear 1 KB pieces per wave
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * VC_WSLOT_B + (wave + 8 * i) * 1024), 16, lane * 16,
+                                               s1 * VC_WSLOT_B + (wave + 8 * i) * 1024, 0, 0);
+  };
+  auto issue_wt = [&](int slot, int s2) {                  // temporal step s2 = tap * 2 + plane: two pieces + one dummy
+    const int base = nchunk * 3 * VC_WSLOT_B + s2 * VC_WT_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * VC_WSLOT_B + (wave + 8 * i) * 1024), 16, lane * 16,
+                                               base + (wave + 8 * i) * 1024, 0, 0);
+    dma_dummy();
+  };
+  auto issue_gn = [&](int c) {                             // one DMA instruction: a | b of chunk c (32 + 32 floats) -> ring slot c & 1
+    if (GN && wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(gn_src + c * 32), (lptr_t)(sGN + (c & 1) * 64), 4, 0, 0);
+    else dma_dummy();
+  };
+
+  // ---- fragment addressing
+  const int ph = (l31 >> 2) & 3, pw = l31 & 3;
+  int rbB[2];                                              // byte offset of halo row (ph + 1, f_b, pw + 1): tap (0, 0) of this lane's row
+#pragma unroll
+  for (int b = 0; b < 2; ++b) rbB[b] = (((ph + 1) * 96 + (wr * 4 + b * 2 + (l31 >> 4)) * 6 + pw + 1)) * 64;
+  const int kw1 = (l31 >> 2) & 3;                          // weight rows of 64 B: chunk key (co >> 2) & 3
+  const int wl1 = (wc * 64 + l31) * 64;
+  const int kw2 = (l31 >> 1) & 7;                          // rows of 128 B (temporal weights, T): chunk key (row >> 1) & 7
+  const int wl2 = (wc * 64 + l31) * 128;
+  const int tl2 = (wr * 64 + l31 + 16) * 128;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- GroupNorm(+SiLU) of one 16-byte slot in place, in two halves that are placed between the MFMA groups of a step
+  u32x4 tv;
+  f32x4 ta1, tb1;
+  uint32_t ty0, ty1;
+  auto tr_first = [&](int stage, int cpar, int i) {
+    const char* q = sA + stage * VC_STAGE_B + tid * 16 + i * 8192;
+    tv = *(const u32x4*)q;
+    const float* ap = sGN + cpar * 64 + ((glc >> (2 * i)) & 3u) * 8;
+    const f32x4 a0 = *(const f32x4*)ap, b0 = *(const f32x4*)(ap + 32);
+    ta1 = *(const f32x4*)(ap + 4);
+    tb1 = *(const f32x4*)(ap + 36);
+    float f[4] = {__uint_as_float(tv[0] << 16), __uint_as_float(tv[0] & 0xffff0000u), __uint_as_float(tv[1] << 16),
+                  __uint_as_float(tv[1] & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float w = f[e] * a0[e] + b0[e];
+      f[e] = GNM == 2 ? silu_f(w) : w;
+    }
+    ty0 = vc_pack2(f[0], f[1]);
+    ty1 = vc_pack2(f[2], f[3]);
+  };
+  auto tr_second = [&](int stage, int i) {
+    char* q = sA + stage * VC_STAGE_B + tid * 16 + i * 8192;
+    float f[4] = {__uint_as_float(tv[2] << 16), __uint_as_float(tv[2] & 0xffff0000u), __uint_as_float(tv[3] << 16),
+                  __uint_as_float(tv[3] & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float w = f[e] * ta1[e] + tb1[e];
+      f[e] = GNM == 2 ? silu_f(w) : w;
+    }
+    const u32x4 y = {ty0, ty1, vc_pack2(f[0], f[1]), vc_pack2(f[2], f[3])};
+    *(u32x4*)q = ((gvalid >> i) & 1u) ? y : tv;
+  };
+
+  // ---- one spatial step: tap row J (dh = J - 1) of chunk c.  TR: 0 none, 1 slots 0..2 of the NEXT stage, 2 slots 3 (, 4) of THIS stage
+  auto spatial = [&](auto jtag, int c, bool more) {
+    constexpr int J = decltype(jtag)::value;
+    // everything but the newest DMA group has landed: this step's weights (issued two steps ago) and the halo pieces it may touch
+    if constexpr (J == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // ... for every wave; every wave is past its fragment reads of the previous step
+    asm volatile("" ::: "memory");
+    // DMA group: weights of the step after next into the slot the previous step left (3), then J = 0: halo rows hh 0..3 of the next
+    // chunk (3), J = 1: its rows hh 4..5 (2), J = 2: the affine rows of the chunk after next (1)
+    if (J == 0 || more) issue_ws((J + 2) % 3, c * 3 + J + 2);
+    else issue_wt((J + 2) % 3, J - 1);
+    if constexpr (J == 0) {
+      if (more) { issue_h((c + 1) & 1, c + 1, 0); issue_h((c + 1) & 1, c + 1, 1); issue_h((c + 1) & 1, c + 1, 2); }
+      else { dma_dummy(); dma_dummy(); dma_dummy(); }
+    } else if constexpr (J == 1) {
+      if (more) { issue_h((c + 1) & 1, c + 1, 3); issue_h((c + 1) & 1, c + 1, 4); }
+      else { dma_dummy(); dma_dummy(); }
+    } else {
+      if (c + 2 < nchunk) issue_gn(c + 2); else dma_dummy();
+    }
+    const int trmode = !GN ? 0 : (J == 2 ? (more ? 1 : 0) : (J == 0 ? (c > 0 ? 2 : 0) : 0));     // block-uniform
+    const int tstage = J == 2 ? (c + 1) & 1 : c & 1, tpar = tstage;
+    const char* bW = sW + J * VC_WSLOT_B + wl1;            // ring slot of step 3 c + J = J
+    const char* bA[2];
+    const int key = (ph + J) & 3;                          // halo rows hh = ph + 1 + dh
+    const char* st = sA + (c & 1) * VC_STAGE_B + (J - 1) * (96 * 64) - 64;   // tap (dh, dw = -1)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bA[b] = st + rbB[b];
+    u32x4 fw[6][2], fa[6][2];
+    auto rd = [&](int k) {                                 // sub-step k = tap dw (k >> 1) x 16-channel k-step (k & 1)
+      const int dwi = k >> 1, k2 = k & 1;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fw[k][a] = *(const u32x4*)(bW + dwi * 8192 + a * 2048 + (((2 * k2 + half) ^ kw1) * 16));
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fa[k][b] = *(const u32x4*)(bA[b] + dwi * 64 + (((2 * k2 + half) ^ key) * 16));
+    };
+    auto mm = [&](int k) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[k][a]), __builtin_bit_cast(bf16x8, fa[k][b]), acc[a][b], 0, 0, 0);
+    };
+    auto tr = [&](int k) {                                 // the norm of (half of) one slot behind MFMA group k
+      if (trmode == 1) {                                   // slots 0, 1, 2: two sub-steps each
+        if (k & 1) tr_second(tstage, k >> 1); else tr_first(tstage, tpar, k >> 1);
+      } else if (trmode == 2) {                            // slot 3 (k = 0, 1), slot 4 (k = 2, 3; waves 0-3)
+        if (k < 2 || (k < 4 && wave < 4)) {
+          if (k & 1) tr_second(tstage, 3 + (k >> 1)); else tr_first(tstage, tpar, 3 + (k >> 1));
+        }
+      }
+    };
+    rd(0); rd(1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(2); mm(0); tr(0);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(3); mm(1); tr(1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(4); mm(2); tr(2);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(5); mm(3); tr(3);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(4); tr(4);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(5); tr(5);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: halo of chunk 0, the affine rows of chunks 0 / 1, the weights of steps 0 / 1; chunk 0 is normalised before the first MFMA
+#pragma unroll
+  for (int j = 0; j < 5; ++j) issue_h(0, 0, j);
+  issue_gn(0);
+  if (nchunk > 1) issue_gn(1); else dma_dummy();
+  issue_ws(0, 0);
+  issue_ws(1, 1);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (GN) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i < 4 || wave < 4) { tr_first(0, 0, i); tr_second(0, i); }
+    // (the first step's barrier orders these LDS writes before the first fragment reads)
+  }
+
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    spatial(std::integral_constant<int, 0>{}, c, more);
+    spatial(std::integral_constant<int, 1>{}, c, more);
+    spatial(std::integral_constant<int, 2>{}, c, more);
+  }
+
+  // ---- transition: T = bf16(acc + bias_s) as the temporal operand image (aliases the halo stages), frames -1 / 16 = zero rows
+  __builtin_amdgcn_s_barrier();                            // every wave is past its last halo read
+  asm volatile("" ::: "memory");
+  {
+    const int zr = tid >> 3, zc = tid & 7;                 // 64 rows x 8 chunks: rows 0..15 and 272..287 of both planes
+    const int row = (zr & 15) + ((zr & 16) ? 272 : 0), plane = zr >> 5;
+    *(u32x4*)(sA + plane * VC_TPLANE_B + row * 128 + zc * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int trow = wr * 64 + b * 32 + l31 + 16;
+      char* tb = sA + wc * VC_TPLANE_B + trow * 128;
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        // acc[4 q + j] = channel 8 q + 4 half + j of row l31; pair q = 2 j2 with q = 2 j2 + 1: this lane then holds the 8 consecutive
+        // channels 16 j2 + 8 half .. + 8 of its row
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][8 * j2 + j]), __float_as_uint(acc[a][b][8 * j2 + 4 + j]), false, false);
+          v[j] = __uint_as_float(sw[0]);
+          v[4 + j] = __uint_as_float(sw[1]);
+        }
+        const int cl = a * 32 + 16 * j2 + 8 * half;        // channel inside the plane (= inside this wave column's 64)
+        const f32x4 b0 = *(const f32x4*)(sBias + wc * 64 + cl), b1 = *(const f32x4*)(sBias + wc * 64 + cl + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+        *(u32x4*)(tb + ((((cl >> 3)) ^ ((trow >> 1) & 7)) * 16)) = Elt<__bf16>::pack(v);
+      }
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- phase 2: temporal k = 3 over T.  Step s2 = tap * 2 + plane in ring slot s2 % 3 (3 nchunk spatial steps: the ring continues)
+  auto temporal = [&](auto stag) {
+    constexpr int S2 = decltype(stag)::value;
+    if constexpr (S2 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if constexpr (S2 + 2 < 6) issue_wt((S2 + 2) % 3, S2 + 2);
+    else { dma_dummy(); dma_dummy(); dma_dummy(); }
+    constexpr int tap = S2 >> 1, plane = S2 & 1;
+    const char* bW = sW + (S2 % 3) * VC_WSLOT_B + wl2;
+    const char* bT = sA + plane * VC_TPLANE_B + tl2 + (tap - 1) * 2048;
+    u32x4 fw[4][2], fa[4][2];
+    auto rd = [&](int k) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fw[k][a] = *(const u32x4*)(bW + a * 4096 + (((2 * k + half) ^ kw2) * 16));
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fa[k][b] = *(const u32x4*)(bT + b * 4096 + (((2 * k + half) ^ kw2) * 16));
+    };
+    auto mm = [&](int k) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[k][a]), __builtin_bit_cast(bf16x8, fa[k][b]), acc[a][b], 0, 0, 0);
+    };
+    rd(0); rd(1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(2); mm(0);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(3); mm(1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(2); mm(3);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  temporal(std::integral_constant<int, 0>{});
+  temporal(std::integral_constant<int, 1>{});
+  temporal(std::integral_constant<int, 2>{});
+  temporal(std::integral_constant<int, 3>{});
+  temporal(std::integral_constant<int, 4>{});
+  temporal(std::integral_constant<int, 5>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing dummies
+
+  // ---- epilogue from the accumulators: + bias_t -> bf16 -> 16-byte row stores; quad statistics of the values as stored
+  const int64_t mbase = (int64_t)n * 16 * HW + (int64_t)(h0 + ph) * p.W + w0 + pw;
+  const int64_t rec = ((int64_t)n * (HW >> 4) + patch) * 4 + wr;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int col = wc * 64 + a * 32 + 16 * j2 + 8 * half;
+      const f32x4 b0 = *(const f32x4*)(sBias + 128 + col), b1 = *(const f32x4*)(sBias + 128 + col + 4);
+      float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][8 * j2 + j]), __float_as_uint(acc[a][b][8 * j2 + 4 + j]), false, false);
+          v[j] = __uint_as_float(sw[0]);
+          v[4 + j] = __uint_as_float(sw[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+        const u32x4 pk = Elt<__bf16>::pack(v);
+        const int64_t m = mbase + (int64_t)(wr * 4 + b * 2 + (l31 >> 4)) * HW;
+        *(u32x4*)(p.Y + (m * p.ldy + col) * 2) = pk;
+        if (p.stats) {
+          float rf[8];
+          Elt<__bf16>::unpack(pk, rf);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            u[0] += rf[j];
+            u[1] += rf[4 + j];
+            u[2] += rf[j] * rf[j];
+            u[3] += rf[4 + j] * rf[4 + j];
+          }
+        }
+      }
+      if (p.stats) {                                       // block-uniform: lanes 16 / 17 of each half hold quad 0 / 1 of the lane group's 8 channels
+        const float t0 = halfwave_total(u[0]), t1 = halfwave_total(u[1]), t2 = halfwave_total(u[2]), t3 = halfwave_total(u[3]);
+        if ((l31 >> 1) == 8) {
+          float* d = p.stats + (rec * p.stats_ld + (col >> 2) + (l31 & 1)) * 2;
+          d[0] = (l31 & 1) ? t1 : t0;
+          d[1] = (l31 & 1) ? t3 : t2;
+        }
+      }
+    }
+}
+
+// ---- weight image.  Spatial slab s1 = chunk * 3 + dhi: [dwi][co][64 B], 16-byte chunk lc of row co stored at chunk lc ^ ((co >> 2) & 3);
+// value = Ws[co][(dhi * 3 + dwi) * Cin + chunk * 32 + lc * 8 + e].  Temporal slab s2 = tap * 2 + plane: [co][128 B], chunk lc at
+// lc ^ ((co >> 1) & 7); value = Wt[co][tap * 128 + plane * 64 + lc * 8 + e].
+__global__ __launch_bounds__(256) void vconv_pack_kernel(const uint16_t* __restrict__ Ws, const uint16_t* __restrict__ Wt, uint16_t* __restrict__ out,
+                                                         int Cin, int64_t total) {
+  const int64_t nsp = (int64_t)(Cin >> 5) * 3 * (VC_WSLOT_B / 2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    uint16_t v;
+    if (i < nsp) {
+      const int s1 = (int)(i / (VC_WSLOT_B / 2)), r = (int)(i - (int64_t)s1 * (VC_WSLOT_B / 2));
+      const int c = s1 / 3, dhi = s1 - c * 3;
+      const int dwi = r / 4096, r2 = r - dwi * 4096, co = r2 >> 5, pc = (r2 >> 3) & 3, e = r2 & 7;
+      const int lc = pc ^ ((co >> 2) & 3);
+      v = Ws[(int64_t)co * 9 * Cin + (dhi * 3 + dwi) * Cin + c * 32 + lc * 8 + e];
+    } else {
+      const int64_t k = i - nsp;
+      const int s2 = (int)(k / (VC_WT_B / 2)), r = (int)(k - (int64_t)s2 * (VC_WT_B / 2));
+      const int tap = s2 >> 1, plane = s2 & 1;
+      const int co = r >> 6, pc = (r >> 3) & 7, e = r & 7;
+      const int lc = pc ^ ((co >> 1) & 7);
+      v = Wt[(int64_t)co * 384 + tap * 128 + plane * 64 + lc * 8 + e];
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int64_t mmd_vconv2d1d_weight_bytes(int Cin) { return (int64_t)(Cin >> 5) * 3 * VC_WSLOT_B + 6 * VC_WT_B; }
+
+extern "C" int mmd_vconv2d1d_pack(const void* Ws, const void* Wt, void* out, int Cin, int Cout, void* stream) {
+  MMD_REQUIRE(Ws && Wt && out, "vconv2d1d_pack: null pointer");
+  MMD_REQUIRE(Cout == 128 && Cin > 0 && Cin % 32 == 0, "vconv2d1d_pack: needs 128 output channels and Cin %% 32 == 0 (got %d -> %d)", Cin, Cout);
+  const int64_t total = mmd_vconv2d1d_weight_bytes(Cin) / 2;
+  hipLaunchKernelGGL(vconv_pack_kernel, dim3(cdiv(total, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Ws, (const uint16_t*)Wt,
+                     (uint16_t*)out, Cin, total);
+  return mmd_check_launch("vconv2d1d_pack");
+}
+
+extern "C" int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, const float* gn_b, int act, int S, int64_t rows_per_slice,
+                             const void* Wf, const float* bias_s, const float* bias_t, void* Y, int64_t ldy, int N, int F, int H, int W,
+                             int Cin, int Cout, float* stats, int64_t stats_ld, void* stream) {
+  MMD_REQUIRE(X && Wf && Y, "vconv2d1d: null pointer");
+  MMD_REQUIRE(F == 16 && Cout == 128 && Cin > 0 && Cin % 32 == 0 && N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0,
+              "vconv2d1d: needs 16 frames, 128 output channels, Cin %% 32 == 0 and frame sides that are multiples of 4 (got F=%d Cout=%d Cin=%d H=%d W=%d)",
+              F, Cout, Cin, H, W);
+  MMD_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= Cin && ldy >= Cout && ((uintptr_t)X | (uintptr_t)Wf | (uintptr_t)Y) % 16 == 0,
+              "vconv2d1d: rows must be 16-byte aligned");
+  MMD_REQUIRE(((int64_t)16 * H * W - 1) * ldx * 2 + (int64_t)Cin * 2 < 0x7fffffffLL, "vconv2d1d: one sample's rows must stay below 2 GB");
+  MMD_REQUIRE((gn_a == nullptr) == (gn_b == nullptr), "vconv2d1d: gn_a and gn_b come together");
+  MMD_REQUIRE(!gn_a || (S > 0 && rows_per_slice > 0 && rows_per_slice % ((int64_t)16 * H * W) == 0 && (int64_t)S * rows_per_slice == (int64_t)N * 16 * H * W),
+              "vconv2d1d: the fused input norm needs slices of whole samples covering the tensor (S=%d rows=%lld)", S, (long long)rows_per_slice);
+  MMD_REQUIRE(!stats || ((uintptr_t)stats % 8 == 0 && stats_ld >= Cout / 4), "vconv2d1d: statistics records: 8-byte aligned, stats_ld >= Cout / 4");
+  VConvParams p;
+  p.X = (const char*)X; p.ldx = ldx; p.Wf = (const char*)Wf; p.wf_bytes = (int)mmd_vconv2d1d_weight_bytes(Cin);
+  p.bias_s = bias_s; p.bias_t = bias_t; p.Y = (char*)Y; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin;
+  p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = act; p.gn_S = S; p.gn_rows = rows_per_slice;
+  p.stats = stats; p.stats_ld = stats_ld;
+  const size_t lds = 2 * VC_STAGE_B + 3 * VC_WSLOT_B + 512 + 1024 + 256;
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)vconv2d1d_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vconv2d1d_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vconv2d1d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "vconv2d1d: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = N * (H / 4) * (W / 4);
+  if (!gn_a) hipLaunchKernelGGL(vconv2d1d_kernel<0>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  else if (act) hipLaunchKernelGGL(vconv2d1d_kernel<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(vconv2d1d_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  return mmd_check_launch("vconv2d1d");
+}

@@ -86,6 +86,9 @@ class UNetEngine:
         tmode = os.environ.get("MMD_GN_TAIL", "0")
         self.tail_enabled = self.rec_enabled and tmode != "0"
         self._gn_small = os.environ.get("MMD_GN_SMALL", "1") != "0"
+        # the fused VideoConv 2d+1d launch (ops.vconv_fused_ok) writes quad RECORDS, not tails: with the tail experiment on, the layer
+        # keeps its two-launch form
+        self._vconv_fused = dtype == torch.bfloat16 and not self.tail_enabled
         self.tail_max = (1 << 62) if tmode == "all" else int(os.environ.get("MMD_GN_TAIL_MAX", str(1 << 21)))
         self._tails = {}              # buffer storage -> entry (slice geometry, accumulator offset, producer structs)
         self._tail_structs = []       # every GnTail handed to a producer launch: (struct, entry)
@@ -148,11 +151,14 @@ class UNetEngine:
         c0 = (t.data_ptr() - ent["ptr"]) // ent["es"]
         return (ent, c0) if 0 <= c0 and c0 + t.shape[1] <= ent["C"] else (None, 0)
 
-    def _stats_for(self, out):
-        """The record view a GEMM writing `out` should fill (None: the buffer has no record buffer)."""
+    def _stats_for(self, out, perm_unit=0):
+        """The record view a GEMM writing `out` should fill (None: the buffer has no record buffer).  perm_unit: the producer's
+        records are 64-row groups in ITS OWN order inside every perm_unit rows (the fused VideoConv: patches x frames), so only norms
+        whose slices are whole multiples of perm_unit may finalize from them."""
         ent, c0 = self._rec_slice(out)
         if ent is None or c0 % 4 or out.shape[1] % 4:
             return None
+        ent["perm_unit"] = max(ent.get("perm_unit", 0), perm_unit)
         ent["cover"].append((c0, c0 + out.shape[1]))
         return ent["view"][:, c0 // 4:(c0 + out.shape[1]) // 4, :]
 
@@ -244,6 +250,8 @@ class UNetEngine:
         ent, c0 = self._rec_slice(x)
         if (ent is None or geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn % 64 or geom.S * geom.Tn != x.shape[0]
                 or c0 % 4 or x.shape[1] % 128):                    # quad records: groups must be whole quads
+            return None
+        if ent.get("perm_unit", 0) and geom.Tn % ent["perm_unit"]:
             return None
         need, pos = c0 + x.shape[1], c0
         for lo, hi in sorted(ent["cover"]):
@@ -388,7 +396,19 @@ class UNetEngine:
             # h feeds the out_layers GroupNorm directly unless it is resampled first (up / down blocks) or shifted by the embedding
             # (non-FiLM blocks): then its producer's epilogue statistics would describe a different tensor
             hstats = fh == 1 and ss
-            if vid and ops.halo_gn_ok(x, ops.TAPS_SPATIAL, (N * F, Hh, Hh), gin):
+            t0 = t1 = h = None
+            if vid and self._vconv_fused and ops.vconv_fused_ok(x, cout, N, F, Hh, Hh):
+                # in_layers norm + SiLU, spatial 3x3 and temporal k=3 in ONE launch (ds1 level): the intermediate stays in LDS
+                ga, gb = self._gn_affine(x, f"{p}.{mod}_in_layers.0", gin, None)
+                h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
+                wkey = f"{p}.video_in_layers.2.video_conv_spatial.weight"
+                wf = self._packed("vconv", wkey, lambda: ops.vconv_pack(
+                    self._gemm_w(wkey), self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight")))
+                ops.vconv2d1d(x, wf, self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"),
+                              self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), N, F, Hh, Hh, a=ga, b=gb, geom=gin, act=True,
+                              out=h, stats=self._stats_for(h, perm_unit=rows_in // N))
+                self._release(ga, gb)
+            elif vid and ops.halo_gn_ok(x, ops.TAPS_SPATIAL, (N * F, Hh, Hh), gin):
                 # in_layers norm + SiLU inside the 3x3 conv's halo stage: no normalised tensor in HBM (ds1 / ds2 levels)
                 ga, gb = self._gn_affine(x, f"{p}.{mod}_in_layers.0", gin, None)
                 t1 = ops.gn_conv_gemm(x, ga, gb, gin, True, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
@@ -398,7 +418,9 @@ class UNetEngine:
                 t0 = None
             else:
                 t0 = self._gn(x, f"{p}.{mod}_in_layers.0", gin, act=True)
-            if vid:
+            if h is not None:
+                pass
+            elif vid:
                 if t0 is not None:
                     t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
                                        self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,

@@ -532,6 +532,57 @@ def gn_conv_gemm(x, a, b, geom: Geom, act, w, bias, taps, dims, residual=None, o
     return out
 
 
+# ---- VideoConv '2d+1d' in one launch (mmd_vconv2d1d): spatial 3x3 + temporal k=3 with the intermediate in LDS, the in_layers norm +
+# SiLU applied to the staged halo and the output statistics in the epilogue.  Its spatial K order is its own (32-channel chunks), so -
+# like the halo tiles and the strip - it is chosen by the LAYER GEOMETRY alone: bf16, 16 frames, 128 output channels (the ds1 level of
+# the base model), Cin a multiple of 32, frame sides multiples of 4.  MMD_VCONV_FUSED=0: the two-launch path (A/B).
+_VCONV_FUSED = os.environ.get("MMD_VCONV_FUSED", "1") != "0"
+
+
+def vconv_shape_ok(x, Cout, N, F, Hh, Ww):
+    """Launches mmd_vconv2d1d accepts."""
+    return (x.dtype == torch.bfloat16 and F == 16 and Cout == 128 and x.shape[1] % 32 == 0 and Hh % 4 == 0 and Ww % 4 == 0
+            and x.shape[0] == N * F * Hh * Ww and (16 * Hh * Ww * x.stride(0) + x.shape[1]) * 2 < 2 ** 31)
+
+
+def vconv_fused_ok(x, Cout, N, F, Hh, Ww):
+    """The layers that always run on the fused kernel (a property of the layer, independent of the batch size)."""
+    return _VCONV_FUSED and vconv_shape_ok(x, Cout, N, F, Hh, Ww)
+
+
+def vconv_pack(ws, wt):
+    """Packed spatial [128, 9 * Cin] and temporal [128, 384] bf16 GEMM matrices -> the kernel's weight image (mmd_vconv2d1d_pack)."""
+    H.require_cuda(ws, wt)
+    Cout, Cin = ws.shape[0], ws.shape[1] // 9
+    if ws.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16 or tuple(wt.shape) != (Cout, 3 * Cout) or not ws.is_contiguous() or not wt.is_contiguous():
+        raise H.MMDError(f"vconv_pack: expected contiguous bf16 [Cout, 9 Cin] / [Cout, 3 Cout], got {tuple(ws.shape)} / {tuple(wt.shape)}")
+    out = torch.empty(H.lib().mmd_vconv2d1d_weight_bytes(Cin) // 2, dtype=torch.bfloat16, device=ws.device)
+    H.call("mmd_vconv2d1d_pack", ws.data_ptr(), wt.data_ptr(), out.data_ptr(), Cin, Cout, H.stream_handle())
+    return out
+
+
+def vconv2d1d(x, wf, bias_s, bias_t, N, F, Hh, Ww, a=None, b=None, geom=None, act=True, out=None, stats=None):
+    """x [N*F*H*W, Cin] bf16 -> [.., 128]: temporal_k3(spatial_3x3(act(x * a + b))) (include/mmd.h: mmd_vconv2d1d).  a / b [S, Cin]:
+    the fused affine of the input norm over geom's slices (whole samples); stats: the output's record view [M / 64, 32, 2]."""
+    _chk2d(x)
+    M, Cin = x.shape
+    Cout = 128
+    if not vconv_shape_ok(x, Cout, N, F, Hh, Ww):
+        raise H.MMDError(f"vconv2d1d: unsupported launch (x {tuple(x.shape)} {x.dtype}, N={N} F={F} H={Hh} W={Ww})")
+    if (a is None) != (b is None) or (a is not None and (geom is None or geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn
+                                                         or geom.S * geom.Tn != M or geom.Tn % (F * Hh * Ww))):
+        raise H.MMDError("vconv2d1d: the fused input norm needs contiguous slices of whole samples")
+    out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    sp, sld = (None, 0) if stats is None else _stats_args(stats, M, Cout)
+    flops = 2 * M * Cout * (9 * Cin + 3 * Cout)
+    nbytes = 2 * (M * Cin + M * Cout + Cout * (9 * Cin + 3 * Cout)) + 8 * Cout
+    _dispatch("mmd_vconv2d1d", x.data_ptr(), x.stride(0), H.ptr(a), H.ptr(b), 1 if act else 0, 0 if geom is None else geom.S,
+              0 if geom is None else geom.Tn, wf.data_ptr(), H.ptr(bias_s), H.ptr(bias_t), out.data_ptr(), out.stride(0), N, F, Hh, Ww, Cin, Cout,
+              sp, sld, meta=(f"vconv2d1d<bf16{',gn' if a is not None else ''}>[M={M},Cin={Cin},N={Cout}]", flops, nbytes))
+    return out
+
+
 def attn(q, kv, out, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group, win,
          q_off=0, k_off=None, v_off=None, shift_dev=None, impl=0):
     """See include/mmd.h: mmd_attn_fwd.  q/kv are qkv GEMM outputs [rows, 3C]; out [q rows, C]."""

@@ -334,3 +334,15 @@ def test_transposing_read_tile_model():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.check()
+
+
+def test_vconv_index_model():
+    """The lane-level numpy model of the fused VideoConv kernel's index maps (weight image, halo pieces, swizzles, fragment addresses,
+    MFMA layouts, T image, epilogue rows and records - tools/vconv_model.py restates the kernel's expressions) against two direct
+    convolutions, exact on integer data: with / without the fused input norm, two chunk counts, several patches and samples."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vconv_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "vconv_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.check(N=1, H=8, W=4, Cin=64, with_gn=True, seed=1)
+    assert m.check(N=2, H=4, W=4, Cin=32, with_gn=False, seed=2)

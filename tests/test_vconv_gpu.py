@@ -1,0 +1,141 @@
+"""Fused VideoConv '2d+1d' (mmd_vconv2d1d, reference multimodal_unet.py:83-99 behind the in_layers GroupNorm32 + SiLU, unet:339-340)
+against (a) the fp32 torch convolutions of the oracle's primitives (F.conv2d per frame, then F.conv1d per pixel), (b) the same with
+the kernel's one intermediate rounding point restated (spatial result + bias -> bf16), (c) the two-launch path of this library
+(gn_apply | conv_gemm tile 130 | conv_gemm strip), and the statistics records against the stored output.
+
+Tolerances (rel-L2): (a) 1e-2 like every bf16 kernel test (inputs are bf16-representable; the budget is the bf16 rounding of the
+intermediate and of the output); (b) 4e-3: only summation order and rare 1-ulp flips of the intermediate remain; (c) 4e-3 and at least
+97 % of the elements bitwise equal (the spatial K order differs: 32- vs 64-channel chunks)."""
+import pytest
+import torch
+import torch.nn.functional as F_
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from mm_diffusion import ops as o
+    return o
+
+
+def make(N, H, W, Cin, seed, ldx_pad=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    M = N * 16 * H * W
+    buf = torch.randn(M, Cin + ldx_pad, device="cuda", generator=g).to(torch.bfloat16)
+    x = buf[:, :Cin] if ldx_pad else buf
+    ws = (torch.randn(128, Cin, 3, 3, device="cuda", generator=g) * (9 * Cin) ** -0.5).to(torch.bfloat16)
+    wt = (torch.randn(128, 128, 3, device="cuda", generator=g) * 384 ** -0.5).to(torch.bfloat16)
+    bs, bt = torch.randn(128, device="cuda", generator=g), torch.randn(128, device="cuda", generator=g)
+    a = torch.rand(N, Cin, device="cuda", generator=g) + 0.5
+    b = torch.randn(N, Cin, device="cuda", generator=g) * 0.5
+    return x, ws, wt, bs, bt, a, b
+
+
+def torch_ref(x, ws, wt, bs, bt, a, b, N, H, W, act, round_mid):
+    """fp32 reference on the bf16-representable inputs: [M, Cin] rows -> [M, 128] rows."""
+    Cin = x.shape[1]
+    v = x.float().reshape(N, 16, H, W, Cin)
+    if a is not None:
+        v = v * a[:, None, None, None, :] + b[:, None, None, None, :]
+        if act:
+            v = v * torch.sigmoid(v)
+        v = v.to(torch.bfloat16).float()          # the halo stage holds the normalised activation in bf16
+    t = F_.conv2d(v.reshape(N * 16, H, W, Cin).permute(0, 3, 1, 2), ws.float(), bs, padding=1)       # [(n f), 128, H, W]
+    if round_mid:
+        t = t.to(torch.bfloat16).float()
+    t = t.reshape(N, 16, 128, H * W).permute(0, 3, 2, 1).reshape(N * H * W, 128, 16)                 # (n hw) c f
+    y = F_.conv1d(t, wt.float(), bt, padding=1)
+    return y.reshape(N, H * W, 128, 16).permute(0, 3, 1, 2).reshape(N * 16 * H * W, 128)
+
+
+@pytest.mark.parametrize("gn", [None, "silu", "affine"])
+@pytest.mark.parametrize("N,H,W,Cin,pad", [(1, 8, 8, 32, 0), (2, 8, 12, 64, 0), (1, 16, 16, 128, 0), (1, 12, 8, 256, 64), (1, 64, 64, 128, 0)])
+def test_vconv_vs_torch(ops, gn, N, H, W, Cin, pad):
+    x, ws, wt, bs, bt, a, b = make(N, H, W, Cin, seed=H * W + Cin, ldx_pad=pad)
+    wf = ops.vconv_pack(ops.pack_conv_weight(ws.float(), torch.bfloat16), ops.pack_conv_weight(wt.float(), torch.bfloat16))
+    geom = ops.Geom.per_sample(N, 16 * H * W)
+    kw = {} if gn is None else dict(a=a, b=b, geom=geom, act=gn == "silu")
+    y = ops.vconv2d1d(x, wf, bs, bt, N, 16, H, W, **kw)
+    aa, bb = (None, None) if gn is None else (a, b)
+    ref = torch_ref(x, ws, wt, bs, bt, aa, bb, N, H, W, gn == "silu", round_mid=False)
+    ref_r = torch_ref(x, ws, wt, bs, bt, aa, bb, N, H, W, gn == "silu", round_mid=True)
+    assert torch.isfinite(y.float()).all()
+    e0, e1 = rel_l2(y.float().cpu(), ref.cpu()), rel_l2(y.float().cpu(), ref_r.to(torch.bfloat16).float().cpu())
+    assert e0 < 1e-2, e0
+    assert e1 < 4e-3, e1
+
+
+@pytest.mark.parametrize("N,H,W,Cin", [(1, 16, 16, 128), (2, 32, 32, 128), (1, 64, 64, 256)])
+def test_vconv_vs_two_launch_path(ops, N, H, W, Cin):
+    """gn_apply | 3x3 on the halo tile | temporal k=3 on the strip: what the ResBlock in_layers ran before round 4."""
+    x, ws, wt, bs, bt, a, b = make(N, H, W, Cin, seed=5)
+    wsp, wtp = ops.pack_conv_weight(ws.float(), torch.bfloat16), ops.pack_conv_weight(wt.float(), torch.bfloat16)
+    geom = ops.Geom.per_sample(N, 16 * H * W)
+    xn = ops.gn_apply(x, a, b, geom, act=True)
+    t1 = ops.conv_gemm(xn, wsp, bs, taps=ops.TAPS_SPATIAL, dims=(N * 16, H, W), tile=130)
+    y0 = ops.conv_gemm(t1, wtp, bt, taps=ops.TAPS_TEMPORAL, dims=(16, H * W, 1), tile=131)
+    y1 = ops.vconv2d1d(x, ops.vconv_pack(wsp, wtp), bs, bt, N, 16, H, W, a=a, b=b, geom=geom, act=True)
+    same = float((y0.view(torch.int16) == y1.view(torch.int16)).float().mean())
+    err = rel_l2(y1.float().cpu(), y0.float().cpu())
+    assert err < 4e-3 and same > 0.97, (err, same)
+
+
+def test_vconv_statistics_records(ops):
+    """The epilogue's quad records: per sample they sum to the column-quad sums / sums of squares of the STORED output."""
+    N, H, W, Cin = 2, 16, 16, 128
+    x, ws, wt, bs, bt, a, b = make(N, H, W, Cin, seed=9)
+    wf = ops.vconv_pack(ops.pack_conv_weight(ws.float(), torch.bfloat16), ops.pack_conv_weight(wt.float(), torch.bfloat16))
+    M = N * 16 * H * W
+    rec = torch.full((M // 64, 32, 2), float("nan"), device="cuda")
+    y = ops.vconv2d1d(x, wf, bs, bt, N, 16, H, W, a=a, b=b, geom=ops.Geom.per_sample(N, 16 * H * W), act=True, stats=rec)
+    y_plain = ops.vconv2d1d(x, wf, bs, bt, N, 16, H, W, a=a, b=b, geom=ops.Geom.per_sample(N, 16 * H * W), act=True)
+    assert torch.equal(y, y_plain)
+    assert torch.isfinite(rec).all()
+    yq = y.double().reshape(N, 16 * H * W, 32, 4)
+    r = rec.double().reshape(N, -1, 32, 2)
+    assert rel_l2(r[..., 0].sum(1).cpu(), yq.sum(dim=(1, 3)).cpu()) < 1e-5
+    assert rel_l2(r[..., 1].sum(1).cpu(), (yq ** 2).sum(dim=(1, 3)).cpu()) < 1e-5
+    # and mmd_gn_finalize_stats turns them into the same affine as the statistics pass over y
+    gamma, beta = torch.rand(128, device="cuda") + 0.5, torch.randn(128, device="cuda")
+    geom = ops.Geom.per_sample(N, 16 * H * W)
+    a1 = torch.empty(N, 128, device="cuda")
+    b1 = torch.empty(N, 128, device="cuda")
+    ops.gn_finalize_stats(rec, gamma, beta, geom, a=a1, b=b1)
+    a0 = torch.empty(N, 128, device="cuda")
+    b0 = torch.empty(N, 128, device="cuda")
+    ops.gn_stats(y, gamma, beta, geom, a=a0, b=b0, ws=ops.gn_workspace(y, geom))
+    assert rel_l2(a1.cpu(), a0.cpu()) < 1e-4 and rel_l2(b1.cpu(), b0.cpu()) < 1e-3
+
+
+def test_vconv_repeatable_and_batch_invariant(ops):
+    """Bitwise repeatable, and the rows of a batch-2 launch equal the batch-1 launches of its samples (also the records)."""
+    N, H, W, Cin = 2, 32, 32, 128
+    x, ws, wt, bs, bt, a, b = make(N, H, W, Cin, seed=11)
+    wf = ops.vconv_pack(ops.pack_conv_weight(ws.float(), torch.bfloat16), ops.pack_conv_weight(wt.float(), torch.bfloat16))
+    M1 = 16 * H * W
+    rec = torch.zeros(N * M1 // 64, 32, 2, device="cuda")
+    y = ops.vconv2d1d(x, wf, bs, bt, N, 16, H, W, a=a, b=b, geom=ops.Geom.per_sample(N, M1), act=True, stats=rec)
+    for _ in range(3):
+        rec2 = torch.zeros_like(rec)
+        assert torch.equal(y, ops.vconv2d1d(x, wf, bs, bt, N, 16, H, W, a=a, b=b, geom=ops.Geom.per_sample(N, M1), act=True, stats=rec2))
+        assert torch.equal(rec, rec2)
+    for n in range(N):
+        r1 = torch.zeros(M1 // 64, 32, 2, device="cuda")
+        y1 = ops.vconv2d1d(x[n * M1:(n + 1) * M1], wf, bs, bt, 1, 16, H, W, a=a[n:n + 1], b=b[n:n + 1], geom=ops.Geom.per_sample(1, M1),
+                           act=True, stats=r1)
+        assert torch.equal(y1, y[n * M1:(n + 1) * M1])
+        assert torch.equal(r1, rec[n * M1 // 64:(n + 1) * M1 // 64])
+
+
+def test_vconv_rejects_unsupported(ops):
+    from mm_diffusion import _hip as H
+    x = torch.zeros(16 * 8 * 8, 48, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(H.MMDError):
+        ops.vconv2d1d(x, x, None, None, 1, 16, 8, 8)
+    x = torch.zeros(8 * 8 * 8, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(H.MMDError):
+        ops.vconv2d1d(x, x, None, None, 1, 8, 8, 8)
