@@ -131,17 +131,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
-#ifdef ATTN_ROWSUM_MFMA
-  // experiment (-DATTN_ROWSUM_MFMA): the softmax denominator on the matrix cores.  The kernel class is VALU-bound at head width 64
-  // (15.6 VALU instructions per MFMA, MFMA pipe 22 % busy), and the row sum is 32 adds + a cross-half shuffle
-  // + the l_run update per tile.  One more accumulator tile whose A operand is all ones gives every row = sum_k P[k][q] over BOTH
-  // half-waves' keys (4 MFMAs per tile, no LDS read); only register 0 is ever read or rescaled.  The sum then runs over the
-  // bf16-rounded P that also feeds the numerator.
-  f32x16 osum;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) osum[r] = 0.f;
-  const u32x4 ones_bf16 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-#endif
 
   u32x4 rk[NK], rv[NK];
   const int ntiles = (gi.k_count + 63) >> 6;
@@ -150,23 +139,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       const int id = tid + 256 * i;
-#ifdef ATTN_BRANCHFREE_KV
-      // experiment (-DATTN_BRANCHFREE_KV): keys past the window read a zero page instead of sitting under a branch - hipcc turns the
-      // predicated form below into s_and_saveexec / s_cbranch pairs around every load (4 per tile and thread)
-      {
-        const int j = id / DV, v = id % DV;
-        const bool ok = id < 64 * DV && kt0 + j < gi.k_count;
-        const char* src = ok ? p.KV + (key_row(gi, ok ? kt0 + j : 0) * p.ldkv + p.k_off + h * D + v * 8) * 2 : (const char*)g_attn_zero;
-        rk[i] = *(const u32x4*)src;
-      }
-      {
-        const int j = (id & 31) + 32 * ((id >> 6) & 1);
-        const int v = 2 * (id >> 7) + ((id >> 5) & 1);
-        const bool ok = id < 64 * DV && kt0 + j < gi.k_count;
-        const char* src = ok ? p.KV + (key_row(gi, ok ? kt0 + j : 0) * p.ldkv + p.v_off + h * D + v * 8) * 2 : (const char*)g_attn_zero;
-        rv[i] = *(const u32x4*)src;
-      }
-#else
       // K: row-major, DV lanes per key row (coalesced)
       {
         const int j = id / DV, v = id % DV;
@@ -184,7 +156,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
           x = *(const u32x4*)(p.KV + (key_row(gi, kt0 + j) * p.ldkv + p.v_off + h * D + v * 8) * 2);
         rv[i] = x;
       }
-#endif
     }
   };
   auto store_kv = [&]() {
@@ -200,9 +171,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
           const int j = (id & 31) + 32 * ((id >> 6) & 1);
           const int v = 2 * (id >> 7) + ((id >> 5) & 1);
           uint16_t* dst = (uint16_t*)(sVt + (8 * v) * SVT_STRIDE + 2 * j);
-#if defined(ATTN_ABLATE) && ATTN_ABLATE == 2
-          if (rv[i][0] == 0x12345678u)
-#endif
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             dst[e * (SVT_STRIDE / 2)] = (uint16_t)((rv[i][e >> 1] >> ((e & 1) * 16)) & 0xffffu);
@@ -216,16 +184,9 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
   // does not leave 68 v_cmp/v_cndmask per tile in the hot loop (hipcc if-converts a plain `if`)
   auto tile_body = [&](int t, auto ragged) {
     __syncthreads();          // previous tile fully consumed
-#if defined(ATTN_ABLATE) && ATTN_ABLATE == 5
-    if (t == 0)
-#endif
     store_kv();
     __syncthreads();
-#if defined(ATTN_ABLATE) && ATTN_ABLATE == 4
-    if (t + 1 < ntiles && gi.k_count < 0) load_kv((t + 1) * 64);
-#else
     if (t + 1 < ntiles) load_kv((t + 1) * 64);   // in flight during the MFMAs below
-#endif
 
     // ---- S^T = K Q^T : two 32-key sub-tiles
     f32x16 s[2];
@@ -266,40 +227,17 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-#if defined(ATTN_ABLATE) && ATTN_ABLATE == 1
-        const float e = s[kt][r] * sc - m_new;
-#elif defined(ATTN_PKFMA)
-        // experiment (-DATTN_PKFMA): the exp2 argument two lanes-worth at a time (v_pk_fma_f32): same fma, half the issue slots
-        float e;
-        if ((r & 1) == 0) {
-          typedef __attribute__((ext_vector_type(2))) float f32x2;
-          const f32x2 a2 = {s[kt][r], s[kt][r + 1]}, sc2 = {sc, sc}, m2 = {-m_new, -m_new};
-          const f32x2 e2 = __builtin_elementwise_fma(a2, sc2, m2);
-          s[kt][r + 1] = e2[1];
-          e = __builtin_amdgcn_exp2f(e2[0]);
-        } else {
-          e = __builtin_amdgcn_exp2f(s[kt][r]);
-        }
-#else
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
-#endif
         s[kt][r] = e;
-#ifndef ATTN_ROWSUM_MFMA
         ps += e;
-#endif
       }
-#ifndef ATTN_ROWSUM_MFMA
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
-#endif
     if (__any(m_new != m_run)) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-#ifdef ATTN_ROWSUM_MFMA
-      osum[0] *= alpha;
-#endif
     }
     m_run = m_new;
     // ---- O^T += V^T P^T : P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
@@ -310,20 +248,13 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * st + j];
-#ifdef ATTN_ROWSUM_MFMA
-        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones_bf16), pf, osum, 0, 0, 0);
-#endif
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const char* vb = sVt + (dt * 32 + l31) * SVT_STRIDE + (32 * kt + 16 * st + 4 * half) * 2;
           const u32x2 v0 = *(const u32x2*)(vb);
           const u32x2 v1 = *(const u32x2*)(vb + 16);
           u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-#if defined(ATTN_ABLATE) && ATTN_ABLATE == 3
-          o[dt][0] += __uint_as_float(vf[0]) * (float)pf[0];
-#else
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
-#endif
         }
       }
   };
@@ -331,9 +262,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
   for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
   // ---- normalise and store: lane owns query qi, d = 32*dt + (r&3) + 8*(r>>2) + 4*half
-#ifdef ATTN_ROWSUM_MFMA
-  l_run = osum[0];
-#endif
   if (qok) {
     const float inv = 1.f / l_run;
     if (p.lse2 && half == 0) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);   // v_log_f32 = log2
@@ -368,11 +296,22 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
 //   * tile t + 1 is in flight while tile t is consumed: one raw s_barrier per tile behind a counted s_waitcnt.
 // Same arithmetic as attn_mfma_kernel (S^T = K Q^T in the log2 domain, lane-local online softmax, P as the B operand straight from the
 // S^T registers): bitwise the same output.
-#ifndef ATTN_DMA_WAVES
-#define ATTN_DMA_WAVES 2
-#endif
-template <int D>
-__global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const AttnParams p) {
+// FAST (round 4; every launch that does not export the log-sum-exp): the softmax loop on a VALU diet.  The per-128-query loop issued
+// 15 VALU instructions per MFMA (profiles/r03_pmc_sq.txt) - 32 v_max, 32 v_fma (scale, subtract the max), 32 v_exp, 32 v_add, 16
+// v_cvt_pk and a 32-multiply rescale of O^T on almost every early tile - against 512 MFMA cycles per tile.  Now
+//   * Q is multiplied by scale * log2(e) ONCE (fp32, rounded back to bf16: the reference itself rounds q * ch^-1/4 in its 16-bit
+//     mode, unet:231-236), so S^T comes out of the matrix pipe in the log2 domain;
+//   * the accumulator operand of the first S^T MFMA of a sub-tile is a register block holding -m (the running reference of this lane's
+//     query) instead of zero: the MFMA delivers S - m, the subtraction costs nothing;
+//   * m only moves when some row's tile maximum exceeds it by more than 8 (thresholded defer-max: P <= 2^8, exact in the fp32 sums and
+//     harmless to the bf16 P operand, whose precision is relative); the rescale of O^T / l and the 32 subtractions of the new offset
+//     live in that rare wave-uniform branch.  The first tile always takes it (m starts at 0, not at -inf: -m must be a finite C operand);
+//   * the row maximum folds in triples (v_max3_f32).
+// Per tile and wave that leaves 16 v_max3 + 32 v_exp + 32 v_add + 16 v_cvt_pk (+ ~10): ~7 VALU instructions per MFMA.
+// The non-FAST instance keeps the exact-scale arithmetic of attn_mfma_kernel (bitwise the same output) for the training forward,
+// whose log-sum-exp feeds a backward that recomputes P from the unscaled q.
+template <int D, bool FAST>
+__global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
   static_assert(D == 64, "DMA-staged attention: head width 64 (one 128-byte LDS row per key)");
   constexpr int KST = D / 16, DT = D / 32, TILE_B = 64 * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -387,6 +326,7 @@ __global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const Att
   const GroupInfo gi = group_info(p, bg);
   const int q0 = qt * 128;
   if (q0 >= gi.q_count) return;        // uniform per block
+  const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l31, half) holds d = 16 s + 8 half + [0, 8)
   const int qi = q0 + wave * 32 + l31;
@@ -398,6 +338,13 @@ __global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const Att
     for (int s = 0; s < KST; ++s) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (qok) v = *(const u32x4*)(qp + (s * 16 + half * 8) * 2);
+      if (FAST) {
+        float f[8];
+        Elt<__bf16>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= sc;
+        v = Elt<__bf16>::pack(f);
+      }
       qf[s] = v;
     }
   }
@@ -406,8 +353,10 @@ __global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const Att
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
+  float m_run = FAST ? 0.f : -1e30f, l_run = 0.f;
+  f32x16 negm;                         // FAST: sixteen copies of -m_run, the C operand of the first S^T MFMA of every sub-tile
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
   // ---- DMA: wave w stages row groups {w, w + 4} of K and of V; lane L of a group covers row 8 g + L / 8, physical chunk L % 8
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -447,19 +396,9 @@ __global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const Att
 
   const int ntiles = (gi.k_count + 63) >> 6;
   issue(0, 0);
-  // S^T = K Q^T of the tile in `stage`: two 32-key sub-tiles, the first k-step on a zero accumulator
+  // S^T = K Q^T of the tile in `stage`: two 32-key sub-tiles; the first k-step accumulates onto -m (FAST) or zero
   auto compute_s = [&](int stage, f32x16 (&s)[2]) {
     const char* kb = kbase + stage * TILE_B;
-#ifdef ATTN_DMA_LEAN          // fragments read where they are consumed (4 waves per SIMD: 128 registers)
-#pragma unroll
-    for (int st = 0; st < KST; ++st)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const u32x4 kf1 = *(const u32x4*)(kb + kt * 32 * 128 + (((2 * st + half) ^ kx) * 16));
-        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf1), __builtin_bit_cast(bf16x8, qf[st]), st == 0 ? z : s[kt], 0, 0, 0);
-      }
-#else
     u32x4 kf[KST][2];
 #pragma unroll
     for (int st = 0; st < KST; ++st)
@@ -468,14 +407,13 @@ __global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const Att
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0][kt]), __builtin_bit_cast(bf16x8, qf[0]), z, 0, 0, 0);
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0][kt]), __builtin_bit_cast(bf16x8, qf[0]), FAST ? negm : z, 0, 0, 0);
     }
 #pragma unroll
     for (int st = 1; st < KST; ++st)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[st][kt]), __builtin_bit_cast(bf16x8, qf[st]), s[kt], 0, 0, 0);
-#endif
   };
   // V^T fragments of the tile in `stage` (transposing reads)
   auto read_v = [&](int stage, bf16x8 (&vf)[2][2][DT]) {
@@ -514,57 +452,74 @@ __global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const Att
           s[kt][r] = kk < gi.k_count ? s[kt][r] : -3e38f;
         }
     }
-#ifdef ATTN_DMA_CHAINS
-    float mxp[4] = {-3e38f, -3e38f, -3e38f, -3e38f};
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mxp[r & 3] = fmaxf(mxp[r & 3], s[kt][r]);
-    float mx = fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3]));
-#else
-    float mx = -3e38f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-#endif
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * sc);        // sc > 0: max commutes with the scale
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-#ifdef ATTN_DMA_CHAINS
-    float psp[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
-        s[kt][r] = e;
-        psp[r & 3] += e;
-      }
-    float ps = (psp[0] + psp[1]) + (psp[2] + psp[3]);
-#else
     float ps = 0.f;
+    if constexpr (FAST) {
+      // s = S - m_run (log2 domain).  Row maximum: eleven 3-input folds per sub-tile pair instead of 31 v_max
+      float g[10];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int i = 0; i < 10; ++i) g[i] = fmaxf(fmaxf(s[i / 5][3 * (i % 5)], s[i / 5][3 * (i % 5) + 1]), s[i / 5][3 * (i % 5) + 2]);
+      float mx = fmaxf(fmaxf(g[0], g[1]), g[2]);
+      mx = fmaxf(fmaxf(mx, g[3]), g[4]);
+      mx = fmaxf(fmaxf(mx, g[5]), g[6]);
+      mx = fmaxf(fmaxf(mx, g[7]), g[8]);
+      mx = fmaxf(fmaxf(mx, g[9]), fmaxf(s[0][15], s[1][15]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (t == 0 || __any(mx > 8.f)) {                     // wave-uniform, rare after the first tile: move the reference
+        const float d = t == 0 ? mx : fmaxf(mx, 0.f);
+        if (t != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          l_run *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
-        s[kt][r] = e;
-        ps += e;
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] -= d;
       }
-#endif
-    ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
-    if (__any(m_new != m_run)) {
+      asm volatile("" : "+v"(negm));                       // sixteen live registers, not a splat re-materialised per MFMA
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kt][r]);
+          s[kt][r] = e;
+          ps += e;
+        }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run += ps;
+    } else {
+      float mx = -3e38f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * sc);        // sc > 0: max commutes with the scale
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
+          s[kt][r] = e;
+          ps += e;
+        }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      if (__any(m_new != m_run)) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+      m_run = m_new;
     }
-    m_run = m_new;
-#ifdef ATTN_DMA_LEAN
-    read_v(t & 1, vf);
-#endif
     // P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -578,49 +533,22 @@ __global__ __launch_bounds__(256, ATTN_DMA_WAVES) void attn_dma_kernel(const Att
       }
   };
   const int nfull = gi.k_count >> 6;
-#ifdef ATTN_DMA_PIPE
-  // software pipeline inside the wave: the S^T MFMAs of tile t + 1 are issued BEFORE the softmax of tile t, so the matrix pipe works
-  // under this wave's own VALU phase (not only under another wave's); two score register sets, two waves per SIMD
-  f32x16 sa[2], sb[2];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (ntiles > 1) issue(1, 64);
-  compute_s(0, sa);
-  auto step = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2]) {
-    bf16x8 vf[2][2][DT];
-    read_v(t & 1, vf);
-    if (t + 1 < ntiles) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // tile t + 1 has landed; this wave holds tile t's V fragments
-      __builtin_amdgcn_s_barrier();                                  // ... every wave does: stage t & 1 is free
-      asm volatile("" ::: "memory");
-      if (t + 2 < ntiles) issue(t & 1, (t + 2) * 64);
-      compute_s((t + 1) & 1, snext);
-    }
-    if (t >= nfull) softmax_pv(t, scur, vf, std::true_type{});
-    else softmax_pv(t, scur, vf, std::false_type{});
-  };
-  for (int t = 0; t < ntiles; t += 2) {
-    step(t, sa, sb);
-    if (t + 1 < ntiles) step(t + 1, sb, sa);
-  }
-#else
   auto tile_body = [&](int t, auto ragged) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this tile's DMA (the only one in flight) has landed
     __builtin_amdgcn_s_barrier();                                    // ... for every wave; everyone is past the other stage's reads
     asm volatile("" ::: "memory");
-    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64);            // in flight during this tile's MFMAs
     f32x16 s[2];
     compute_s(t & 1, s);
     bf16x8 vf[2][2][DT];
-#ifndef ATTN_DMA_LEAN
     read_v(t & 1, vf);                                               // requested under the softmax
-#endif
+    // the next tile's DMA goes out BEHIND the transposing reads: hipcc cannot tell that ds_read_b64_tr_b16 does not touch the stage an
+    // outstanding LDS-DMA writes and put s_waitcnt vmcnt(0) in front of the first one - the wave sat out the whole L2 round trip of
+    // the tile it had just requested (round 3 ISA).  In flight during this tile's softmax and P V, and every other wave's tile.
+    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64);
     softmax_pv(t, s, vf, ragged);
   };
   for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
-#endif
   // ---- normalise, transpose through LDS (stage 0 of K / V: free after the last tile) and store whole 128-byte head rows
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -831,11 +759,7 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-#if defined(ATS_ABLATE) && ATS_ABLATE == 4      // no exp
-        const float e = __builtin_fmaf(s[kt][r], sc, -m_new);
-#else
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
-#endif
         s[kt][r] = e;
         psp[r & 3] += e;
       }
@@ -865,20 +789,10 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
   load_stage(0);
   for (int k0 = 0; k0 < gi.k_count; k0 += ATS_KEYS) {
     __syncthreads();                       // the previous stage is fully consumed
-#if defined(ATS_ABLATE) && ATS_ABLATE == 3      // stage only the first 256 keys: no staging cost in the loop
-    if (k0 == 0)
-#endif
     store_stage();
     __syncthreads();
-#if defined(ATS_ABLATE) && ATS_ABLATE == 3
-    if (gi.k_count < 0)
-#endif
     if (k0 + ATS_KEYS < gi.k_count) load_stage(k0 + ATS_KEYS);    // in flight during this stage's MFMAs
-#if defined(ATS_ABLATE) && ATS_ABLATE == 2      // no compute: prologue + staging + epilogue only
-    if (live && gi.k_count < 0) {
-#else
     if (live) {
-#endif
       const int kn = min(gi.k_count - k0, ATS_KEYS);
       const int nfull = kn >> 6, nsub = (kn + 63) >> 6;
       read_k(0);
@@ -905,9 +819,6 @@ __global__ __launch_bounds__(512, 1) void attn_stage_kernel(const AttnParams p) 
         for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[dt][4 * q4 + e] * inv);
         *(bf16x4*)(so + l31 * SK + d * 2) = w;
       }
-#if defined(ATS_ABLATE) && ATS_ABLATE == 1      // no output stores
-    if (l_run == -123.f)
-#endif
 #pragma unroll
     for (int ps = 0; ps < 32 * DV / 64; ++ps) {
       const int idx = ps * 64 + lane;
@@ -1292,7 +1203,8 @@ template <int D>
 static int launch_dma(const AttnParams& p, int qmax, hipStream_t st) {
   const size_t lds = 4 * 64 * 128;
   dim3 grid(cdiv(qmax, 128), p.heads, p.nb * p.G);
-  hipLaunchKernelGGL(attn_dma_kernel<D>, grid, dim3(256), lds, st, p);
+  if (p.lse2) hipLaunchKernelGGL((attn_dma_kernel<D, false>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((attn_dma_kernel<D, true>), grid, dim3(256), lds, st, p);
   return mmd_check_launch("attn_dma");
 }
 
@@ -1357,9 +1269,25 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   const bool stage_ok = dtype == MMD_BF16 && aligned && ch == 64 && ldo % 8 == 0 && (uintptr_t)O % 16 == 0;
   // DMA-staged kernel (impl 4; the default at head width 64 unless MMD_ATTN_DMA=0): 32-bit byte offsets into the K/V rows
   static const bool dma_on = [] { const char* e = getenv("MMD_ATTN_DMA"); return !(e && e[0] == '0'); }();
-  const bool dma_ok = stage_ok && (int64_t)nb * k_rows_per_batch * ldkv * 2 < 0x7fffffffLL;
-  if (impl == 4 && !dma_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 4 (DMA-staged): needs bf16, head width 64, aligned rows, K/V below 2 GB");
-  if (dma_ok && (impl == 4 || (impl == 0 && dma_on))) return launch_dma<64>(p, qmax, st);
+  // Its descriptor covers the K/V rows of the batches of ONE launch: a batch range beyond 2 GB is cut into several launches of
+  // the same kernel (the kernel family of a layer - and with it the last bits of its output - must not depend on the batch size)
+  const int64_t kv_batch_bytes = k_rows_per_batch * ldkv * 2;
+  const bool dma_ok = stage_ok && kv_batch_bytes < 0x7fffffffLL;
+  if (impl == 4 && !dma_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 4 (DMA-staged): needs bf16, head width 64, aligned rows, one batch of K/V below 2 GB");
+  if (dma_ok && (impl == 4 || (impl == 0 && dma_on))) {
+    const int per = (int)(0x7fffffffLL / kv_batch_bytes) < nb ? (int)(0x7fffffffLL / kv_batch_bytes) : nb;
+    for (int n0 = 0; n0 < nb; n0 += per) {
+      AttnParams c = p;
+      c.nb = nb - n0 < per ? nb - n0 : per;
+      c.Q = p.Q + (int64_t)n0 * q_rows_per_batch * ldq * 2;
+      c.KV = p.KV + (int64_t)n0 * kv_batch_bytes;
+      c.O = p.O + (int64_t)n0 * q_rows_per_batch * ldo * 2;
+      if (p.lse2) c.lse2 = p.lse2 + (int64_t)n0 * q_rows_per_batch * heads;
+      const int rc = launch_dma<64>(c, qmax, st);
+      if (rc != MMD_OK) return rc;
+    }
+    return MMD_OK;
+  }
   if (impl == 3 && !stage_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 3 (staged window): needs bf16, head width 64, aligned rows");
   // auto rule from tools/attn_bench.py on MI355X (batch 4): the staged kernel wins where a group has FEW queries per staged key
   // (audio <- video at ds2: 400 queries x 1024 keys, 63 us vs 74 us) and loses a few percent where the per-128-query kernel's three

@@ -101,16 +101,9 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
 #define ROWB 144   // LDS bytes per staged operand row
 
 // Fragment reads of a K step: hipcc places each ds_read_b128 right in front of the MFMA that consumes it and waits lgkmcnt(0) - eight
-// exposed LDS round trips per K step (GEMM_FRAG_HOIST=0 keeps that order for A/B builds).  With the 16 reads of a step issued first
+// exposed LDS round trips per K step.  With the 16 reads of a step issued first
 // and pinned there, every MFMA waits with a counted lgkmcnt and the LDS latency of read n + 1 hides under MFMA n.
-#ifndef GEMM_FRAG_HOIST
-#define GEMM_FRAG_HOIST 1
-#endif
-#if GEMM_FRAG_HOIST
 #define FRAG_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define FRAG_FENCE() do { } while (0)
-#endif
 
 // Padding taps / out-of-range rows read this zero page instead of branching around the load: every thread then issues a
 // STATIC number of global loads per K step, so the compiler can keep the newer register stage in flight with a counted
@@ -118,21 +111,6 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) uint32_t g_zero_row[32] = {};      // 128 bytes: one K plane of a padding row (strip kernel)
 
-#ifdef GEMM_TIMELINE
-// Debug builds (tools/gemm_timeline.py, -DGEMM_TIMELINE): thread 0 of every direct-to-LDS GEMM block stamps s_memrealtime
-// (100 MHz) at block start / first operands landed / main loop done / stores issued, plus its XCC and CU ids.
-__device__ unsigned long long* g_gemm_timeline = nullptr;
-extern "C" int mmd_debug_set_gemm_timeline(void* buf) {
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_timeline), &buf, sizeof(buf));
-  return e == hipSuccess ? MMD_OK : mmd_set_error(MMD_ERR_LAUNCH, "set_gemm_timeline: %s", hipGetErrorString(e));
-}
-#define GEMM_TL(slot)                                                                            \
-  do {                                                                                           \
-    if (threadIdx.x == 0 && g_gemm_timeline) g_gemm_timeline[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
-  } while (0)
-#else
-#define GEMM_TL(slot) do { } while (0)
-#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
@@ -440,7 +418,6 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
   float* sC = (float*)smem;
   int* s_taps = (int*)(smem + MAIN_B);
 
-  GEMM_TL(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -646,15 +623,10 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
     for (int j = 0; j < 8; ++j) bs[j] = (p.bias && e_co < p.Cout) ? p.bias[e_co + j] : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    GEMM_TL(1);
     for (int it = 0; it + 1 < nit; ++it) {
-#ifndef GEMM_ABLATE_NODMA                                   // ablation builds (tools/gemm_bench.py): compute-only / DMA-only loops
       advance();
       issue(cur ^ 1);                                      // DMA of the next K step runs under this step's MFMAs
-#endif
-#ifndef GEMM_ABLATE_NOMMA
       compute(cur);
-#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       cur ^= 1;
@@ -670,7 +642,6 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
       issue(s0);
       advance();
     }
-    GEMM_TL(1);
     for (int it = 0; it + 1 < nit; ++it) {
       const int ahead = nit - 1 - it < D - 1 ? nit - 1 - it : D - 1;       // younger steps that may stay in flight (uniform)
       if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -701,7 +672,6 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
   }
   compute(cur);
   __syncthreads();                                       // every wave is past its last operand read: sC may alias
-  GEMM_TL(2);
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -760,15 +730,6 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
     epilogue_stats<128, 128>(p, ssum, ssq, sC, m0, n0, tid);
     if (p.gt.acc) gn_tail_arrive(p.gt, (unsigned*)sC, tid, 256, gridDim.x);
   }
-  GEMM_TL(3);
-#ifdef GEMM_TIMELINE
-  if (threadIdx.x == 0 && g_gemm_timeline) {
-    unsigned xcc, hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    g_gemm_timeline[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -805,7 +766,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   int* s_taps = (int*)(smem + MAIN_B);
   float* sGN = (float*)(smem + MAIN_B + 336);  // GN: [2 chunk parities][a (64 channels) | b (64 channels)]
 
-  GEMM_TL(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -988,7 +948,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
     transform(0, 0, -1);
     __syncthreads();
   }
-  GEMM_TL(1);
   int c = 0, t = 0;
   for (int it = 0; it + 1 < nit; ++it) {
     int tn = t + 1, cn = c;
@@ -1020,7 +979,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   }
   compute((nit - 1) & 1, c & 1, t);
   __syncthreads();                                           // every wave is past its last operand read: sC may alias
-  GEMM_TL(2);
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -1059,7 +1017,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
         *(u32x4*)(p.Y + (m * p.ldy + e_co + h * EPV) * ES) = Elt<T>::pack(v + h * EPV);
     }
   }
-  GEMM_TL(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1369,50 +1326,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 // never by timing (ops.strip_tile_pinned).
 // Grid = row strips x nsplit column ranges (nsplit fills the chip when M is small; results do not depend on it).
 // (halfwave_total - the DPP fold of the quad statistics - lives in mmd_common.h: the fused VideoConv kernel shares it.)
-__device__ __forceinline__ float halfwave_sum16(const float (&u)[16], int l31) {
-  // sum of u[i] over the 32 lanes of a half-wave for all sixteen i at once: each xor step halves what a lane carries; the lane
-  // ends with the total of u[l31 >> 1] (the xor-1 step completes it in both lanes of a pair)
-  float a8[8], a4[4], a2[2];
-  {
-    const bool hi = (l31 & 16) != 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float keep = hi ? u[8 + i] : u[i], send = hi ? u[i] : u[8 + i];
-      a8[i] = keep + __shfl_xor(send, 16, 64);
-    }
-  }
-  {
-    const bool hi = (l31 & 8) != 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float keep = hi ? a8[4 + i] : a8[i], send = hi ? a8[i] : a8[4 + i];
-      a4[i] = keep + __shfl_xor(send, 8, 64);
-    }
-  }
-  {
-    const bool hi = (l31 & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float keep = hi ? a4[2 + i] : a4[i], send = hi ? a4[i] : a4[2 + i];
-      a2[i] = keep + __shfl_xor(send, 4, 64);
-    }
-  }
-  const bool hi = (l31 & 2) != 0;
-  const float keep = hi ? a2[1] : a2[0], send = hi ? a2[0] : a2[1];
-  float a1 = keep + __shfl_xor(send, 2, 64);
-  a1 += __shfl_xor(a1, 1, 64);
-  return a1;
-}
-
-#ifdef STRIP_JOINT
-#define STRIP_WAVES_K128 2                   // four chains need 64 accumulator registers: two waves per SIMD
-#else
-#define STRIP_WAVES_K128 3
-#endif
 template <int KS, int RF, int CC, int GNM, int STM>   // STM: output statistics 0 none / 1 per-column records / 2 in-launch tail (compile
                                              // time: the runtime branches cost the K = 128 instance 30 spilled registers).  GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
                                              // normalisation in one kernel spill ~100 registers around the branch)
-__global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
+__global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
   constexpr int K = 64 * KS;                 // input channels
   constexpr int NCG = 4 * KS;                // 16-channel k-steps (one MFMA each)
   constexpr int BR = 128 * RF;               // rows per block: 4 waves x RF fragments of 32 rows
@@ -1575,46 +1492,11 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
     t_nsl = (int)(((int64_t)m0 + BR - 1) / p.gt.rows_per_slice) - t_s0 + 1;
     t_lds = t_nsl * (Cs >> 2) * 4 <= 2048;
   }
-#if defined(STRIP_ABLATE) && STRIP_ABLATE == 4      // prologue + one chunk
-  for (int ci = 0; ci < 1; ++ci) {
-#else
   for (int ci = 0; ci < nchunk; ++ci) {
-#endif
     const int st = ci & 1;
-#if !(defined(STRIP_ABLATE) && STRIP_ABLATE == 3)    // 3: no weight DMA after chunk 0 (the loop never waits for L2)
     if (ci + 1 < nchunk) issue(st ^ 1, ci + 1);         // next chunk's weights land under this chunk's MFMAs
-#endif
     u32x4 outv[RF][2];                                  // the LAST sub-tile's stores wait until after the barrier (see above)
     float srec[2][2];
-#ifdef STRIP_JOINT
-    // experiment (-DSTRIP_JOINT, K = 128 only): the MFMAs of BOTH 32-channel sub-tiles of a chunk issued together = four independent
-    // accumulator chains per wave instead of two (the SQ counters show ~50 % issue stalls), the epilogues after them
-    constexpr bool JOINT = KS == 2 && NA == 2;
-    f32x16 jacc[JOINT ? NA : 1][RF];
-    if (JOINT) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int f = 0; f < RF; ++f)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) jacc[JOINT ? a : 0][f][r] = 0.f;
-#pragma unroll
-      for (int pl = 0; pl < KS; ++pl)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          u32x4 fw2[NA];
-#pragma unroll
-          for (int a = 0; a < NA; ++a)
-            fw2[a] = *(const u32x4*)(sW + st * STAGE_B + (a * 32 + l31) * 128 + pl * PLANE_B + (((2 * c + half) ^ xsw) * 16));
-#pragma unroll
-          for (int a = 0; a < NA; ++a)
-#pragma unroll
-            for (int f = 0; f < RF; ++f) Mma<__bf16>::run(fw2[a], xa[f][4 * pl + c], jacc[JOINT ? a : 0][f]);
-        }
-    }
-#else
-    constexpr bool JOINT = false;
-#endif
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
       const int cb = ci * CC + a * 32;                   // first column of the sub-tile inside this block's range
@@ -1631,26 +1513,14 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
       for (int f = 0; f < RF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-#ifdef STRIP_JOINT
-      if (JOINT) {
-#pragma unroll
-        for (int f = 0; f < RF; ++f) acc[f] = jacc[JOINT ? a : 0][f];
-      }
-#endif
       const char* bW = sW + st * STAGE_B + (a * 32 + l31) * 128;
 #pragma unroll
-      for (int pl = 0; pl < (JOINT ? 0 : KS); ++pl)
+      for (int pl = 0; pl < KS; ++pl)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-#if defined(STRIP_ABLATE) && STRIP_ABLATE == 1      // ablation builds (tools/strip_ablate.sh): no weight fragment reads, no MFMAs
-          if (pl == 0 && c == 0)
-#pragma unroll
-            for (int f = 0; f < RF; ++f) acc[f][0] = __uint_as_float(xa[f][0].x);
-#else
           const u32x4 fw = *(const u32x4*)(bW + pl * PLANE_B + (((2 * c + half) ^ xsw) * 16));
 #pragma unroll
           for (int f = 0; f < RF; ++f) Mma<__bf16>::run(fw, xa[f][4 * pl + c], acc[f]);
-#endif
         }
       // acc[f][4 q + j] = channel 8 q + 4 half + j of row l31.  Pair q = 2 j2 (vdst) with q = 2 j2 + 1 (src): afterwards this lane
       // holds the 8 consecutive channels 16 j2 + 8 half .. + 8 of its row
@@ -1680,13 +1550,8 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
             for (int j = 0; j < 8; ++j) v[j] += rf[j];
           }
           const u32x4 pk = Elt<__bf16>::pack(v);
-#if defined(STRIP_ABLATE) && STRIP_ABLATE == 2      // no output stores (one never-taken store keeps the epilogue alive)
-          if (pk.x == 0x7fc17fc1u && pk.y == 0x12345678u) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = pk;
-          if (DEFER && a == NA - 1) outv[f][j2] = pk;
-#else
           if (DEFER && a == NA - 1) outv[f][j2] = pk;
           else if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = pk;
-#endif
           if (STM != 0) {                                // statistics of the values as STORED: the lane's 8 channels = two QUADS
             float rf[8];
             Elt<__bf16>::unpack(pk, rf);
@@ -1752,11 +1617,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? STRIP_WAVES_K128 : 2)) void conv1x1
       const int col = cbase + ci * CC + (NA - 1) * 32 + 16 * j2 + 8 * half;
 #pragma unroll
       for (int f = 0; f < RF; ++f)
-#if defined(STRIP_ABLATE) && STRIP_ABLATE == 2
-        if (outv[f][j2].x == 0x7fc17fc1u && outv[f][j2].y == 0x12345678u) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = outv[f][j2];
-#else
         if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = outv[f][j2];
-#endif
       if (RF == 1) {
         if (STM == 1 && wave_ok && (wave & 1) == 0 && (l31 >> 1) == 8) {
           const float* o = sRec + ((((ci & 1) * 4 + wave + 1) * (NA * 2) + (NA - 1) * 2 + j2) * 2 + half) * 4 + (l31 & 1) * 2;

@@ -132,19 +132,13 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     else
       dma_dummy();
   };
-  auto issue_ws = [&](int slot, int s1) {                  // spatial step s1 = chunk * 3 + tap row: three linear 1 KB pieces per wave
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * VC_WSLOT_B + (wave + 8 * i) * 1024), 16, lane * 16,
-                                               s1 * VC_WSLOT_B + (wave + 8 * i) * 1024, 0, 0);
+  auto issue_ws = [&](int slot, int s1, int i) {           // piece i (of three per wave) of spatial step s1 = chunk * 3 + tap row: a linear 1 KB copy
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * VC_WSLOT_B + (wave + 8 * i) * 1024), 16, lane * 16,
+                                             s1 * VC_WSLOT_B + (wave + 8 * i) * 1024, 0, 0);
   };
-  auto issue_wt = [&](int slot, int s2) {                  // temporal step s2 = tap * 2 + plane: two pieces + one dummy
-    const int base = nchunk * 3 * VC_WSLOT_B + s2 * VC_WT_B;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * VC_WSLOT_B + (wave + 8 * i) * 1024), 16, lane * 16,
-                                               base + (wave + 8 * i) * 1024, 0, 0);
-    dma_dummy();
+  auto issue_wt = [&](int slot, int s2, int i) {           // piece i (of two per wave) of temporal step s2 = tap * 2 + plane
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * VC_WSLOT_B + (wave + 8 * i) * 1024), 16, lane * 16,
+                                             nchunk * 3 * VC_WSLOT_B + s2 * VC_WT_B + (wave + 8 * i) * 1024, 0, 0);
   };
   auto issue_gn = [&](int c) {                             // one DMA instruction: a | b of chunk c (32 + 32 floats) -> ring slot c & 1
     if (GN && wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(gn_src + c * 32), (lptr_t)(sGN + (c & 1) * 64), 4, 0, 0);
@@ -204,30 +198,53 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     *(u32x4*)q = ((gvalid >> i) & 1u) ? y : tv;
   };
 
-  // ---- one spatial step: tap row J (dh = J - 1) of chunk c.  TR: 0 none, 1 slots 0..2 of the NEXT stage, 2 slots 3 (, 4) of THIS stage
-  auto spatial = [&](auto jtag, int c, bool more) {
+  // ---- one spatial step: tap row J (dh = J - 1) of chunk c; MORE: another chunk follows.  Six sub-steps k = (tap dw, 16-channel k-step),
+  // each {fragment reads two sub-steps ahead | 4 MFMAs | ONE DMA instruction | half a slot of the input norm}: the DMA issue (~100
+  // cycles apiece beside LDS traffic) and the norm's VALU work run under the MFMAs instead of in front of them.
+  // DMA groups (per wave, in issue order) and the counted waits they imply (a step's top wait leaves exactly the previous step's
+  // group - minus what this step needs of it - in flight):
+  //   J = 0: halo rows hh 0..3 of chunk c + 1 (3), then the weights of step s + 2 (3)      top of J = 1: vmcnt(3) - the halo pieces landed
+  //   J = 1: weights of step s + 2 (3), halo rows hh 4..5 of chunk c + 1 (2)               top of J = 2: vmcnt(5)
+  //   J = 2: weights of step s + 2 (3), affine rows of chunk c + 2 (GN: 1)                 top of J = 0: vmcnt(3 + GN)
+  //   last chunk: J = 0 weights (3); J = 1 / J = 2 the temporal steps 0 / 1 (2 each)       tops: vmcnt(3), vmcnt(2), (temporal) vmcnt(2)
+  // Norm slots (GN): 0, 1 of the next stage at J = 1, slot 2 at J = 2 (their pieces landed with the top of J = 1), slots 3 (, 4) of
+  // THIS stage at J = 0 (rows hh 4..5: landed with this step's top wait, not read by the dh = -1 taps).
+  auto spatial = [&](auto jtag, auto mtag, int c) {
     constexpr int J = decltype(jtag)::value;
-    // everything but the newest DMA group has landed: this step's weights (issued two steps ago) and the halo pieces it may touch
-    if constexpr (J == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    constexpr bool MORE = decltype(mtag)::value;
+    if constexpr (J == 0) {
+      if constexpr (GN) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    } else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (MORE) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // ... for every wave; every wave is past its fragment reads of the previous step
     asm volatile("" ::: "memory");
-    // DMA group: weights of the step after next into the slot the previous step left (3), then J = 0: halo rows hh 0..3 of the next
-    // chunk (3), J = 1: its rows hh 4..5 (2), J = 2: the affine rows of the chunk after next (1)
-    if (J == 0 || more) issue_ws((J + 2) % 3, c * 3 + J + 2);
-    else issue_wt((J + 2) % 3, J - 1);
-    if constexpr (J == 0) {
-      if (more) { issue_h((c + 1) & 1, c + 1, 0); issue_h((c + 1) & 1, c + 1, 1); issue_h((c + 1) & 1, c + 1, 2); }
-      else { dma_dummy(); dma_dummy(); dma_dummy(); }
-    } else if constexpr (J == 1) {
-      if (more) { issue_h((c + 1) & 1, c + 1, 3); issue_h((c + 1) & 1, c + 1, 4); }
-      else { dma_dummy(); dma_dummy(); }
-    } else {
-      if (c + 2 < nchunk) issue_gn(c + 2); else dma_dummy();
-    }
-    const int trmode = !GN ? 0 : (J == 2 ? (more ? 1 : 0) : (J == 0 ? (c > 0 ? 2 : 0) : 0));     // block-uniform
-    const int tstage = J == 2 ? (c + 1) & 1 : c & 1, tpar = tstage;
+    const int s1n = c * 3 + J + 2;                         // the spatial step whose weights go out now (slot (J + 2) % 3: the previous step left it)
+    auto dma = [&](int k) {
+      if constexpr (J == 0 && MORE) {
+        if (k < 3) issue_h((c + 1) & 1, c + 1, k); else issue_ws(2, s1n, k - 3);
+      } else if constexpr (J == 0) {
+        if (k < 3) issue_ws(2, s1n, k);
+      } else if constexpr (J == 1 && MORE) {
+        if (k < 3) issue_ws(0, s1n, k); else if (k < 5) issue_h((c + 1) & 1, c + 1, k);
+      } else if constexpr (J == 1) {
+        if (k < 2) issue_wt(0, 0, k);
+      } else if constexpr (MORE) {
+        if (k < 3) issue_ws(1, s1n, k);
+        else if (GN && k == 3) { if (c + 2 < nchunk) issue_gn(c + 2); else dma_dummy(); }
+      } else {
+        if (k < 2) issue_wt(1, 1, k);
+      }
+    };
+    const bool tr_on = GN && (J == 0 ? c > 0 : MORE);      // block-uniform
+    const int tstage = J == 0 ? c & 1 : (c + 1) & 1;       // the stage (= affine ring slot) whose slots this step normalises
+    auto tr = [&](int k) {                                 // half a slot behind MFMA group k
+      if (!tr_on) return;
+      const int i = J == 0 ? 3 + (k >> 1) : (J == 1 ? (k >> 1) : 2);
+      if ((J == 2 && k >= 2) || k >= 4 || (J == 0 && k >= 2 && wave >= 4)) return;
+      if (k & 1) tr_second(tstage, i); else tr_first(tstage, tstage, i);
+    };
     const char* bW = sW + J * VC_WSLOT_B + wl1;            // ring slot of step 3 c + J = J
     const char* bA[2];
     const int key = (ph + J) & 3;                          // halo rows hh = ph + 1 + dh
@@ -249,38 +266,33 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[k][a]), __builtin_bit_cast(bf16x8, fa[k][b]), acc[a][b], 0, 0, 0);
     };
-    auto tr = [&](int k) {                                 // the norm of (half of) one slot behind MFMA group k
-      if (trmode == 1) {                                   // slots 0, 1, 2: two sub-steps each
-        if (k & 1) tr_second(tstage, k >> 1); else tr_first(tstage, tpar, k >> 1);
-      } else if (trmode == 2) {                            // slot 3 (k = 0, 1), slot 4 (k = 2, 3; waves 0-3)
-        if (k < 2 || (k < 4 && wave < 4)) {
-          if (k & 1) tr_second(tstage, 3 + (k >> 1)); else tr_first(tstage, tpar, 3 + (k >> 1));
-        }
-      }
-    };
     rd(0); rd(1);
     __builtin_amdgcn_sched_barrier(0);
-    rd(2); mm(0); tr(0);
+    rd(2); mm(0); dma(0); tr(0);
     __builtin_amdgcn_sched_barrier(0);
-    rd(3); mm(1); tr(1);
+    rd(3); mm(1); dma(1); tr(1);
     __builtin_amdgcn_sched_barrier(0);
-    rd(4); mm(2); tr(2);
+    rd(4); mm(2); dma(2); tr(2);
     __builtin_amdgcn_sched_barrier(0);
-    rd(5); mm(3); tr(3);
+    rd(5); mm(3); dma(3); tr(3);
     __builtin_amdgcn_sched_barrier(0);
-    mm(4); tr(4);
+    mm(4); dma(4); tr(4);
     __builtin_amdgcn_sched_barrier(0);
-    mm(5); tr(5);
+    mm(5); dma(5); tr(5);
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- prologue: halo of chunk 0, the affine rows of chunks 0 / 1, the weights of steps 0 / 1; chunk 0 is normalised before the first MFMA
 #pragma unroll
   for (int j = 0; j < 5; ++j) issue_h(0, 0, j);
-  issue_gn(0);
-  if (nchunk > 1) issue_gn(1); else dma_dummy();
-  issue_ws(0, 0);
-  issue_ws(1, 1);
+  if (GN) {
+    issue_gn(0);
+    if (nchunk > 1) issue_gn(1);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) issue_ws(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) issue_ws(1, 1, i);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -291,12 +303,14 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     // (the first step's barrier orders these LDS writes before the first fragment reads)
   }
 
-  for (int c = 0; c < nchunk; ++c) {
-    const bool more = c + 1 < nchunk;
-    spatial(std::integral_constant<int, 0>{}, c, more);
-    spatial(std::integral_constant<int, 1>{}, c, more);
-    spatial(std::integral_constant<int, 2>{}, c, more);
+  for (int c = 0; c + 1 < nchunk; ++c) {
+    spatial(std::integral_constant<int, 0>{}, std::true_type{}, c);
+    spatial(std::integral_constant<int, 1>{}, std::true_type{}, c);
+    spatial(std::integral_constant<int, 2>{}, std::true_type{}, c);
   }
+  spatial(std::integral_constant<int, 0>{}, std::false_type{}, nchunk - 1);
+  spatial(std::integral_constant<int, 1>{}, std::false_type{}, nchunk - 1);
+  spatial(std::integral_constant<int, 2>{}, std::false_type{}, nchunk - 1);
 
   // ---- transition: T = bf16(acc + bias_s) as the temporal operand image (aliases the halo stages), frames -1 / 16 = zero rows
   __builtin_amdgcn_s_barrier();                            // every wave is past its last halo read
@@ -340,12 +354,11 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   // ---- phase 2: temporal k = 3 over T.  Step s2 = tap * 2 + plane in ring slot s2 % 3 (3 nchunk spatial steps: the ring continues)
   auto temporal = [&](auto stag) {
     constexpr int S2 = decltype(stag)::value;
-    if constexpr (S2 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    // the newest group in flight: the weights of step S2 + 1 (two pieces; none behind step 4)
+    if constexpr (S2 < 5) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (S2 + 2 < 6) issue_wt((S2 + 2) % 3, S2 + 2);
-    else { dma_dummy(); dma_dummy(); dma_dummy(); }
     constexpr int tap = S2 >> 1, plane = S2 & 1;
     const char* bW = sW + (S2 % 3) * VC_WSLOT_B + wl2;
     const char* bT = sA + plane * VC_TPLANE_B + tl2 + (tap - 1) * 2048;
@@ -363,11 +376,14 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[k][a]), __builtin_bit_cast(bf16x8, fa[k][b]), acc[a][b], 0, 0, 0);
     };
+    auto dma = [&](int k) {
+      if constexpr (S2 + 2 < 6) issue_wt((S2 + 2) % 3, S2 + 2, k);
+    };
     rd(0); rd(1);
     __builtin_amdgcn_sched_barrier(0);
-    rd(2); mm(0);
+    rd(2); mm(0); dma(0);
     __builtin_amdgcn_sched_barrier(0);
-    rd(3); mm(1);
+    rd(3); mm(1); dma(1);
     __builtin_amdgcn_sched_barrier(0);
     mm(2); mm(3);
     __builtin_amdgcn_sched_barrier(0);
@@ -378,7 +394,6 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   temporal(std::integral_constant<int, 3>{});
   temporal(std::integral_constant<int, 4>{});
   temporal(std::integral_constant<int, 5>{});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing dummies
 
   // ---- epilogue from the accumulators: + bias_t -> bf16 -> 16-byte row stores; quad statistics of the values as stored
   const int64_t mbase = (int64_t)n * 16 * HW + (int64_t)(h0 + ph) * p.W + w0 + pw;

@@ -346,3 +346,14 @@ def test_vconv_index_model():
     spec.loader.exec_module(m)
     assert m.check(N=1, H=8, W=4, Cin=64, with_gn=True, seed=1)
     assert m.check(N=2, H=4, W=4, Cin=32, with_gn=False, seed=2)
+
+
+def test_vconv_dma_schedule_model():
+    """The counted s_waitcnt vmcnt(N) of the fused VideoConv kernel against its DMA issue order (tools/vconv_dma_model.py): at the
+    top of every step everything the step reads - weights, the halo rows of its taps, the slots and affine rows of its norm pieces -
+    has landed, for 1 .. 12 channel chunks with and without the fused norm."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vconv_dma_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "vconv_dma_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.check()

@@ -380,17 +380,39 @@ def test_self_attention_staged_window(ops, T, heads):
         assert rel_l2(out.float().cpu(), ref) < tol(dt)
 
 
-def test_attention_softmax_spike(ops):
-    """Online-softmax rescale path: one key dominates late in the sequence (forces a big running-max jump)."""
+@pytest.mark.parametrize("spike_key,scale", [(250, 40.0), (70, 40.0), (3, 40.0), (250, -40.0)])
+def test_attention_softmax_spike(ops, spike_key, scale):
+    """Online-softmax rescale path: one key dominates (a big jump of the running reference) in the first tile, in the second and late in
+    the sequence - the branch the thresholded defer-max of the DMA-staged kernel (impl 4) only takes when a tile maximum exceeds the
+    reference by 2^8 - and one key far BELOW everything (all scores of a row negative: the reference must still start at the first
+    tile's maximum, not at zero)."""
     T, heads, ch = 300, 1, 64
     qkv = rnd(T, 3 * 64, dt=torch.bfloat16, seed=28) * 0.3
-    qkv[250, 64:128] = qkv[7, :64] * 40           # key 250 (4th tile) aligned with query 7
+    qkv[spike_key, 64:128] = qkv[7, :64] * scale           # key aligned (or anti-aligned) with query 7
     qkv = qkv.to(torch.bfloat16).float()
     ref = _ref_attn(qkv, qkv, heads, ch, torch.arange(T), torch.arange(T))
-    for impl in (2, 3):         # per-128-query kernel, staged-window kernel (the spike sits in the second key stage)
+    for impl in (2, 3, 4):      # per-128-query kernel, staged-window kernel, DMA-staged kernel
         out = torch.zeros(T, 64, dtype=torch.bfloat16, device="cuda")
         ops.attn(dev(qkv, torch.bfloat16), dev(qkv, torch.bfloat16), out, heads, ch, 1, 1, T, T, T, T, 1, impl=impl)
-        assert rel_l2(out.float().cpu(), ref) < 1e-2
+        assert torch.isfinite(out.float()).all()
+        assert rel_l2(out.float().cpu(), ref) < 1e-2, impl
+        assert rel_l2(out.float().cpu()[7], ref[7]) < 2e-2, impl            # the row that takes the jump
+
+
+def test_attention_all_scores_far_below_zero(ops):
+    """Every score of every row around -60 (log2 domain): a softmax reference that started at 0 would underflow every P to 0 and
+    divide by zero.  impl 4's first tile always moves the reference to the tile maximum."""
+    T, heads, ch = 200, 1, 64
+    q = torch.full((T, 64), 1.0) + rnd(T, 64, seed=5) * 0.05
+    k = -q * 5.0 + rnd(T, 64, seed=6) * 0.05
+    v = rnd(T, 64, seed=7)
+    qkv = torch.cat([q, k, v], dim=1).to(torch.bfloat16).float()
+    ref = _ref_attn(qkv, qkv, heads, ch, torch.arange(T), torch.arange(T))
+    for impl in (2, 4):
+        out = torch.zeros(T, 64, dtype=torch.bfloat16, device="cuda")
+        ops.attn(dev(qkv, torch.bfloat16), dev(qkv, torch.bfloat16), out, heads, ch, 1, 1, T, T, T, T, 1, impl=impl)
+        assert torch.isfinite(out.float()).all()
+        assert rel_l2(out.float().cpu(), ref) < 1e-2, impl
 
 
 @pytest.mark.parametrize("dt", DTYPES)

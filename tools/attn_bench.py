@@ -27,7 +27,7 @@ def main():
         H.call("mmd_event_create", ctypes.byref(e))
     st = H.stream_handle()
     only = os.environ.get("ATTN_BENCH_SHAPES")
-    impls = tuple(int(v) for v in os.environ.get("ATTN_BENCH_IMPLS", "2,3").split(","))
+    impls = tuple(int(v) for v in os.environ.get("ATTN_BENCH_IMPLS", "2,3,4").split(","))
     for si, (name, qr, qg, kr, kg, win, heads, ch) in enumerate(SHAPES):
         if only and str(si) not in only.split(","):
             continue
@@ -67,6 +67,19 @@ def main():
             H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
             us = ms.value / n * 1000
             line += f" | impl{impl}: {us:7.1f} us {flops/us/1e6:5.0f} TF/s ({100*flops/us/1e6/2500:4.1f}% mfma) e={err:.1e}{vs}"
+        if ch == 64:                   # the DMA-staged kernel's exact-scale instance (training forward): the round-3 softmax loop, for A/B
+            out = torch.zeros(N * qr, C, device="cuda", dtype=dt)
+            lse = torch.zeros(N * qr, heads, device="cuda")
+            for _ in range(2):
+                ops.attn_lse(q, kv, out, lse, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh)
+            H.call("mmd_event_record", ev[0], st)
+            for _ in range(10):
+                ops.attn_lse(q, kv, out, lse, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh)
+            H.call("mmd_event_record", ev[1], st)
+            ms = ctypes.c_float()
+            H.call("mmd_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
+            us = ms.value / 10 * 1000
+            line += f" | dma-exact(+lse): {us:7.1f} us {flops/us/1e6:5.0f} TF/s"
         print(line, flush=True)
 
 
