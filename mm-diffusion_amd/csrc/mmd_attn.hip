@@ -296,21 +296,11 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
 //   * tile t + 1 is in flight while tile t is consumed: one raw s_barrier per tile behind a counted s_waitcnt.
 // Same arithmetic as attn_mfma_kernel (S^T = K Q^T in the log2 domain, lane-local online softmax, P as the B operand straight from the
 // S^T registers): bitwise the same output.
-// FAST (round 4; every launch that does not export the log-sum-exp): the softmax loop on a VALU diet.  The per-128-query loop issued
-// 15 VALU instructions per MFMA (profiles/r03_pmc_sq.txt) - 32 v_max, 32 v_fma (scale, subtract the max), 32 v_exp, 32 v_add, 16
-// v_cvt_pk and a 32-multiply rescale of O^T on almost every early tile - against 512 MFMA cycles per tile.  Now
-//   * Q is multiplied by scale * log2(e) ONCE (fp32, rounded back to bf16: the reference itself rounds q * ch^-1/4 in its 16-bit
-//     mode, unet:231-236), so S^T comes out of the matrix pipe in the log2 domain;
-//   * the accumulator operand of the first S^T MFMA of a sub-tile is a register block holding -m (the running reference of this lane's
-//     query) instead of zero: the MFMA delivers S - m, the subtraction costs nothing;
-//   * m only moves when some row's tile maximum exceeds it by more than 8 (thresholded defer-max: P <= 2^8, exact in the fp32 sums and
-//     harmless to the bf16 P operand, whose precision is relative); the rescale of O^T / l and the 32 subtractions of the new offset
-//     live in that rare wave-uniform branch.  The first tile always takes it (m starts at 0, not at -inf: -m must be a finite C operand);
-//   * the row maximum folds in triples (v_max3_f32).
-// Per tile and wave that leaves 16 v_max3 + 32 v_exp + 32 v_add + 16 v_cvt_pk (+ ~10): ~7 VALU instructions per MFMA.
-// The non-FAST instance keeps the exact-scale arithmetic of attn_mfma_kernel (bitwise the same output) for the training forward,
-// whose log-sum-exp feeds a backward that recomputes P from the unscaled q.
-template <int D, bool FAST>
+// Round 4 measured a VALU diet of this loop (q pre-multiplied by scale * log2 e, -m as the C operand of the first S^T MFMA, thresholded
+// defer-max, v_max3 folds: 15 -> ~7 VALU instructions per MFMA): 105.1 vs 104.3 us on the spatial ds2 shape, 51.3 vs 48.7 and 49.7 vs
+// 51.3 us on the two RS cross-attention shapes (profiles/r04_attn_fast_softmax_ab.txt) - nothing: the loop is bound by the dependent
+// chain S^T MFMAs -> row max -> exp -> P V MFMAs of the three waves a SIMD holds, not by what it issues.  Not adopted (it re-rounds q).
+template <int D>
 __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
   static_assert(D == 64, "DMA-staged attention: head width 64 (one 128-byte LDS row per key)");
   constexpr int KST = D / 16, DT = D / 32, TILE_B = 64 * 128;
@@ -338,13 +328,6 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
     for (int s = 0; s < KST; ++s) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (qok) v = *(const u32x4*)(qp + (s * 16 + half * 8) * 2);
-      if (FAST) {
-        float f[8];
-        Elt<__bf16>::unpack(v, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] *= sc;
-        v = Elt<__bf16>::pack(f);
-      }
       qf[s] = v;
     }
   }
@@ -353,10 +336,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-  float m_run = FAST ? 0.f : -1e30f, l_run = 0.f;
-  f32x16 negm;                         // FAST: sixteen copies of -m_run, the C operand of the first S^T MFMA of every sub-tile
-#pragma unroll
-  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
 
   // ---- DMA: wave w stages row groups {w, w + 4} of K and of V; lane L of a group covers row 8 g + L / 8, physical chunk L % 8
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -396,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
 
   const int ntiles = (gi.k_count + 63) >> 6;
   issue(0, 0);
-  // S^T = K Q^T of the tile in `stage`: two 32-key sub-tiles; the first k-step accumulates onto -m (FAST) or zero
+  // S^T = K Q^T of the tile in `stage`: two 32-key sub-tiles, the first k-step on a zero accumulator
   auto compute_s = [&](int stage, f32x16 (&s)[2]) {
     const char* kb = kbase + stage * TILE_B;
     u32x4 kf[KST][2];
@@ -407,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0][kt]), __builtin_bit_cast(bf16x8, qf[0]), FAST ? negm : z, 0, 0, 0);
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0][kt]), __builtin_bit_cast(bf16x8, qf[0]), z, 0, 0, 0);
     }
 #pragma unroll
     for (int st = 1; st < KST; ++st)
@@ -453,47 +433,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
         }
     }
     float ps = 0.f;
-    if constexpr (FAST) {
-      // s = S - m_run (log2 domain).  Row maximum: eleven 3-input folds per sub-tile pair instead of 31 v_max
-      float g[10];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) g[i] = fmaxf(fmaxf(s[i / 5][3 * (i % 5)], s[i / 5][3 * (i % 5) + 1]), s[i / 5][3 * (i % 5) + 2]);
-      float mx = fmaxf(fmaxf(g[0], g[1]), g[2]);
-      mx = fmaxf(fmaxf(mx, g[3]), g[4]);
-      mx = fmaxf(fmaxf(mx, g[5]), g[6]);
-      mx = fmaxf(fmaxf(mx, g[7]), g[8]);
-      mx = fmaxf(fmaxf(mx, g[9]), fmaxf(s[0][15], s[1][15]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      if (t == 0 || __any(mx > 8.f)) {                     // wave-uniform, rare after the first tile: move the reference
-        const float d = t == 0 ? mx : fmaxf(mx, 0.f);
-        if (t != 0) {
-          const float alpha = __builtin_amdgcn_exp2f(-d);
-          l_run *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
-        m_run += d;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[kt][r] -= d;
-      }
-      asm volatile("" : "+v"(negm));                       // sixteen live registers, not a splat re-materialised per MFMA
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kt][r]);
-          s[kt][r] = e;
-          ps += e;
-        }
-      ps += __shfl_xor(ps, 32, 64);
-      l_run += ps;
-    } else {
+    {
       float mx = -3e38f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -1203,8 +1143,7 @@ template <int D>
 static int launch_dma(const AttnParams& p, int qmax, hipStream_t st) {
   const size_t lds = 4 * 64 * 128;
   dim3 grid(cdiv(qmax, 128), p.heads, p.nb * p.G);
-  if (p.lse2) hipLaunchKernelGGL((attn_dma_kernel<D, false>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((attn_dma_kernel<D, true>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(attn_dma_kernel<D>, grid, dim3(256), lds, st, p);
   return mmd_check_launch("attn_dma");
 }
 

@@ -1136,12 +1136,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
   __syncthreads();
 
   auto dma_dummy = [&]() { __builtin_amdgcn_global_load_lds((gptr_t)g_zero_page, (lptr_t)sDummy, 4, 0, 0); };
-  auto issue_w = [&](int slot, int c2, int t2) {               // weights of (chunk c2, tap t2): two DMA instructions
+  auto issue_w1 = [&](int slot, int c2, int t2, int i) {       // weights of (chunk c2, tap t2): piece i of two per wave
     const int soff = (t2 * p.Cin + c2 * 64) * ES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * W_B + (wave + 8 * i) * 1024), 16, w_off[i], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sW + slot * W_B + (wave + 8 * i) * 1024), 16, w_off[i], soff, 0, 0);
   };
+  auto issue_w = [&](int slot, int c2, int t2) { issue_w1(slot, c2, t2, 0); issue_w1(slot, c2, t2, 1); };
   auto issue_h = [&](int buf, int c, int j) {                  // exactly one DMA instruction (j is a literal at every call site)
     if (wave + 8 * j < HG)                                     // wave-uniform
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(sA + buf * A_B + (wave + 8 * j) * 1024), 16, h_off[j], c * 128, 0, 0);
@@ -1169,7 +1168,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
     rb[b] = ((px >> 4) + 1) * HWD + (px & 15) + 1;
   }
   const char* bWl = sW + (wc * 64 + l31) * 128;                // + slot * W_B
-  auto compute = [&](int wslot, int bufa, int toff) {          // toff: the tap's halo-row shift (a literal)
+  auto compute = [&](int wslot, int bufa, int toff, auto&& dma) {   // toff: the tap's halo-row shift (a literal); dma(i): the step's i-th DMA instruction
     const char* bW = bWl + wslot * W_B;
     const char* bA[2];
     int key[2];
@@ -1192,13 +1191,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 #pragma unroll
         for (int b = 0; b < 2; ++b) Mma<T>::run(fw[c][a], fa[c][b], acc[a][b]);
     };
+    // (round 4) the step's three DMA instructions go out BEHIND MFMA groups, not in front of the first fragment read: ~100 issue
+    // cycles apiece that every wave used to spend between the barrier and its first MFMA
     rd(0); rd(1);
     FRAG_FENCE();
-    rd(2); mm(0);
+    rd(2); mm(0); dma(0);
     FRAG_FENCE();
-    rd(3); mm(1);
+    rd(3); mm(1); dma(1);
     FRAG_FENCE();
-    mm(2); mm(3);
+    mm(2); dma(2); mm(3);
     FRAG_FENCE();
   };
   auto transform = [&](int buf, int c, int i) {                // halo slot i of stage buf (chunk c): act(x a + b) in place
@@ -1255,19 +1256,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
       asm volatile("" ::: "memory");
       const int wslot = (c * NT + t) % NWS;
       // the DMA group of this step: weights of the step after next into the slot the previous step left + one instruction for a later chunk
-      auto group = [&]() {
+      auto group = [&](int i) {
         const int t2 = (t + 2) % NT, c2 = c + (t + 2) / NT;
-        if (c2 < nchunk) issue_w((wslot + 2) % NWS, c2, t2);
-        else { dma_dummy(); dma_dummy(); }
-        if (t < HJ) { if (more) issue_h((c + 1) & 1, c + 1, t); else dma_dummy(); }
+        if (i < 2) {
+          if (c2 < nchunk) issue_w1((wslot + 2) % NWS, c2, t2, i);
+          else dma_dummy();
+        } else if (t < HJ) { if (more) issue_h((c + 1) & 1, c + 1, t); else dma_dummy(); }
         else if (t == NT - 1 && c + 2 < nchunk) issue_gn(c + 2); // (its ring slot was last read in steps 2 .. 7 of chunk c - 1)
         else dma_dummy();
       };
       constexpr int TOFF[9] = {-19, -18, -17, -1, 0, 1, 17, 18, 19};   // (dh, dw) in row-major 3 x 3 order -> halo-row shift dh * 18 + dw
       int toff = TOFF[t];
       asm volatile("" : "+s"(toff));       // keep the 72 per-tap fragment addresses out of the registers: recomputed per step (~20 VALU)
-      group();
-      compute(wslot, c & 1, toff);
+      compute(wslot, c & 1, toff, group);
       if (GN && more && t >= 2 && t < 2 + NSLOT) transform((c + 1) & 1, c + 1, t - 2);   // piece t - 2 landed with this step's wait
     }
   }

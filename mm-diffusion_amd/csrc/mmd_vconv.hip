@@ -69,60 +69,69 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   const int wc = wave & 1, wr = wave >> 1;
   const int half = lane >> 5, l31 = lane & 31;
 
-  // XCD-aware order: consecutive patches (sharing halos) stay on one L2
-  const int nwg = gridDim.x;
-  int wgid;
-  {
-    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
+  // Persistent blocks (one per CU, grid = min(patches, CUs)): block b walks the patches L = b, b + grid, ... in the XCD-aware order
+  // (consecutive patches - sharing halos - stay on one L2; L and b share their XCD while grid % 8 == 0).  While a patch's last two
+  // temporal steps run the next patch's first two weight slabs are already on their way, and its first halo stage is requested
+  // before the epilogue stores of this one: the ~2 us of launch + first-operand latency per patch hide behind work.
   const int PWc = p.W >> 2, ppf = PWc * (p.H >> 2);
-  const int n = wgid / ppf, patch = wgid - n * ppf;
-  const int h0 = (patch / PWc) * 4, w0 = (patch % PWc) * 4;
   const int HW = p.H * p.W;
   const int nchunk = p.Cin >> 5;
-
-  // ---- DMA descriptors (wave-uniform) and lane-constant offsets
+  const int total = p.N * ppf;
   const uint32_t OOB = 0xfffffff0u;
-  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (int64_t)n * 16 * HW * p.ldx * 2), 0,
-                                                       (int)(((int64_t)16 * HW - 1) * p.ldx * 2 + (int64_t)p.Cin * 2), 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wf, 0, p.wf_bytes, 0x00020000);
-  // halo pieces of this wave: j = 0..2 rows hh 0..3 (pieces w, w + 8, w + 16), j = 3: piece 24 + w, j = 4: piece 32 + w (waves 0-3)
+  const int x_bytes = (int)(((int64_t)16 * HW - 1) * p.ldx * 2 + (int64_t)p.Cin * 2);
+  // ---- per-patch state (setup): sample / patch origin, the activation descriptor of the sample, lane-constant halo offsets
+  // (pieces of this wave: j = 0..2 rows hh 0..3 = pieces w, w + 8, w + 16; j = 3: piece 24 + w; j = 4: piece 32 + w, waves 0-3),
+  // the in-place norm slots (slot i of this thread = 16 bytes at tid * 16 + i * 8192 of a stage; i = 4: waves 0-3 only)
+  int n = 0, patch = 0, h0 = 0, w0 = 0;
+  auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, x_bytes, 0x00020000);
   uint32_t h_off[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int g = j < 3 ? wave + 8 * j : (j == 3 ? 24 + wave : 32 + wave);
-    const int row = 16 * g + (lane >> 2), pc = lane & 3;
-    const int hh = row / 96, rem = row - hh * 96, f = rem / 6, ww = rem - f * 6;
-    const int y = h0 - 1 + hh, x = w0 - 1 + ww;
-    const bool ok = g < 36 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    const int logical = pc ^ (hh & 3);
-    h_off[j] = ok ? (uint32_t)((((int64_t)f * p.H + y) * p.W + x) * p.ldx * 2 + logical * 16) : OOB;
-  }
-  // ---- in-place GroupNorm slots: slot i of this thread = 16 bytes at tid * 16 + i * 8192 of a stage (i = 4: waves 0-3 only)
   unsigned gvalid = 0, glc = 0;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int s = tid + 512 * i, row = s >> 2, pc = s & 3;
-    const int hh = row / 96, rem = row - hh * 96, f = rem / 6, ww = rem - f * 6;
-    (void)f;
-    const bool ok = (unsigned)(h0 - 1 + hh) < (unsigned)p.H && (unsigned)(w0 - 1 + ww) < (unsigned)p.W;
-    gvalid |= (ok ? 1u : 0u) << i;
-    glc |= (unsigned)(pc ^ (hh & 3)) << (2 * i);
-  }
-  // padding slots of both stages are zeroed ONCE (an out-of-range DMA lane may or may not write its zero, the transform leaves them alone)
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-    if ((i < 4 || wave < 4) && !((gvalid >> i) & 1u)) {
-      *(u32x4*)(sA + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
-      *(u32x4*)(sA + VC_STAGE_B + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
-    }
-  if (tid < 256) sBias[tid] = tid < 128 ? (p.bias_s ? p.bias_s[tid] : 0.f) : (p.bias_t ? p.bias_t[tid - 128] : 0.f);
   const float* gn_src = nullptr;
-  if (GN) {
-    const int sidx = min((int)(((int64_t)n * 16 * HW) / p.gn_rows), p.gn_S - 1);
-    gn_src = (lane < 32 ? p.gn_a : p.gn_b) + (int64_t)sidx * p.Cin + (lane & 31);
-  }
+  auto setup = [&](int L) {
+    const int q = total >> 3, r = total & 7, xcd = L & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    n = wgid / ppf;
+    patch = wgid - n * ppf;
+    h0 = (patch / PWc) * 4;
+    w0 = (patch % PWc) * 4;
+    rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (int64_t)n * 16 * HW * p.ldx * 2), 0, x_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int g = j < 3 ? wave + 8 * j : (j == 3 ? 24 + wave : 32 + wave);
+      const int row = 16 * g + (lane >> 2), pc = lane & 3;
+      const int hh = row / 96, rem = row - hh * 96, f = rem / 6, ww = rem - f * 6;
+      const int y = h0 - 1 + hh, x = w0 - 1 + ww;
+      const bool ok = g < 36 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const int logical = pc ^ (hh & 3);
+      h_off[j] = ok ? (uint32_t)((((int64_t)f * p.H + y) * p.W + x) * p.ldx * 2 + logical * 16) : OOB;
+    }
+    gvalid = 0;
+    glc = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int s = tid + 512 * i, row = s >> 2, pc = s & 3;
+      const int hh = row / 96, rem = row - hh * 96, ww = rem % 6;
+      const bool ok = (unsigned)(h0 - 1 + hh) < (unsigned)p.H && (unsigned)(w0 - 1 + ww) < (unsigned)p.W;
+      gvalid |= (ok ? 1u : 0u) << i;
+      glc |= (unsigned)(pc ^ (hh & 3)) << (2 * i);
+    }
+    if (GN) {
+      const int sidx = min((int)(((int64_t)n * 16 * HW) / p.gn_rows), p.gn_S - 1);
+      gn_src = (lane < 32 ? p.gn_a : p.gn_b) + (int64_t)sidx * p.Cin + (lane & 31);
+    }
+  };
+  // padding slots of both stages are zeroed once per patch (an out-of-range DMA lane may or may not write its zero, the norm leaves
+  // them alone, and the temporal operand image of the previous patch lay over both stages)
+  auto zero_padding = [&]() {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if ((i < 4 || wave < 4) && !((gvalid >> i) & 1u)) {
+        *(u32x4*)(sA + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
+        *(u32x4*)(sA + VC_STAGE_B + tid * 16 + i * 8192) = u32x4{0u, 0u, 0u, 0u};
+      }
+  };
+  if (tid < 256) sBias[tid] = tid < 128 ? (p.bias_s ? p.bias_s[tid] : 0.f) : (p.bias_t ? p.bias_t[tid - 128] : 0.f);
 
   auto dma_dummy = [&]() { __builtin_amdgcn_global_load_lds((gptr_t)g_vc_zero, (lptr_t)sDummy, 4, 0, 0); };
   auto issue_h = [&](int stage, int c, int j) {            // one DMA instruction (j is a literal at every call site)
@@ -282,26 +291,40 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: halo of chunk 0, the affine rows of chunks 0 / 1, the weights of steps 0 / 1; chunk 0 is normalised before the first MFMA
+  // ---- the first halo stage, the affine rows of chunks 0 / 1 and the weights of steps 0 / 1 of a patch
+  auto issue_first_halo = [&]() {
 #pragma unroll
-  for (int j = 0; j < 5; ++j) issue_h(0, 0, j);
-  if (GN) {
-    issue_gn(0);
-    if (nchunk > 1) issue_gn(1);
-  }
+    for (int j = 0; j < 5; ++j) issue_h(0, 0, j);
+    if (GN) {
+      issue_gn(0);
+      if (nchunk > 1) issue_gn(1);
+    }
+  };
+  int L = blockIdx.x;
+  setup(L);
+  zero_padding();
+  issue_first_halo();
 #pragma unroll
   for (int i = 0; i < 3; ++i) issue_ws(0, 0, i);
 #pragma unroll
   for (int i = 0; i < 3; ++i) issue_ws(1, 1, i);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  for (;;) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the first operands of this patch (and the previous patch's stores)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (GN) {
+  if (GN) {                                                // chunk 0 is normalised before the first MFMA
 #pragma unroll
     for (int i = 0; i < 5; ++i)
       if (i < 4 || wave < 4) { tr_first(0, 0, i); tr_second(0, i); }
     // (the first step's barrier orders these LDS writes before the first fragment reads)
   }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   for (int c = 0; c + 1 < nchunk; ++c) {
     spatial(std::integral_constant<int, 0>{}, std::true_type{}, c);
@@ -352,11 +375,12 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   // ---- phase 2: temporal k = 3 over T.  Step s2 = tap * 2 + plane in ring slot s2 % 3 (3 nchunk spatial steps: the ring continues)
+  const bool has_next = L + (int)gridDim.x < total;        // block-uniform
   auto temporal = [&](auto stag) {
     constexpr int S2 = decltype(stag)::value;
-    // the newest group in flight: the weights of step S2 + 1 (two pieces; none behind step 4)
+    // the newest group in flight: the weights of step S2 + 1 (two pieces) - behind step 4 the first slab of the NEXT patch (three)
     if constexpr (S2 < 5) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     constexpr int tap = S2 >> 1, plane = S2 & 1;
@@ -377,7 +401,11 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[k][a]), __builtin_bit_cast(bf16x8, fa[k][b]), acc[a][b], 0, 0, 0);
     };
     auto dma = [&](int k) {
-      if constexpr (S2 + 2 < 6) issue_wt((S2 + 2) % 3, S2 + 2, k);
+      if constexpr (S2 + 2 < 6) {
+        if (k < 2) issue_wt((S2 + 2) % 3, S2 + 2, k);
+      } else {                                              // steps 4 / 5: spatial slabs 0 / 1 of the next patch into slots 0 / 1 (three pieces)
+        if (has_next) issue_ws(S2 - 4, S2 - 4, k); else dma_dummy();
+      }
     };
     rd(0); rd(1);
     __builtin_amdgcn_sched_barrier(0);
@@ -385,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     __builtin_amdgcn_sched_barrier(0);
     rd(3); mm(1); dma(1);
     __builtin_amdgcn_sched_barrier(0);
-    mm(2); mm(3);
+    mm(2); dma(2); mm(3);
     __builtin_amdgcn_sched_barrier(0);
   };
   temporal(std::integral_constant<int, 0>{});
@@ -395,9 +423,17 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   temporal(std::integral_constant<int, 4>{});
   temporal(std::integral_constant<int, 5>{});
 
-  // ---- epilogue from the accumulators: + bias_t -> bf16 -> 16-byte row stores; quad statistics of the values as stored
+  // ---- epilogue from the accumulators: + bias_t -> bf16 -> 16-byte row stores; quad statistics of the values as stored.  The next
+  // patch's first halo stage is requested first (the temporal operand image is dead once every wave is past its last fragment read)
   const int64_t mbase = (int64_t)n * 16 * HW + (int64_t)(h0 + ph) * p.W + w0 + pw;
   const int64_t rec = ((int64_t)n * (HW >> 4) + patch) * 4 + wr;
+  if (has_next) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    setup(L + (int)gridDim.x);
+    zero_padding();
+    issue_first_halo();
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -440,6 +476,10 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
         }
       }
     }
+  if (!has_next) break;
+  L += (int)gridDim.x;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // trailing dummies
 }
 
 // ---- weight image.  Spatial slab s1 = chunk * 3 + dhi: [dwi][co][64 B], 16-byte chunk lc of row co stored at chunk lc ^ ((co >> 2) & 3);
@@ -508,7 +548,10 @@ extern "C" int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, cons
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "vconv2d1d: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  const int grid = N * (H / 4) * (W / 4);
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, mmd_device_slot()) != hipSuccess || ncu <= 0) ncu = 256;
+  const int total = N * (H / 4) * (W / 4);
+  const int grid = total < ncu ? total : ncu;               // persistent blocks, one per CU
   if (!gn_a) hipLaunchKernelGGL(vconv2d1d_kernel<0>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
   else if (act) hipLaunchKernelGGL(vconv2d1d_kernel<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(vconv2d1d_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);

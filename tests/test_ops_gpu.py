@@ -383,9 +383,7 @@ def test_self_attention_staged_window(ops, T, heads):
 @pytest.mark.parametrize("spike_key,scale", [(250, 40.0), (70, 40.0), (3, 40.0), (250, -40.0)])
 def test_attention_softmax_spike(ops, spike_key, scale):
     """Online-softmax rescale path: one key dominates (a big jump of the running reference) in the first tile, in the second and late in
-    the sequence - the branch the thresholded defer-max of the DMA-staged kernel (impl 4) only takes when a tile maximum exceeds the
-    reference by 2^8 - and one key far BELOW everything (all scores of a row negative: the reference must still start at the first
-    tile's maximum, not at zero)."""
+    the sequence, and one key far BELOW everything."""
     T, heads, ch = 300, 1, 64
     qkv = rnd(T, 3 * 64, dt=torch.bfloat16, seed=28) * 0.3
     qkv[spike_key, 64:128] = qkv[7, :64] * scale           # key aligned (or anti-aligned) with query 7
@@ -400,8 +398,8 @@ def test_attention_softmax_spike(ops, spike_key, scale):
 
 
 def test_attention_all_scores_far_below_zero(ops):
-    """Every score of every row around -60 (log2 domain): a softmax reference that started at 0 would underflow every P to 0 and
-    divide by zero.  impl 4's first tile always moves the reference to the tile maximum."""
+    """Every score of every row around -60 (log2 domain): a softmax whose running reference started at 0 instead of the first tile's
+    maximum would underflow every P to 0 and divide by zero."""
     T, heads, ch = 200, 1, 64
     q = torch.full((T, 64), 1.0) + rnd(T, 64, seed=5) * 0.05
     k = -q * 5.0 + rnd(T, 64, seed=6) * 0.05

@@ -307,13 +307,12 @@ def test_gn_small_is_stats_plus_apply(ops, dt, act, N, F, HW, C):
     ("spatial 1024", 2, 4, 4 * 1024, 1024, 4 * 1024, 1024, 1, 4), ("v<-a", 2, 16, 16 * 256, 256, 1600, 100, 1, 4),
     ("a<-v window 4", 1, 16, 1600, 100, 16 * 256, 256, 4, 6), ("ragged keys / queries", 2, 8, 8 * 77, 77, 8 * 50, 50, 3, 2),
     ("last group takes the remainder", 1, 16, 1610, 100, 16 * 64, 64, 8, 2), ("one short tile", 1, 16, 16 * 64, 64, 16 * 25, 25, 1, 8)])
-def test_attn_dma_kernel_against_the_mfma_kernel(ops, name, N, F, qr, qg, kr, kg, win, heads):
-    """The DMA-staged kernel (K / V tiles by buffer_load ... lds, V^T fragments by transposing LDS reads, one barrier per tile) against
-    the register-staged per-128-query kernel (impl 2, which test_ops_gpu.py pins against the oracle's attention): circular windows with
-    a shift, key counts that are not multiples of 64 (zero-filled DMA rows + masking), ragged query tiles, the last group's remainder.
-    Its exact-scale instance (the training forward: mmd_attn_fwd_lse) does the same arithmetic in the same order -> bitwise equal;
-    the inference instance (round 4: q pre-multiplied by scale * log2 e and re-rounded, -m as the MFMA's C operand, thresholded
-    defer-max) agrees to the rounding of q: 4e-3."""
+def test_attn_dma_kernel_is_bitwise_the_mfma_kernel(ops, name, N, F, qr, qg, kr, kg, win, heads):
+    """mmd_attn_fwd impl 4 (K / V tiles by buffer_load ... lds, V^T fragments by transposing LDS reads, one barrier per tile) against
+    impl 2 (register-staged, transposing 2-byte LDS writes): same arithmetic in the same order -> bitwise equal; circular windows with
+    a shift, key counts that are not multiples of 64 (zero-filled DMA rows + masking), ragged query tiles, the last group's
+    remainder.  (impl 2 is the kernel test_ops_gpu.py pins against the oracle's attention.)  The training forward (mmd_attn_fwd_lse)
+    runs the same kernel: same output."""
     ch = 64
     C = heads * ch
     g = torch.Generator(device="cuda").manual_seed(qr + kr)
@@ -329,9 +328,8 @@ def test_attn_dma_kernel_against_the_mfma_kernel(ops, name, N, F, qr, qg, kr, kg
         ops.attn(q, kv, o4, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=4)
         ops.attn_lse(q, kv, ol, lse, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh)
         torch.cuda.synchronize()
-        assert torch.equal(o2, ol), f"{name} shift {shift}: rel-L2 {rel_l2(ol.float().cpu(), o2.float().cpu().numpy()):.3e}"
-        assert torch.isfinite(o4.float()).all()
-        assert rel_l2(o4.float().cpu(), o2.float().cpu().numpy()) < 4e-3, f"{name} shift {shift}"
+        assert torch.equal(o2, o4), f"{name} shift {shift}: rel-L2 {rel_l2(o4.float().cpu(), o2.float().cpu().numpy()):.3e}"
+        assert torch.equal(o2, ol), f"{name} shift {shift} (lse forward)"
 
 
 def test_graph_replays_are_bitwise_repeatable_under_two_stream_concurrency():

@@ -53,7 +53,7 @@ def torch_ref(x, ws, wt, bs, bt, a, b, N, H, W, act, round_mid):
 
 
 @pytest.mark.parametrize("gn", [None, "silu", "affine"])
-@pytest.mark.parametrize("N,H,W,Cin,pad", [(1, 8, 8, 32, 0), (2, 8, 12, 64, 0), (1, 16, 16, 128, 0), (1, 12, 8, 256, 64), (1, 64, 64, 128, 0)])
+@pytest.mark.parametrize("N,H,W,Cin,pad", [(1, 8, 8, 32, 0), (2, 8, 12, 64, 0), (1, 16, 16, 128, 0), (1, 12, 8, 256, 64), (1, 64, 64, 128, 0), (2, 64, 72, 64, 0)])
 def test_vconv_vs_torch(ops, gn, N, H, W, Cin, pad):
     x, ws, wt, bs, bt, a, b = make(N, H, W, Cin, seed=H * W + Cin, ldx_pad=pad)
     wf = ops.vconv_pack(ops.pack_conv_weight(ws.float(), torch.bfloat16), ops.pack_conv_weight(wt.float(), torch.bfloat16))
