@@ -115,10 +115,12 @@ def build_id():
 
 
 def cpu_baseline(fl, seconds_budget=30.0):
-    """The oracle (oracle/*.py, CPU restatement of the reference path, kind "port") on the host cores: one timed p_sample step at batch 1
-    on 16 and on 32 threads after one warm-up step (`threads_tried`: seconds per step; torch's CPU kernels oversubscribe badly on this
-    model - 256 threads took 688 s per step, 64 threads 6.1 s, 16 threads ~2.5 s on the GPU box), then one timed step at batch 4 on
-    the faster setting (SURVEY 8d asks for N = 1 and N = 4).  ~15-25 s of CPU work."""
+    """The oracle (oracle/*.py, CPU restatement of the reference path, kind "port") on the host cores, BASELINE.md section 3's protocol:
+    fp32, x_T from CPU seed 0, `timestep_respacing="2"`, ONE warm-up p_sample step, then the TWO timed steps of the 2-step loop
+    (timesteps [999, 0]) at batch 1; then, while the ~30 s budget lasts, one timed step at batch 4 (SURVEY 8d asks for N = 1 and N = 4;
+    two would take 30 s on their own).  Threads: BASELINE.md says os.cpu_count(), which on the GPU box is 256 - torch's CPU kernels
+    oversubscribe badly on this model (256 threads: 688 s per step; 64: 6.1 s; 16: ~2.5 s), so the warm-up step is run on 16 and on
+    32 threads and the faster setting does the timed steps (`threads_tried`, `cores` = the threads actually used)."""
     from oracle import diffusion_ref as dref, unet_ref as uref
     from mm_diffusion.synth import synth_tensor
     from mm_diffusion import multimodal_script_util as msu
@@ -134,18 +136,21 @@ def cpu_baseline(fl, seconds_budget=30.0):
     t_all = time.perf_counter()
     x1 = {"video": torch.randn(1, *fl["video_size"]), "audio": torch.randn(1, *fl["audio_size"])}
     tried = {}
-    for th_ in (16, 32):                                        # the full oracle step is the probe: a layer micro-probe picked 64 threads,
-        if th_ > ncpu and tried:                                # on which the whole step ran 2.4x SLOWER than on 16 (6.1 s vs 2.5 s)
+    for th_ in (16, 32):                                        # warm-up steps double as the thread probe (the first also warms the allocator,
+        if th_ > ncpu and tried:                                # the thread pool and the oneDNN primitive caches: it is the slower of its kind)
             continue
         torch.set_num_threads(min(th_, ncpu))
         if not tried:
-            x1 = dref.p_sample(S, om, x1, torch.tensor([1]))    # ONE warm-up step (allocator, thread pool, oneDNN primitive caches)
+            dref.p_sample(S, om, x1, torch.tensor([1]))         # the untimed warm-up step
         t0 = time.perf_counter()
-        x1 = dref.p_sample(S, om, x1, torch.tensor([0]))
+        dref.p_sample(S, om, x1, torch.tensor([1]))
         tried[min(th_, ncpu)] = round(time.perf_counter() - t0, 3)
     cores = min(tried, key=tried.get)
     torch.set_num_threads(cores)
-    out = {1: tried[cores]}
+    t0 = time.perf_counter()                                    # the two timed steps of the 2-step loop
+    x = dref.p_sample(S, om, x1, torch.tensor([1]))
+    x = dref.p_sample(S, om, x, torch.tensor([0]))
+    out = {1: (time.perf_counter() - t0) / 2}
     if time.perf_counter() - t_all < seconds_budget:            # bounded sample: one more timed step, at batch 4
         x = {"video": torch.randn(4, *fl["video_size"]), "audio": torch.randn(4, *fl["audio_size"])}
         t0 = time.perf_counter()
@@ -154,8 +159,9 @@ def cpu_baseline(fl, seconds_budget=30.0):
     best_b = max(out, key=lambda b: b / out[b])
     return {"value": best_b / out[best_b], "unit": "pair-steps/s", "cores": cores, "kind": "port", "threads_tried": tried,
             "pair_steps_per_s_batch1": 1 / out[1], "pair_steps_per_s_batch4": (4 / out[4]) if 4 in out else None,
-            "sample": f"one timed p_sample step at batch 1 ({out[1]:.1f} s)" + (f" and one at batch 4 ({out[4]:.1f} s)" if 4 in out else "") + " after one batch-1 warm-up step" +
-                      f" of the Landscape base model, fp32, oracle/unet_ref.py on {cores} host threads (of {ncpu}); value = the better of the two"}
+            "sample": f"1 warm-up + the 2 timed p_sample steps of the 2-step loop at batch 1 ({out[1]:.1f} s per step)" +
+                      (f" and one timed step at batch 4 ({out[4]:.1f} s)" if 4 in out else "") +
+                      f" of the Landscape base model, fp32, oracle/unet_ref.py on {cores} host threads (of {ncpu}; probed 16 / 32: more threads are slower); value = the better batch"}
 
 
 def wgrad_roofline(B, device):

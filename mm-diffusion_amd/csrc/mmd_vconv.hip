@@ -63,11 +63,12 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   float* sBias = sGN + 128;                          // [bias_s (128) | bias_t (128)]
   char* sDummy = (char*)(sBias + 256);               // 256 B: target of the DMA instructions that only keep the per-step count static
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wr = wave >> 1;
-  const int half = lane >> 5, l31 = lane & 31;
+  // (not const: the persistent loop re-derives every lane constant per patch from laundered copies, see its top)
+  int tid = threadIdx.x;
+  int lane = tid & 63;
+  int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wc = wave & 1, wr = wave >> 1;
+  int half = lane >> 5, l31 = lane & 31;
 
   // Persistent blocks (one per CU, grid = min(patches, CUs)): block b walks the patches L = b, b + grid, ... in the XCD-aware order
   // (consecutive patches - sharing halos - stay on one L2; L and b share their XCD while grid % 8 == 0).  While a patch's last two
@@ -155,15 +156,22 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   };
 
   // ---- fragment addressing
-  const int ph = (l31 >> 2) & 3, pw = l31 & 3;
+  int ph, pw;
   int rbB[2];                                              // byte offset of halo row (ph + 1, f_b, pw + 1): tap (0, 0) of this lane's row
+  int kw1, wl1;                                            // weight rows of 64 B: chunk key (co >> 2) & 3, lane offset
+  int kw2, wl2, tl2;                                       // rows of 128 B (temporal weights, T): chunk key (row >> 1) & 7, lane offsets
+  auto lane_constants = [&]() {
+    ph = (l31 >> 2) & 3;
+    pw = l31 & 3;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) rbB[b] = (((ph + 1) * 96 + (wr * 4 + b * 2 + (l31 >> 4)) * 6 + pw + 1)) * 64;
-  const int kw1 = (l31 >> 2) & 3;                          // weight rows of 64 B: chunk key (co >> 2) & 3
-  const int wl1 = (wc * 64 + l31) * 64;
-  const int kw2 = (l31 >> 1) & 7;                          // rows of 128 B (temporal weights, T): chunk key (row >> 1) & 7
-  const int wl2 = (wc * 64 + l31) * 128;
-  const int tl2 = (wr * 64 + l31 + 16) * 128;
+    for (int b = 0; b < 2; ++b) rbB[b] = (((ph + 1) * 96 + (wr * 4 + b * 2 + (l31 >> 4)) * 6 + pw + 1)) * 64;
+    kw1 = (l31 >> 2) & 3;
+    wl1 = (wc * 64 + l31) * 64;
+    kw2 = (l31 >> 1) & 7;
+    wl2 = (wc * 64 + l31) * 128;
+    tl2 = (wr * 64 + l31 + 16) * 128;
+  };
+  lane_constants();
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -310,6 +318,13 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   for (int i = 0; i < 3; ++i) issue_ws(1, 1, i);
 
   for (;;) {
+  // Every lane / wave constant goes through an opaque copy once per patch: what is derived from them (fragment, slot and store
+  // addresses) is then recomputed per patch instead of being hoisted out of this loop as ~60 loop-invariant registers - the
+  // persistent form of the kernel otherwise needs all 256 VGPRs and spills (the one-patch form: 191).
+  asm volatile("" : "+v"(tid), "+v"(lane), "+v"(half), "+v"(l31), "+s"(wave));
+  wc = wave & 1;
+  wr = wave >> 1;
+  lane_constants();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the first operands of this patch (and the previous patch's stores)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");

@@ -29,52 +29,107 @@ from . import _hip as H
 from . import ops
 
 
+class _Knots:
+    """y(x), piecewise linear through ascending knots, the end segments extended outside (what the reference's interpolate_fn
+    computes, dpm:1306-1347, for one curve): fp32, same expression order - the solver's integer model timesteps are floor((t - 1/N) N),
+    so t must come out to the last bit."""
+
+    def __init__(self, x, y):
+        self.x, self.y = x.reshape(-1).cpu().contiguous(), y.reshape(-1).cpu().contiguous()     # dtypes kept: a float64 beta table gives float64 curves
+
+    def __call__(self, q):
+        q = q.reshape(-1).contiguous()
+        x, y = self.x.to(q.device), self.y.to(q.device)
+        ct = torch.promote_types(x.dtype, q.dtype)
+        hi = torch.searchsorted(x.to(ct), q.to(ct), right=False).clamp(1, x.numel() - 1)         # first knot >= q, kept inside the table
+        lo = hi - 1
+        return y[lo] + (q - x[lo]) * (y[hi] - y[lo]) / (x[hi] - x[lo])
+
+    def swapped(self):
+        """x(y) of a DEcreasing curve: the knots reversed so that the abscissa ascends again."""
+        return _Knots(self.y.flip(0), self.x.flip(0))
+
+
 def interpolate_fn(x, xp, yp):
-    """Piecewise-linear y(x) through the keypoints (xp, yp) with linear extrapolation outside (dpm:1306-1347).
-    x [N, C], xp / yp [C, K] -> [N, C]."""
-    N, K = x.shape[0], xp.shape[1]
-    xpe = xp.unsqueeze(0).expand(N, -1, -1).contiguous()
-    idx = torch.searchsorted(xpe, x.unsqueeze(2).contiguous(), right=False).squeeze(2)     # keypoints strictly below x
-    start = (idx - 1).clamp(0, K - 2)
-    ype = yp.unsqueeze(0).expand(N, -1, -1)
-    g = lambda t, i: torch.gather(t, 2, i.unsqueeze(2)).squeeze(2)                        # noqa: E731
-    x0, x1, y0, y1 = g(xpe, start), g(xpe, start + 1), g(ype, start), g(ype, start + 1)
-    return y0 + (x - x0) * (y1 - y0) / (x1 - x0)
+    """The reference's module-level helper (dpm:1306-1347), kept for its import surface: x [N, C], keypoints xp / yp [C, K] ->
+    [N, C], one knot table per channel."""
+    return torch.stack([_Knots(xp[c], yp[c])(x[:, c]) for c in range(xp.shape[0])], dim=1)
+
+
+def _log_alpha_of_lambda(lamb):
+    """log alpha = -1/2 log(1 + exp(-2 lambda)) for a VP process (alpha^2 + sigma^2 = 1, lambda = log alpha - log sigma)."""
+    return -0.5 * torch.logaddexp(torch.zeros((1,)).to(lamb), -2. * lamb)
+
+
+class _TableSchedule:
+    """'discrete': log alpha known at t_i = (i + 1) / N from the trained betas / alphas_cumprod, linear in between."""
+
+    def __init__(self, log_alphas):
+        self.total_N, self.T = len(log_alphas), 1.
+        self.curve = _Knots(torch.linspace(0., 1., self.total_N + 1)[1:], log_alphas)
+        self.inverse = self.curve.swapped()
+
+    def log_alpha(self, t):
+        return self.curve(t)
+
+    def t_of_lambda(self, lamb):
+        return self.inverse(_log_alpha_of_lambda(lamb))
+
+
+class _LinearSchedule:
+    """'linear' VP-SDE: beta(t) = beta_0 + t (beta_1 - beta_0), log alpha(t) = -t^2 (beta_1 - beta_0) / 4 - t beta_0 / 2."""
+
+    def __init__(self, beta_0, beta_1):
+        self.total_N, self.T, self.b0, self.db = 1000, 1., beta_0, beta_1 - beta_0
+
+    def log_alpha(self, t):
+        return -0.25 * t ** 2 * self.db - 0.5 * t * self.b0
+
+    def t_of_lambda(self, lamb):          # the positive root of the quadratic in t, in the cancellation-free form
+        w = 2. * self.db * torch.logaddexp(-2. * lamb, torch.zeros((1,)).to(lamb))
+        return w / (torch.sqrt(self.b0 ** 2 + w) + self.b0) / self.db
+
+
+class _CosineSchedule:
+    """'cosine': alpha(t) = cos(pi/2 (t + s) / (1 + s)) / cos(pi/2 s / (1 + s)), s = 0.008, T = 0.9946."""
+
+    def __init__(self):
+        self.total_N, self.T, self.s = 1000, 0.9946, 0.008
+        self.log_alpha_0 = math.log(math.cos(self.s / (1. + self.s) * math.pi / 2.))
+
+    def log_alpha(self, t):
+        return torch.log(torch.cos((t + self.s) / (1. + self.s) * math.pi / 2.)) - self.log_alpha_0
+
+    def t_of_lambda(self, lamb):
+        la = -0.5 * torch.logaddexp(-2. * lamb, torch.zeros((1,)).to(lamb))
+        return torch.arccos(torch.exp(la + self.log_alpha_0)) * 2. * (1. + self.s) / math.pi - self.s
 
 
 class NoiseScheduleVP:
-    """VP-SDE noise schedule wrapper (dpm:11-181): 'discrete' (piecewise-linear log alpha over t_i = (i+1)/N),
-    'linear' and 'cosine'.  All functions take / return fp32 torch tensors of times (any device; solver scalars live on
-    the CPU)."""
+    """The VP noise schedule the solver integrates over (the reference's class of the same name, dpm:11-181): alpha(t), sigma(t),
+    lambda(t) = log alpha - log sigma and its inverse for the 'discrete' (trained betas), 'linear' and 'cosine' families.  Times are
+    fp32 torch tensors (any device; the solver's scalars live on the CPU)."""
 
     def __init__(self, schedule="discrete", betas=None, alphas_cumprod=None, continuous_beta_0=0.1, continuous_beta_1=20.):
-        if schedule not in ("discrete", "linear", "cosine"):
-            raise ValueError(f"Unsupported noise schedule {schedule}. The schedule needs to be 'discrete' or 'linear' or 'cosine'")
-        self.schedule = schedule
         if schedule == "discrete":
             if betas is not None:
                 log_alphas = 0.5 * torch.log(1 - torch.as_tensor(betas)).cumsum(dim=0)
-            else:
-                assert alphas_cumprod is not None
+            elif alphas_cumprod is not None:
                 log_alphas = 0.5 * torch.log(torch.as_tensor(alphas_cumprod))
-            self.total_N = len(log_alphas)
-            self.T = 1.
-            self.t_array = torch.linspace(0., 1., self.total_N + 1)[1:].reshape((1, -1))
-            self.log_alpha_array = log_alphas.reshape((1, -1)).cpu()
+            else:
+                raise ValueError("the 'discrete' noise schedule needs betas or alphas_cumprod")
+            self._family = _TableSchedule(log_alphas)
+        elif schedule == "linear":
+            self._family = _LinearSchedule(continuous_beta_0, continuous_beta_1)
+        elif schedule == "cosine":
+            self._family = _CosineSchedule()
         else:
-            self.total_N = 1000
-            self.beta_0, self.beta_1 = continuous_beta_0, continuous_beta_1
-            self.cosine_s, self.cosine_beta_max = 0.008, 999.
-            self.cosine_t_max = math.atan(self.cosine_beta_max * (1. + self.cosine_s) / math.pi) * 2. * (1. + self.cosine_s) / math.pi - self.cosine_s
-            self.cosine_log_alpha_0 = math.log(math.cos(self.cosine_s / (1. + self.cosine_s) * math.pi / 2.))
-            self.T = 0.9946 if schedule == "cosine" else 1.
+            raise ValueError(f"Unsupported noise schedule {schedule}. The schedule needs to be 'discrete' or 'linear' or 'cosine'")
+        self.schedule, self.total_N, self.T = schedule, self._family.total_N, self._family.T
 
     def marginal_log_mean_coeff(self, t):
-        if self.schedule == "discrete":
-            return interpolate_fn(t.reshape((-1, 1)), self.t_array.to(t.device), self.log_alpha_array.to(t.device)).reshape((-1))
-        if self.schedule == "linear":
-            return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
-        return torch.log(torch.cos((t + self.cosine_s) / (1. + self.cosine_s) * math.pi / 2.)) - self.cosine_log_alpha_0
+        shape = t.shape
+        return self._family.log_alpha(t).reshape(shape) if self.schedule != "discrete" else self._family.log_alpha(t).reshape((-1))
 
     def marginal_alpha(self, t):
         return torch.exp(self.marginal_log_mean_coeff(t))
@@ -83,22 +138,12 @@ class NoiseScheduleVP:
         return torch.sqrt(1. - torch.exp(2. * self.marginal_log_mean_coeff(t)))
 
     def marginal_lambda(self, t):
-        log_mean_coeff = self.marginal_log_mean_coeff(t)
-        log_std = 0.5 * torch.log(1. - torch.exp(2. * log_mean_coeff))
-        return log_mean_coeff - log_std
+        la = self.marginal_log_mean_coeff(t)
+        return la - 0.5 * torch.log(1. - torch.exp(2. * la))
 
     def inverse_lambda(self, lamb):
-        if self.schedule == "linear":
-            tmp = 2. * (self.beta_1 - self.beta_0) * torch.logaddexp(-2. * lamb, torch.zeros((1,)).to(lamb))
-            Delta = self.beta_0 ** 2 + tmp
-            return tmp / (torch.sqrt(Delta) + self.beta_0) / (self.beta_1 - self.beta_0)
-        if self.schedule == "discrete":
-            log_alpha = -0.5 * torch.logaddexp(torch.zeros((1,)).to(lamb.device), -2. * lamb)
-            t = interpolate_fn(log_alpha.reshape((-1, 1)), torch.flip(self.log_alpha_array.to(lamb.device), [1]),
-                               torch.flip(self.t_array.to(lamb.device), [1]))
-            return t.reshape((-1,))
-        log_alpha = -0.5 * torch.logaddexp(-2. * lamb, torch.zeros((1,)).to(lamb))
-        return torch.arccos(torch.exp(log_alpha + self.cosine_log_alpha_0)) * 2. * (1. + self.cosine_s) / math.pi - self.cosine_s
+        t = self._family.t_of_lambda(lamb)
+        return t.reshape((-1,)) if self.schedule == "discrete" else t
 
 
 def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, guidance_type="uncond", condition=None,

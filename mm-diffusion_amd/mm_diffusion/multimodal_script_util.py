@@ -115,6 +115,12 @@ def add_dict_to_argparser(parser, default_dict):
 
 
 def args_to_dict(args, keys):
+    """The scripts turn their parsed flags into factory keywords with this (right after parse_args, long before the sampling loop):
+    the one place to say EARLY that a --ref_path run will get no FVD / KVD / FAD numbers at its end (evaluator.py)."""
+    if getattr(args, "ref_path", ""):
+        import warnings
+        from .evaluator import unavailable_message
+        warnings.warn(unavailable_message(args.ref_path) + "; the samples will be written, the metrics skipped", RuntimeWarning, stacklevel=2)
     return {k: getattr(args, k) for k in keys}
 
 

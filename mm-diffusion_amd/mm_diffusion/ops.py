@@ -305,7 +305,7 @@ def halo_tile_code(x, taps, dims):
     channel chunks on (ds1 256->128: 193 -> 164 us, ds2 640->256: 200 -> 166 us); with two chunks its prologue and epilogue have no
     co-resident block to hide behind (ds1 128->128: 103 vs 110 us)."""
     return 133 if (_HALO16 and x.dtype == torch.bfloat16 and len(taps) == 9 and dims[1] % 16 == 0 and dims[2] % 16 == 0
-                   and (x.shape[1] >= 256 or dims[1] % 8) and tuple(tuple(t) for t in taps) == tuple(TAPS_SPATIAL)) else 130
+                   and x.shape[1] >= 256 and tuple(tuple(t) for t in taps) == tuple(TAPS_SPATIAL)) else 130
 
 
 def _stats_args(stats, M, Cout):
@@ -324,8 +324,9 @@ _HALO_MIN_PIXELS = int(os.environ.get("MMD_HALO_MIN_PIXELS", "1024"))
 
 
 def halo_tile_pinned(x, taps, dims):
-    """The layers that always run on tile 130: spatial 3x3 convs on frames of >= 1024 pixels (ds1 / ds2 of the base model) - a property
-    of the layer, independent of the batch size."""
+    """The layers that always run on a halo tile (130, or 133 where halo_tile_code says so): bf16 spatial 3x3 convs on frames of at
+    least _HALO_MIN_PIXELS pixels (default 1024: ds1 / ds2 of the base model; MMD_HALO_MIN_PIXELS) - a property of the layer,
+    independent of the batch size."""
     return (_HALO_MODE == "pin" and x.dtype == torch.bfloat16 and len(taps) == 9 and dims[1] * dims[2] >= _HALO_MIN_PIXELS
             and halo_tile_ok(x, taps, dims))
 

@@ -47,13 +47,23 @@ def test_script_import_surface_resolves(surface):
             assert obj is not None, f"{mod}.{n}"
 
 
-def test_evaluator_counterpart_raises_only_when_called():
-    from mm_diffusion import evaluator
+def test_evaluator_counterpart_does_not_cost_the_samples(monkeypatch):
+    """The reference script calls eval_multimodal AFTER the sampling loop (sample_sr.py:268): the counterpart warns and returns no
+    metrics instead of throwing the finished samples away; MMD_EVAL_STRICT=1 makes it an error; the flag parser warns up front."""
+    import argparse
+    from mm_diffusion import evaluator, multimodal_script_util as msu
+    monkeypatch.delenv("MMD_EVAL_STRICT", raising=False)
+    with pytest.warns(RuntimeWarning, match="out of scope"):
+        assert evaluator.eval_multimodal("/ref", "/fake", eval_num=8) == {}
+    monkeypatch.setenv("MMD_EVAL_STRICT", "1")
     with pytest.raises(evaluator.EvaluatorUnavailable, match="out of scope"):
         evaluator.eval_multimodal("/ref", "/fake", eval_num=8)
     import inspect
     sig = inspect.signature(evaluator.eval_multimodal)
     assert list(sig.parameters) == ["real_path", "fake_path", "video_size", "eval_num"] and sig.parameters["eval_num"].default == 2048
+    ns = argparse.Namespace(ref_path="/data/landscape/test", num_channels=128)
+    with pytest.warns(RuntimeWarning, match="out of scope"):
+        assert msu.args_to_dict(ns, ["num_channels"]) == {"num_channels": 128}
 
 
 def test_bench_self_launches_its_ranks():

@@ -357,3 +357,31 @@ def test_vconv_dma_schedule_model():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.check()
+
+
+def test_noise_schedule_vp_matches_reference_fixture():
+    """NoiseScheduleVP (round 4: own structure - one knot-table object used in both directions, one small class per schedule family)
+    against the reference's class evaluated on fixed times (tools/gen_golden.py: gen_noise_schedule): every marginal_* function and
+    inverse_lambda, all three families.  Bitwise where torch's CPU kernels are deterministic; asserted to 1 ulp-level tolerance."""
+    import numpy as np
+    import torch
+    from helpers import gold
+    from mm_diffusion.multimodal_dpm_solver_plus import NoiseScheduleVP
+    g = gold("noise_schedule_vp")
+    betas = np.linspace(1e-4, 0.02, 1000, dtype=np.float64)
+    cases = {"discrete_betas": dict(schedule="discrete", betas=torch.tensor(betas)),
+             "discrete_acp": dict(schedule="discrete", alphas_cumprod=torch.tensor(np.cumprod(1 - betas), dtype=torch.float32)),
+             "linear": dict(schedule="linear"), "cosine": dict(schedule="cosine")}
+    for tag, kw in cases.items():
+        ns = NoiseScheduleVP(**kw)
+        assert ns.T == float(g[f"{tag}_T"]) and ns.total_N == int(g[f"{tag}_N"])
+        t = torch.tensor(g[f"{tag}_t"])
+        for name, fn in (("log_alpha", ns.marginal_log_mean_coeff), ("alpha", ns.marginal_alpha), ("std", ns.marginal_std), ("lambda", ns.marginal_lambda)):
+            out = fn(t)
+            assert tuple(out.shape) == g[f"{tag}_{name}"].shape
+            np.testing.assert_allclose(out.numpy(), g[f"{tag}_{name}"], rtol=2e-7, atol=1e-9, err_msg=f"{tag} {name}")
+        inv = ns.inverse_lambda(torch.tensor(g[f"{tag}_lambda"]))
+        assert tuple(inv.shape) == g[f"{tag}_inv"].shape
+        np.testing.assert_allclose(inv.numpy(), g[f"{tag}_inv"], rtol=2e-7, atol=1e-9, err_msg=f"{tag} inverse_lambda")
+    with pytest.raises(ValueError):
+        NoiseScheduleVP("quadratic")

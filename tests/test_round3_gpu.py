@@ -306,7 +306,8 @@ def test_gn_small_is_stats_plus_apply(ops, dt, act, N, F, HW, C):
 @pytest.mark.parametrize("name,N,F,qr,qg,kr,kg,win,heads", [
     ("spatial 1024", 2, 4, 4 * 1024, 1024, 4 * 1024, 1024, 1, 4), ("v<-a", 2, 16, 16 * 256, 256, 1600, 100, 1, 4),
     ("a<-v window 4", 1, 16, 1600, 100, 16 * 256, 256, 4, 6), ("ragged keys / queries", 2, 8, 8 * 77, 77, 8 * 50, 50, 3, 2),
-    ("last group takes the remainder", 1, 16, 1610, 100, 16 * 64, 64, 8, 2), ("one short tile", 1, 16, 16 * 64, 64, 16 * 25, 25, 1, 8)])
+    ("last group takes the remainder", 1, 16, 1610, 100, 16 * 64, 64, 8, 2), ("one short tile", 1, 16, 16 * 64, 64, 16 * 25, 25, 1, 8),
+    ("v<-a ds2 full size", 1, 16, 16 * 1024, 1024, 6400, 400, 1, 4), ("600 queries, 7 resident tiles", 2, 4, 4 * 600, 600, 4 * 440, 440, 1, 2)])
 def test_attn_dma_kernel_is_bitwise_the_mfma_kernel(ops, name, N, F, qr, qg, kr, kg, win, heads):
     """mmd_attn_fwd impl 4 (K / V tiles by buffer_load ... lds, V^T fragments by transposing LDS reads, one barrier per tile) against
     impl 2 (register-staged, transposing 2-byte LDS writes): same arithmetic in the same order -> bitwise equal; circular windows with
@@ -330,6 +331,14 @@ def test_attn_dma_kernel_is_bitwise_the_mfma_kernel(ops, name, N, F, qr, qg, kr,
         torch.cuda.synchronize()
         assert torch.equal(o2, o4), f"{name} shift {shift}: rel-L2 {rel_l2(o4.float().cpu(), o2.float().cpu().numpy()):.3e}"
         assert torch.equal(o2, ol), f"{name} shift {shift} (lse forward)"
+        # round 4: 64 queries per wave - streamed key tiles (impl 5) and, where the window fits the LDS, resident (impl 6)
+        for impl in (5, 6):
+            if impl == 6 and win * kg > 448:
+                continue
+            ow = torch.full((N * qr, C), 7.0, device="cuda", dtype=BF)
+            ops.attn(q, kv, ow, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=impl)
+            torch.cuda.synchronize()
+            assert torch.equal(o2, ow), f"{name} shift {shift} impl {impl}: rel-L2 {rel_l2(ow.float().cpu(), o2.float().cpu().numpy()):.3e}"
 
 
 def test_graph_replays_are_bitwise_repeatable_under_two_stream_concurrency():

@@ -351,6 +351,25 @@ def gen_dpm(tag, seed, predict_x0, thresholding, **sample_kw):
     save(tag, seed=seed, B=B, shifts=np.asarray(rec.draws), nfe=len(rec.draws) // 9, video=out["video"], audio=out["audio"])      # 9 shift draws per tiny forward
 
 
+def gen_noise_schedule():
+    """The reference's NoiseScheduleVP (dpm:11-181) on fixed times: the three schedule families, both parameterisations of the
+    discrete one; marginal_* and inverse_lambda (the solver's integer model timesteps are floor((t - 1/N) N): t must match to the bit)."""
+    from ref_mm import multimodal_dpm_solver_plus as rdpm
+    betas = np.linspace(1e-4, 0.02, 1000, dtype=np.float64)
+    g = th.Generator().manual_seed(5)
+    out = {}
+    for tag, kw in (("discrete_betas", dict(schedule="discrete", betas=th.tensor(betas))),
+                    ("discrete_acp", dict(schedule="discrete", alphas_cumprod=th.tensor(np.cumprod(1 - betas), dtype=th.float32))),
+                    ("linear", dict(schedule="linear")), ("cosine", dict(schedule="cosine"))):
+        ns = rdpm.NoiseScheduleVP(**kw)
+        t = th.cat([th.rand(61, generator=g) * (ns.T - 2e-3) + 1e-3, th.tensor([1e-3, 1. / 1000, 0.5, ns.T])]).float()
+        lam = ns.marginal_lambda(t)
+        out.update({f"{tag}_t": t, f"{tag}_log_alpha": ns.marginal_log_mean_coeff(t), f"{tag}_alpha": ns.marginal_alpha(t),
+                    f"{tag}_std": ns.marginal_std(t), f"{tag}_lambda": lam, f"{tag}_inv": ns.inverse_lambda(lam),
+                    f"{tag}_T": ns.T, f"{tag}_N": ns.total_N})
+    save("noise_schedule_vp", **out)
+
+
 SR_TINY = dict(large_size=64, small_size=16, sr_num_channels=32, sr_num_res_blocks=1, sr_attention_resolutions="2,4", sr_num_heads=2,
                sr_resblock_updown=True)
 
@@ -435,6 +454,7 @@ ALL = {
     "tiny_cond_guided_v": lambda: gen_cond("tiny", 1, 52, "4", "video", 3.0),
     "tiny_cond_guided_a": lambda: gen_cond("tiny", 1, 53, "2", "audio", 3.0),
     "helpers": gen_helpers,
+    "noise_schedule": gen_noise_schedule,
     "sr": gen_sr,
     "sr_dpm": gen_sr_dpm,
     "dpm_singlestep3": lambda: gen_dpm("tiny_dpm_singlestep3", 61, False, False, steps=20, order=3, skip_type="logSNR", method="singlestep"),
