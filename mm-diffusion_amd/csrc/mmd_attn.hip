@@ -281,6 +281,17 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_mfma_kernel(const
   }
 }
 
+// max / sum over the two lanes (l, l ^ 32) that share a query: v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip
+// queued behind the fragment reads).  swap(x, x) leaves {lower-half values, upper-half values} in the two results for every lane.
+__device__ __forceinline__ float half_pair_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_pair_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // ============================================================================= DMA-staged MFMA attention (bf16, head width 64; round 3)
 // attn_mfma_kernel above issues ~360 instructions per 64-key tile and wave for its 16 MFMAs: ~110 of them stage K / V (per-lane 64-bit
 // addresses, bounds branches, register round trip, eight 2-byte transposing LDS writes per lane), 32 re-zero the score accumulators, and
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = half_pair_max(mx);       // (v_permlane32_swap: a ds_bpermute here drains lgkmcnt - the V fragment reads in flight - first)
       const float m_new = fmaxf(m_run, mx * sc);        // sc > 0: max commutes with the scale
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
           s[kt][r] = e;
           ps += e;
         }
-      ps += __shfl_xor(ps, 32, 64);
+      ps = half_pair_sum(ps);
       l_run = l_run * alpha + ps;
       if (__any(m_new != m_run)) {
 #pragma unroll
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void attn_wide_kernel(const AttnParams p) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = half_pair_max(mx);       // (v_permlane32_swap: a ds_bpermute here drains lgkmcnt - the V fragment reads in flight - first)
       const float m_new = fmaxf(m_run[u], mx * sc);        // sc > 0: max commutes with the scale
       const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
       float ps = 0.f;
@@ -677,7 +688,7 @@ __global__ __launch_bounds__(512, 2) void attn_wide_kernel(const AttnParams p) {
           s[u][kt][r] = e;
           ps += e;
         }
-      ps += __shfl_xor(ps, 32, 64);
+      ps = half_pair_sum(ps);
       l_run[u] = l_run[u] * alpha + ps;
       if (__any(m_new != m_run[u])) {
 #pragma unroll
@@ -780,17 +791,6 @@ __global__ __launch_bounds__(512, 2) void attn_wide_kernel(const AttnParams p) {
 __device__ __forceinline__ int ats_vt_col(int j) {
   const int q = (j >> 2) & 3;
   return (j & ~12) | ((((q & 1) << 1) | (q >> 1)) << 2);
-}
-
-// max / sum over the two lanes (l, l ^ 32) that share a query: v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip
-// queued behind the fragment reads).  swap(x, x) leaves {lower-half values, upper-half values} in the two results for every lane.
-__device__ __forceinline__ float half_pair_max(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_pair_sum(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 template <int D>
