@@ -532,243 +532,11 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
   }
 }
 
-// ============================================================================= 64 queries per wave (bf16, head width 64; round 4)
-// attn_dma_kernel above is bound by what ONE 32-query wave can overlap with itself and two neighbours: every 64-key tile costs a block
-// barrier, a K / V DMA shared by only 128 queries, 24 LDS fragment reads per 16 MFMAs and a serial S -> softmax -> P V chain (a diet of
-// its VALU work changed nothing, profiles/r04_attn_fast_softmax_ab.txt).  Here a wave owns TWO 32-query sub-tiles: each K / V fragment
-// read feeds two MFMAs (12 reads per 16 MFMAs), the two sub-tiles' chains are independent (the softmax of one runs under the MFMAs of
-// the other), and a block of 8 waves covers 512 queries, so a streamed K / V tile serves four times the queries.  Two instances:
-//   RES (the key window fits in LDS: k_count <= 448 - video <- audio at every level): the whole K / V window is fetched ONCE per
-//     (batch, group, head), then the waves walk the group's 64-query tiles with no barrier at all;
-//   streamed (audio <- video, spatial self-attention): double-buffered 64-key tiles, one barrier per tile as in attn_dma_kernel.
-// Per query the arithmetic and its order are those of attn_mfma_kernel / attn_dma_kernel: bitwise the same output.
-#define ATW_MAXT 7                                  // resident key tiles (448 keys)
-template <bool RES>
-__global__ __launch_bounds__(512, 2) void attn_wide_kernel(const AttnParams p) {
-  constexpr int D = 64, KST = 4, DT = 2, TILE_B = 64 * 128, SO = D * 2 + 16;
-  constexpr int NST = RES ? ATW_MAXT : 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;                               // [NST][64 keys][128 B]
-  char* sV = smem + NST * TILE_B;                // [NST][64 keys][128 B]
-  char* sO = smem + 2 * NST * TILE_B;            // [8 waves][32 rows][SO]: output transposition, private to a wave
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  int qt, h, bg;
-  if (RES) { qt = 0; h = blockIdx.x; bg = blockIdx.y; }
-  else attn_block_coords(qt, h, bg);
-  const GroupInfo gi = group_info(p, bg);
-  if (!RES && qt * 512 >= gi.q_count) return;   // uniform per block
-  const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
-
-  // ---- DMA: wave w stages row group w (8 keys) of K and of V per tile; lane L covers row 8 w + L / 8, physical chunk L % 8
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.KV, 0, (int)((int64_t)p.nb * p.k_rows_per_batch * p.ldkv * 2), 0x00020000);
-  const int lrow = lane >> 3, pc = lane & 7;
-  const int row_in_tile = 8 * wave + lrow;
-  const uint32_t kcol = (uint32_t)((p.k_off + h * D) * 2 + ((pc ^ ((row_in_tile >> 1) & 7)) * 16));
-  const uint32_t vcol = (uint32_t)((p.v_off + h * D) * 2 + ((pc ^ (((row_in_tile >> 1) & 1) << 2)) * 16));
-  const uint32_t ldb = (uint32_t)(p.ldkv * 2);
-  auto issue = [&](int stage, int kt0) {
-    const int kk = kt0 + row_in_tile;
-    int r = gi.k_start + kk;
-    r = r >= gi.k_mod ? r - gi.k_mod : r;
-    const uint32_t rowoff = (uint32_t)(gi.k_row0 + r) * ldb;
-    const bool ok = kk < gi.k_count;
-    const uint32_t ko = ok ? rowoff + kcol : 0xfffffff0u, vo = ok ? rowoff + vcol : 0xfffffff0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(sK + stage * TILE_B + wave * 1024), 16, ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(sV + stage * TILE_B + wave * 1024), 16, vo, 0, 0, 0);
-  };
-  // fragment addresses (as attn_dma_kernel).  K: row 32 kt + l31, logical chunk 2 st + half.  V^T by transposing reads.
-  const int kx = (l31 >> 1) & 7;
-  const char* kbase = sK + l31 * 128;
-  const int vrow0 = 4 * half + ((lane & 15) >> 2);
-  const int vcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-  typedef __attribute__((ext_vector_type(4))) short s16x4;
-  typedef __attribute__((address_space(3))) s16x4* lp4;
-  const int ntiles = (gi.k_count + 63) >> 6, nfull = gi.k_count >> 6;
-
-  // per-wave query state: two 32-query sub-tiles u
-  u32x4 qf[2][KST];
-  f32x16 o[2][DT];
-  float m_run[2], l_run[2];
-  auto load_q = [&](int qbase) {                 // queries qbase + 32 u + l31
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int qi = qbase + 32 * u + l31;
-      const char* qp = p.Q + ((gi.q_row0 + qi) * p.ldq + p.q_off + h * D) * 2;
-#pragma unroll
-      for (int s = 0; s < KST; ++s) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (qi < gi.q_count) v = *(const u32x4*)(qp + (s * 16 + half * 8) * 2);
-        qf[u][s] = v;
-      }
-#pragma unroll
-      for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[u][t][r] = 0.f;
-      m_run[u] = -1e30f;
-      l_run[u] = 0.f;
-    }
-  };
-  // one 64-key tile (in LDS stage `stage`) against both sub-tiles
-  auto tile = [&](int stage, int t, auto ragged, auto&& after_reads) {
-    const char* kb = kbase + stage * TILE_B;
-    const char* vb = sV + stage * TILE_B;
-    u32x4 kf[KST][2];
-#pragma unroll
-    for (int st = 0; st < KST; ++st)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) kf[st][kt] = *(const u32x4*)(kb + kt * 32 * 128 + (((2 * st + half) ^ kx) * 16));
-    f32x16 s[2][2];
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-        s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0][kt]), __builtin_bit_cast(bf16x8, qf[u][0]), z, 0, 0, 0);
-#pragma unroll
-    for (int st = 1; st < KST; ++st)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[st][kt]), __builtin_bit_cast(bf16x8, qf[u][st]), s[u][kt], 0, 0, 0);
-    // V^T fragments (transposing reads), requested under the softmax
-    bf16x8 vf[2][2][DT];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          s16x4 lo, hi;
-          {
-            const int row = 32 * kt + 16 * st + vrow0;
-            const int ch = ((vcolb >> 4) + 4 * dt) ^ (((row >> 1) & 1) << 2);
-            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(vb + row * 128 + ch * 16 + (vcolb & 15)));
-          }
-          {
-            const int row = 32 * kt + 16 * st + 8 + vrow0;
-            const int ch = ((vcolb >> 4) + 4 * dt) ^ (((row >> 1) & 1) << 2);
-            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(vb + row * 128 + ch * 16 + (vcolb & 15)));
-          }
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          vf[kt][st][dt] = __builtin_bit_cast(bf16x8, both);
-        }
-    after_reads();                                 // streamed: the next tile's DMA goes out behind this tile's fragment reads
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if constexpr (decltype(ragged)::value) {
-        const int kbase2 = t * 64 + 4 * half;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kk = kbase2 + 32 * kt + (r & 3) + 8 * (r >> 2);
-            s[u][kt][r] = kk < gi.k_count ? s[u][kt][r] : -3e38f;
-          }
-      }
-      float mx = -3e38f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][kt][r]);
-      mx = half_pair_max(mx);       // (v_permlane32_swap: a ds_bpermute here drains lgkmcnt - the V fragment reads in flight - first)
-      const float m_new = fmaxf(m_run[u], mx * sc);        // sc > 0: max commutes with the scale
-      const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
-      float ps = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][kt][r], sc, -m_new));
-          s[u][kt][r] = e;
-          ps += e;
-        }
-      ps = half_pair_sum(ps);
-      l_run[u] = l_run[u] * alpha + ps;
-      if (__any(m_new != m_run[u])) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[u][dt][r] *= alpha;
-      }
-      m_run[u] = m_new;
-      // P fragments straight from the S^T registers (k-slot j <-> reg 8*st + j)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          bf16x8 pf;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[u][kt][8 * st + j];
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][st][dt], pf, o[u][dt], 0, 0, 0);
-        }
-    }
-  };
-  // normalise, transpose through the wave's private LDS rows, store whole 128-byte head rows
-  auto store_q = [&](int qbase) {
-    char* so = sO + wave * 32 * SO;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int qi = qbase + 32 * u + l31;
-      const float inv = 1.f / l_run[u];
-      if (p.lse2 && half == 0 && qi < gi.q_count) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run[u] + __builtin_amdgcn_logf(l_run[u]);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int d = dt * 32 + 8 * q4 + 4 * half;
-          bf16x4 w;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[u][dt][4 * q4 + e] * inv);
-          *(bf16x4*)(so + l31 * SO + d * 2) = w;
-        }
-      const int tq = qbase + 32 * u;
-#pragma unroll
-      for (int ps2 = 0; ps2 < 32 * (D / 8) / 64; ++ps2) {
-        const int idx = ps2 * 64 + lane;
-        const int row = idx / (D / 8), v = idx % (D / 8);
-        if (tq + row < gi.q_count) {
-          const u32x4 x = *(const u32x4*)(so + row * SO + v * 16);
-          *(u32x4*)(p.O + ((gi.q_row0 + tq + row) * p.ldo + h * D + v * 8) * 2) = x;
-        }
-      }
-    }
-  };
-
-  if constexpr (RES) {
-    for (int t = 0; t < ntiles; ++t) issue(t, t * 64);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                    // the window is resident: no further block synchronisation
-    asm volatile("" ::: "memory");
-    const int nq = (gi.q_count + 63) >> 6;
-    for (int q = wave; q < nq; q += 8) {
-      load_q(q * 64);
-      for (int t = 0; t < nfull; ++t) tile(t, t, std::false_type{}, [] {});
-      if (nfull < ntiles) tile(nfull, nfull, std::true_type{}, [] {});
-      store_q(q * 64);
-    }
-  } else {
-    const int qbase = qt * 512 + wave * 64;
-    load_q(qbase);
-    issue(0, 0);
-    auto body = [&](int t, auto ragged) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // this tile's DMA (the only one in flight) has landed
-      __builtin_amdgcn_s_barrier();                                  // ... for every wave; everyone is past the other stage's reads
-      asm volatile("" ::: "memory");
-      // (behind the reads: hipcc would put s_waitcnt vmcnt(0) in front of the transposing reads of a tile whose successor is in flight)
-      tile(t & 1, t, ragged, [&] { if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64); });
-    };
-    for (int t = 0; t < nfull; ++t) body(t, std::false_type{});
-    if (nfull < ntiles) body(nfull, std::true_type{});
-    if (qbase < gi.q_count) store_q(qbase);                          // (wave-uniform; sO is private to the wave)
-  }
-}
+// Round 4 also built a 64-queries-per-wave form of the kernel above (8 waves, two 32-query sub-tiles per wave sharing every K / V fragment
+// read; key tiles streamed, or - video <- audio - the whole key window resident in LDS with no barrier in the loop), bitwise equal and
+// tested, and measured it: 109.0 vs 108.9 us (spatial ds2), 50.7 vs 51.2 us (v <- a ds2, resident), 48.9 vs 50.8 us (a <- v ds2), 1.5 -
+// 2.7x slower at ds4 (profiles/r04_attn_wide_kernel_bench.txt; the code is in the history at 22912f0).  Neither the per-tile barrier +
+// DMA, nor the fragment traffic, nor the chains per wave bound this loop.  Not kept.
 
 // ============================================================================= staged-window MFMA attention (bf16)
 // For the long windows of the ds-2 level (spatial self-attention 1024 x 1024, RS cross-attention 1024 x 400 / 400 x 1024: ~80 % of
@@ -1385,22 +1153,6 @@ static int launch_dma(const AttnParams& p, int qmax, hipStream_t st) {
   return mmd_check_launch("attn_dma");
 }
 
-// 64 queries per wave: resident key window (k_count <= 448) / streamed key tiles
-static int launch_wide(const AttnParams& p, int qmax, bool resident, hipStream_t st) {
-  const size_t lds = (size_t)2 * (resident ? ATW_MAXT : 2) * 64 * 128 + 8 * 32 * (64 * 2 + 16);
-  static bool attr_done[MMD_MAX_DEVICES] = {};
-  bool& attr_set = attr_done[mmd_device_slot()];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * ATW_MAXT * 64 * 128 + 8 * 32 * 144));
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * 64 * 128 + 8 * 32 * 144));
-    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "attn_wide: set LDS attr: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  if (resident) hipLaunchKernelGGL(attn_wide_kernel<true>, dim3(p.heads, p.nb * p.G), dim3(512), lds, st, p);
-  else hipLaunchKernelGGL(attn_wide_kernel<false>, dim3(cdiv(qmax, 512), p.heads, p.nb * p.G), dim3(512), lds, st, p);
-  return mmd_check_launch("attn_wide");
-}
-
 template <int D>
 static int launch_stage(const AttnParams& p, int qmax, hipStream_t st) {
   const size_t lds = (size_t)ATS_KEYS * (D * 2 + 16) + (size_t)D * ATS_VT_STRIDE;
@@ -1466,8 +1218,8 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   // the same kernel (the kernel family of a layer - and with it the last bits of its output - must not depend on the batch size)
   const int64_t kv_batch_bytes = k_rows_per_batch * ldkv * 2;
   const bool dma_ok = stage_ok && kv_batch_bytes < 0x7fffffffLL;
-  if (impl >= 4 && impl <= 6 && !dma_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 4 - 6 (DMA-staged): needs bf16, head width 64, aligned rows, one batch of K/V below 2 GB");
-  if (dma_ok && ((impl >= 4 && impl <= 6) || (impl == 0 && dma_on))) {
+  if (impl == 4 && !dma_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 4 (DMA-staged): needs bf16, head width 64, aligned rows, one batch of K/V below 2 GB");
+  if (dma_ok && (impl == 4 || (impl == 0 && dma_on))) {
     const int per = (int)(0x7fffffffLL / kv_batch_bytes) < nb ? (int)(0x7fffffffLL / kv_batch_bytes) : nb;
     for (int n0 = 0; n0 < nb; n0 += per) {
       AttnParams c = p;
@@ -1476,9 +1228,7 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
       c.KV = p.KV + (int64_t)n0 * kv_batch_bytes;
       c.O = p.O + (int64_t)n0 * q_rows_per_batch * ldo * 2;
       if (p.lse2) c.lse2 = p.lse2 + (int64_t)n0 * q_rows_per_batch * heads;
-      // impl 5 / 6: the 64-queries-per-wave kernel, streamed / with the key window resident in LDS (bitwise the same output)
-      if (impl == 6 && k_count > 64 * ATW_MAXT) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 6 (resident window): at most %d keys per window", 64 * ATW_MAXT);
-      const int rc = impl == 6 ? launch_wide(c, qmax, true, st) : impl == 5 ? launch_wide(c, qmax, false, st) : launch_dma<64>(c, qmax, st);
+      const int rc = launch_dma<64>(c, qmax, st);
       if (rc != MMD_OK) return rc;
     }
     return MMD_OK;

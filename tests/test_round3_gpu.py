@@ -331,14 +331,6 @@ def test_attn_dma_kernel_is_bitwise_the_mfma_kernel(ops, name, N, F, qr, qg, kr,
         torch.cuda.synchronize()
         assert torch.equal(o2, o4), f"{name} shift {shift}: rel-L2 {rel_l2(o4.float().cpu(), o2.float().cpu().numpy()):.3e}"
         assert torch.equal(o2, ol), f"{name} shift {shift} (lse forward)"
-        # round 4: 64 queries per wave - streamed key tiles (impl 5) and, where the window fits the LDS, resident (impl 6)
-        for impl in (5, 6):
-            if impl == 6 and win * kg > 448:
-                continue
-            ow = torch.full((N * qr, C), 7.0, device="cuda", dtype=BF)
-            ops.attn(q, kv, ow, heads, ch, N, F, qr, qg, kr, kg, win, shift_dev=sh, impl=impl)
-            torch.cuda.synchronize()
-            assert torch.equal(o2, ow), f"{name} shift {shift} impl {impl}: rel-L2 {rel_l2(ow.float().cpu(), o2.float().cpu().numpy()):.3e}"
 
 
 def test_graph_replays_are_bitwise_repeatable_under_two_stream_concurrency():
