@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
     rb[b] = ((px >> 4) + 1) * HWD + (px & 15) + 1;
   }
   const char* bWl = sW + (wc * 64 + l31) * 128;                // + slot * W_B
-  auto compute = [&](int wslot, int bufa, int toff, auto&& dma) {   // toff: the tap's halo-row shift (a literal); dma(i): the step's i-th DMA instruction
+  auto compute = [&](int wslot, int bufa, int toff, auto&& dma, auto&& tr) {   // toff: the tap's halo-row shift (a literal); dma(i): the step's i-th DMA instruction; tr(g): norm piece behind MFMA group g
     const char* bW = bWl + wslot * W_B;
     const char* bA[2];
     int key[2];
@@ -1195,30 +1195,38 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
     // cycles apiece that every wave used to spend between the barrier and its first MFMA
     rd(0); rd(1);
     FRAG_FENCE();
-    rd(2); mm(0); dma(0);
+    rd(2); mm(0); dma(0); tr(0);
     FRAG_FENCE();
-    rd(3); mm(1); dma(1);
+    rd(3); mm(1); dma(1); tr(1);
     FRAG_FENCE();
-    mm(2); dma(2); mm(3);
+    mm(2); dma(2); tr(2);
+    FRAG_FENCE();
+    mm(3); tr(3);
     FRAG_FENCE();
   };
-  auto transform = [&](int buf, int c, int i) {                // halo slot i of stage buf (chunk c): act(x a + b) in place
+  // halo slot i of stage buf (chunk c): act(x a + b) in place, dwords d0 .. d0 + nd - 1 of its 16 bytes (two channels each).  Inside
+  // the main loop a slot is normalised in four quarters, one behind each MFMA group of a step (round 4): a whole slot (~65 VALU
+  // instructions) behind the step's sixteen MFMAs was paid in full - a wave hides ~5 instructions in the shadow of one MFMA.
+  u32x4 tv;
+  uint32_t ty[4];
+  auto transform = [&](int buf, int c, int i, int d0, int nd) {
     if (i * 512 + 512 <= HG * 64 || tid < HG * 64 - i * 512) { // the partial last slot: wave-uniform
       const float* ap = sGN + (c & 1) * 128 + glc;
-      const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4), b0 = *(const f32x4*)(ap + 64), b1 = *(const f32x4*)(ap + 68);
-      const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
       char* q = sA + buf * A_B + tid * 16 + i * 8192;
-      const u32x4 v = *(const u32x4*)q;
-      float f[EPV];
-      Elt<T>::unpack(v, f);
+      if (d0 == 0) tv = *(const u32x4*)q;
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        const float w = f[e] * av[e] + bv[e];
-        f[e] = p.gn_act ? silu_f(w) : w;
+      for (int d = d0; d < d0 + nd; ++d) {
+        const float w0 = __uint_as_float(tv[d] << 16) * ap[2 * d] + ap[64 + 2 * d];
+        const float w1 = __uint_as_float(tv[d] & 0xffff0000u) * ap[2 * d + 1] + ap[65 + 2 * d];
+        const float y[2] = {p.gn_act ? silu_f(w0) : w0, p.gn_act ? silu_f(w1) : w1};
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        const bf16x2 pk = {(__bf16)y[0], (__bf16)y[1]};
+        ty[d] = __builtin_bit_cast(uint32_t, pk);
       }
-      const u32x4 y = Elt<T>::pack(f);
-      *(u32x4*)q = ((gvalid >> i) & 1u) ? y : v;
+      if (d0 + nd == 4) {
+        const u32x4 y4 = {ty[0], ty[1], ty[2], ty[3]};
+        *(u32x4*)q = ((gvalid >> i) & 1u) ? y4 : tv;
+      }
     }
   };
 
@@ -1244,7 +1252,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) transform(0, 0, i);
+    for (int i = 0; i < NSLOT; ++i) transform(0, 0, i, 0, 4);
     // (the loop's first barrier orders these LDS writes before the first fragment reads)
   }
   for (int c = 0; c < nchunk; ++c) {
@@ -1268,8 +1276,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
       constexpr int TOFF[9] = {-19, -18, -17, -1, 0, 1, 17, 18, 19};   // (dh, dw) in row-major 3 x 3 order -> halo-row shift dh * 18 + dw
       int toff = TOFF[t];
       asm volatile("" : "+s"(toff));       // keep the 72 per-tap fragment addresses out of the registers: recomputed per step (~20 VALU)
-      compute(wslot, c & 1, toff, group);
-      if (GN && more && t >= 2 && t < 2 + NSLOT) transform((c + 1) & 1, c + 1, t - 2);   // piece t - 2 landed with this step's wait
+      const bool tr_on = GN && more && t >= 2 && t < 2 + NSLOT;                        // halo piece t - 2 landed with this step's wait
+      compute(wslot, c & 1, toff, group, [&](int g) { if (tr_on) transform((c + 1) & 1, c + 1, t - 2, g, 1); });
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

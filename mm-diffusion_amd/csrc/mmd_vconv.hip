@@ -181,42 +181,30 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // ---- GroupNorm(+SiLU) of one 16-byte slot in place, in two halves that are placed between the MFMA groups of a step
+  // ---- GroupNorm(+SiLU) of one 16-byte slot in place, in PIECES of d0 .. d0 + nd - 1 of its four dwords (two channels each) that
+  // are placed behind the MFMA groups of a step: a wave hides ~5 other instructions in the shadow of one of its MFMAs
+  // (profiles/r04_instruction_rates.txt: v_fma 5.1, v_exp / v_rcp 8.5 cycles per instruction against 32 per MFMA) - a quarter slot
+  // (~16 VALU) per group of four MFMAs fits, half a slot (33) does not and its excess is paid in full.
   u32x4 tv;
-  f32x4 ta1, tb1;
-  uint32_t ty0, ty1;
-  auto tr_first = [&](int stage, int cpar, int i) {
-    const char* q = sA + stage * VC_STAGE_B + tid * 16 + i * 8192;
-    tv = *(const u32x4*)q;
-    const float* ap = sGN + cpar * 64 + ((glc >> (2 * i)) & 3u) * 8;
-    const f32x4 a0 = *(const f32x4*)ap, b0 = *(const f32x4*)(ap + 32);
-    ta1 = *(const f32x4*)(ap + 4);
-    tb1 = *(const f32x4*)(ap + 36);
-    float f[4] = {__uint_as_float(tv[0] << 16), __uint_as_float(tv[0] & 0xffff0000u), __uint_as_float(tv[1] << 16),
-                  __uint_as_float(tv[1] & 0xffff0000u)};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float w = f[e] * a0[e] + b0[e];
-      f[e] = GNM == 2 ? silu_f(w) : w;
-    }
-    ty0 = vc_pack2(f[0], f[1]);
-    ty1 = vc_pack2(f[2], f[3]);
-  };
-  auto tr_second = [&](int stage, int i) {
+  uint32_t ty[4];
+  auto tr_piece = [&](int stage, int i, int d0, int nd) {
     char* q = sA + stage * VC_STAGE_B + tid * 16 + i * 8192;
-    float f[4] = {__uint_as_float(tv[2] << 16), __uint_as_float(tv[2] & 0xffff0000u), __uint_as_float(tv[3] << 16),
-                  __uint_as_float(tv[3] & 0xffff0000u)};
+    if (d0 == 0) tv = *(const u32x4*)q;
+    const float* ap = sGN + stage * 64 + ((glc >> (2 * i)) & 3u) * 8;     // the stage's affine ring slot: a (32) | b (32)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float w = f[e] * ta1[e] + tb1[e];
-      f[e] = GNM == 2 ? silu_f(w) : w;
+    for (int d = d0; d < d0 + nd; ++d) {
+      const float a0 = ap[2 * d], a1 = ap[2 * d + 1], b0 = ap[32 + 2 * d], b1 = ap[33 + 2 * d];
+      const float w0 = __uint_as_float(tv[d] << 16) * a0 + b0, w1 = __uint_as_float(tv[d] & 0xffff0000u) * a1 + b1;
+      ty[d] = vc_pack2(GNM == 2 ? silu_f(w0) : w0, GNM == 2 ? silu_f(w1) : w1);
     }
-    const u32x4 y = {ty0, ty1, vc_pack2(f[0], f[1]), vc_pack2(f[2], f[3])};
-    *(u32x4*)q = ((gvalid >> i) & 1u) ? y : tv;
+    if (d0 + nd == 4) {
+      const u32x4 y = {ty[0], ty[1], ty[2], ty[3]};
+      *(u32x4*)q = ((gvalid >> i) & 1u) ? y : tv;
+    }
   };
 
   // ---- one spatial step: tap row J (dh = J - 1) of chunk c; MORE: another chunk follows.  Six sub-steps k = (tap dw, 16-channel k-step),
-  // each {fragment reads two sub-steps ahead | 4 MFMAs | ONE DMA instruction | half a slot of the input norm}: the DMA issue (~100
+  // each {fragment reads two sub-steps ahead | 4 MFMAs | ONE DMA instruction | a quarter slot of the input norm}: the DMA issue (~100
   // cycles apiece beside LDS traffic) and the norm's VALU work run under the MFMAs instead of in front of them.
   // DMA groups (per wave, in issue order) and the counted waits they imply (a step's top wait leaves exactly the previous step's
   // group - minus what this step needs of it - in flight):
@@ -224,8 +212,8 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   //   J = 1: weights of step s + 2 (3), halo rows hh 4..5 of chunk c + 1 (2)               top of J = 2: vmcnt(5)
   //   J = 2: weights of step s + 2 (3), affine rows of chunk c + 2 (GN: 1)                 top of J = 0: vmcnt(3 + GN)
   //   last chunk: J = 0 weights (3); J = 1 / J = 2 the temporal steps 0 / 1 (2 each)       tops: vmcnt(3), vmcnt(2), (temporal) vmcnt(2)
-  // Norm slots (GN): 0, 1 of the next stage at J = 1, slot 2 at J = 2 (their pieces landed with the top of J = 1), slots 3 (, 4) of
-  // THIS stage at J = 0 (rows hh 4..5: landed with this step's top wait, not read by the dh = -1 taps).
+  // Norm slots (GN): 0, 1, 2 of the next stage in twelve quarters over the sub-steps of J = 1 and J = 2 (their pieces landed with
+  // the top of J = 1), slots 3 (, 4) of THIS stage at J = 0 (rows hh 4..5: landed with this step's top wait, not read by the dh = -1 taps).
   auto spatial = [&](auto jtag, auto mtag, int c) {
     constexpr int J = decltype(jtag)::value;
     constexpr bool MORE = decltype(mtag)::value;
@@ -256,11 +244,15 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     };
     const bool tr_on = GN && (J == 0 ? c > 0 : MORE);      // block-uniform
     const int tstage = J == 0 ? c & 1 : (c + 1) & 1;       // the stage (= affine ring slot) whose slots this step normalises
-    auto tr = [&](int k) {                                 // half a slot behind MFMA group k
+    auto tr = [&](int k) {                                 // a piece of the norm behind MFMA group k
       if (!tr_on) return;
-      const int i = J == 0 ? 3 + (k >> 1) : (J == 1 ? (k >> 1) : 2);
-      if ((J == 2 && k >= 2) || k >= 4 || (J == 0 && k >= 2 && wave >= 4)) return;
-      if (k & 1) tr_second(tstage, i); else tr_first(tstage, tstage, i);
+      if constexpr (J == 0) {                              // slot 3 in quarters (k = 0..3), slot 4 in halves (k = 4, 5; waves 0-3)
+        if (k < 4) tr_piece(tstage, 3, k, 1);
+        else if (wave < 4) tr_piece(tstage, 4, 2 * (k - 4), 2);
+      } else {                                             // slots 0, 1, 2 in twelve quarters over the twelve sub-steps of J = 1, 2
+        const int qq = (J - 1) * 6 + k;
+        tr_piece(tstage, qq >> 2, qq & 3, 1);
+      }
     };
     const char* bW = sW + J * VC_WSLOT_B + wl1;            // ring slot of step 3 c + J = J
     const char* bA[2];
@@ -331,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   if (GN) {                                                // chunk 0 is normalised before the first MFMA
 #pragma unroll
     for (int i = 0; i < 5; ++i)
-      if (i < 4 || wave < 4) { tr_first(0, 0, i); tr_second(0, i); }
+      if (i < 4 || wave < 4) tr_piece(0, i, 0, 4);
     // (the first step's barrier orders these LDS writes before the first fragment reads)
   }
 #pragma unroll
