@@ -165,8 +165,8 @@ def cpu_baseline(fl, seconds_budget=30.0):
 
 
 def wgrad_roofline(B, device):
-    """The training step's dominant kernel family - the conv weight gradients (22 % of the step's kernel time, profiles/r02_train_step_
-    kernel_stats.txt) - measured live with HIP events on the launch stream, on the video 3x3 / k=3 / 1x1 layer shapes of the step at this
+    """The training step's dominant kernel family - the conv weight gradients (their share of the step's kernel time comes from the
+    tracked rocprofv3 trace of this command, profiles/kernel_stats_train.json / r04_train_step_kernel_stats.txt) - measured live with HIP events on the launch stream, on the video 3x3 / k=3 / 1x1 layer shapes of the step at this
     batch size: algorithmic flops (2 M Cout Cin taps) / average launch time against the dense bf16 MFMA peak."""
     import ctypes
     from mm_diffusion import _hip as H, ops
@@ -201,8 +201,22 @@ def wgrad_roofline(B, device):
     for e in ev:
         H.lib().mmd_event_destroy(e)
     ach = flops / us / 1e6
+    # how much of the step's kernel time the family is: from the rocprofv3 kernel trace of this command (profiles/kernel_stats_train.json,
+    # tools/round_profile.sh), when that profile was taken on THIS build
+    share = share_note = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "kernel_stats_train.json")) as f:
+            ks = json.load(f)
+        if ks.get("build_id") == build_id():
+            tot = sum(v["total_us"] for v in ks["kernels"].values())
+            share = sum(v["total_us"] for k, v in ks["kernels"].items() if "wgrad" in k or "colsum" in k) / max(tot, 1e-9)
+            share_note = f"profiles/kernel_stats_train.json ({ks.get('command')})"
+        else:
+            share_note = f"profiles/kernel_stats_train.json is from build {ks.get('build_id')}, this is {build_id()}: not used"
+    except Exception:
+        pass
     return {"kernel": "conv_wgrad (wgrad_tr_bf16 / wgrad128_bf16 + colsum)", "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "per_shape": per,
+            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "per_shape": per, "share_of_step_kernel_time": share, "share_source": share_note,
             "note": "launch-weighted over six layer shapes of the step at this batch size, HIP events on the launch stream"}
 
 
@@ -559,19 +573,42 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json is from build {pt.get('build_id')}, this is {build_id()}: not used"
         except Exception:
             pass
+        # the same kernel family's average launch INSIDE the profiled step (profiles/kernel_stats.json: rocprofv3 --kernel-trace of this
+        # command, tools/round_profile.sh; both launch streams busy, caches as the step leaves them) - the isolated HIP-event replay
+        # above flatters a launch by up to 15 %.  `frac` is computed from the in-step figure when it exists for THIS build.
+        in_step_ms = in_step_note = None
+        try:
+            import re
+            with open(os.path.join(ROOT, "profiles", "kernel_stats.json")) as f:
+                ks = json.load(f)
+            pat = {"conv_gemm<bf16,strip>": r"conv1x1_strip_kernel<\d+, \d+, \d+, 0, \d+>", "gn_conv1x1<bf16,strip>": r"conv1x1_strip_kernel<\d+, \d+, \d+, [12], \d+>",
+                   "conv_gemm<bf16,128glds>": r"conv_gemm_glds_kernel<.*, 2, (true|false)>", "conv_gemm<bf16,128ring>": r"conv_gemm_glds_kernel<.*, 4, (true|false)>",
+                   "attn_fwd": r"attn_(dma|mfma|stage)_kernel", "vconv2d1d<bf16,gn>": r"vconv2d1d_kernel", "gn_conv_gemm<bf16,256halo>": r"conv_gemm_halo16_kernel<true>"}.get(dom)
+            if ks.get("build_id") != build_id():
+                in_step_note = f"profiles/kernel_stats.json is from build {ks.get('build_id')}, this is {build_id()}: not used"
+            elif pat:
+                hit = [v for k, v in ks["kernels"].items() if re.search(pat, k)]
+                if hit:
+                    in_step_ms = sum(v["total_us"] for v in hit) / max(sum(v["calls"] for v in hit), 1) / 1e3
+        except Exception:
+            pass
         # which roof binds the dominant kernel: its arithmetic intensity against the ridge (MFMA peak / HBM peak = 312 flop/B in bf16)
         ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         ai = a["flops"] / max(a["bytes"], 1)
         bound, unit = "mfma", "TFLOP/s"
         if ai < ridge:             # HBM-side kernel (elementwise, or a short-K GEMM): price the algorithmic bytes against 8 TB/s
             bound, unit, ach, peak = "hbm", "GB/s", a["bytes"] / (a["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS
+        iso_ms = a["ms"] / max(a["calls"], 1)
+        if in_step_ms:                         # per-launch algorithmic work / the in-step launch time
+            ach = ach * iso_ms / in_step_ms
         res["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                           "avg_launch_ms_in_step": in_step_ms, "avg_launch_ms_in_step_note": in_step_note or ("rocprofv3 kernel trace of this command, profiles/kernel_stats.json" if in_step_ms else "no profile of this build: frac is from the isolated replay"),
                            "arithmetic_intensity_flop_per_B": ai, "ridge_flop_per_B": ridge,
                            "mfma_frac_of_peak": a["flops"] / (a["ms"] * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS),
-                           "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": a["calls"], "avg_launch_ms": a["ms"] / max(a["calls"], 1),
+                           "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": a["calls"], "avg_launch_ms": iso_ms,
                            "algorithmic_gflop_per_launch": a["flops"] / max(a["calls"], 1) / 1e9,
                            "algorithmic_MB_per_launch": a["bytes"] / max(a["calls"], 1) / 1e6,
-                           "hbm_frac_of_8TBs": a["bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "hbm_frac_of_8TBs": a["bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS * (iso_ms / in_step_ms if in_step_ms else 1.0),
                            "share_of_step": a["ms"] / total_ms}
         res["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         hb = {k: v for k, v in agg.items() if v["flops"] == 0 and v["bytes"] > 0}
