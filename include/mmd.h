@@ -180,31 +180,6 @@ int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const float* gn_
                          int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                          int M, int Cout, int Cin, int tile, float* stats, int64_t stats_ld, void* stream);
 
-/* Finalize in the CONSUMER (round 4): for slices with few records the mmd_gn_finalize_stats launch between a producer and the
- * kernel that applies the norm is a 7 us link of the step's dependency chain that moves a few KB.  Here the consumer's blocks turn
- * the records of their own slice into the fused affine in their prologue (the same double sums, var = E[x^2] - mean^2, and the same
- * a = rstd gamma (1 + scale), b = (beta - mean rstd gamma)(1 + scale) + shift as mmd_gn_finalize_stats; nn.py:16-33, unet:457-470).
- * `rec` as for mmd_gn_finalize_stats: the first quad of the C normalised channels, rec[(row / 64) * rec_ld + quad] = (sum, sumsq);
- * slices are S contiguous runs of Tn rows, Tn % 64 == 0, C % 128 == 0.  Every block re-reads its slice's Tn / 64 x C / 4 records
- * (from L2), so the caller uses this where that is a few KB (the engine: <= 64 KB per slice) and the finalize launch elsewhere. */
-typedef struct mmd_gn_rec {
-  const float* rec;
-  long long rec_ld;               /* quads per record row */
-  const float* gamma;             /* [C] */
-  const float* beta;              /* [C] */
-  const float* film;              /* [S, >= 2C] rows (scale | shift) or NULL */
-  long long film_ld;
-  float eps;
-} mmd_gn_rec;
-/* mmd_gn_apply for contiguous slices with the affine taken from records: y = act(GN(x) gamma + beta (FiLM)). */
-int mmd_gn_apply_rec(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn,
-                     const mmd_gn_rec* src, int act, void* stream);
-/* mmd_gn_conv1x1 / mmd_gn_conv1x1_stats (stats nullable) on the row-strip main loop (tile 131, bf16, Cin in {128, 256, 384, 512},
- * rows_per_slice >= the strip height) with the affine taken from records. */
-int mmd_gn_conv1x1_rec(int dtype, const void* A, int64_t lda, const mmd_gn_rec* src, int act, int S, int64_t rows_per_slice,
-                       const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy, int M, int Cout,
-                       int Cin, float* stats, int64_t stats_ld, void* stream);
-
 /* Spatial 3x3 conv whose input GroupNorm32(+FiLM)(+SiLU) is applied to the staged halo tile in LDS (tile 130, bf16, the nine
  * (0, dh, dw) taps, slices of whole frames): Y = conv3x3(act(A * gn_a[s(m)] + gn_b[s(m)])) + bias (+ R), zero padding of the
  * NORMALISED activation.  Replaces GroupNorm32 -> SiLU -> video_conv_spatial of the ResBlock in_layers (unet:339-340,83-99,

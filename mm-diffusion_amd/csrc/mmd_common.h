@@ -119,55 +119,6 @@ __device__ __forceinline__ float halfwave_total(float v) {
   return dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
 }
 
-// ----------------------------------------------------------------------------- GroupNorm moments in the CONSUMER (include/mmd.h: mmd_gn_rec)
-// The 256 threads of a block turn the quad records of `nsl` (1 or 2) consecutive slices, first slice s0, into the (mean, rstd) of the
-// 32 groups: smr[(sl * 32 + g) * 2 + {0, 1}].  Thread = (thread row, group); the thread rows of a slice (8, or 4 each for two
-// slices) walk its nrec x qpg records strided, four independent 8-byte loads in flight; the partials meet in LDS (sp: 8 x 32 double2
-// = 4 KB) and ONE thread per (slice, group) adds them in row order: a fixed order, deterministic.  After the sums the arithmetic is
-// gn_finalize_rec_kernel's: double, var = E[x^2] - mean^2 clamped at 0, rstd = 1 / sqrt(var + eps).  (Sums of fp32 records in
-// double are exact unless the records of a group span more than ~2^17 in magnitude, so the two kernels agree to the last bit in
-// practice; nothing relies on it - which of them a norm uses is a function of its geometry.)
-// Two __syncthreads(): sp / smr may alias memory the block does not otherwise touch until the second one.
-__device__ __forceinline__ void gn_rec_moments(const mmd_gn_rec& r, int C, int Tn, int s0, int nsl, int S, double* sp, float* smr, int tid) {
-  const int cpg = C / 32, qpg = cpg >> 2, nrec = Tn >> 6;
-  const int g = tid & 31, idx = tid >> 5;
-  const int nparts = nsl == 2 ? 4 : 8;
-  const int sl = nsl == 2 ? idx >> 2 : 0, part = nsl == 2 ? idx & 3 : idx;
-  const int s = min(s0 + sl, S - 1);
-  const int total = nrec * qpg;
-  const float* base = r.rec + ((int64_t)s * nrec * r.rec_ld + (int64_t)g * qpg) * 2;
-  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int i = part; i < total; i += 4 * nparts) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {            // branch-free: clamped address, masked value -> the four loads issue together
-      const int k = i + nparts * u;
-      const int kk = min(k, total - 1);
-      const int rr = kk / qpg, c = kk - rr * qpg;
-      const float2 v = *(const float2*)(base + ((int64_t)rr * r.rec_ld + c) * 2);
-      const double m = k < total ? 1.0 : 0.0;
-      a[u] += m * (double)v.x;
-      b[u] += m * (double)v.y;
-    }
-  }
-  sp[(idx * 32 + g) * 2] = (a[0] + a[1]) + (a[2] + a[3]);
-  sp[(idx * 32 + g) * 2 + 1] = (b[0] + b[1]) + (b[2] + b[3]);
-  __syncthreads();
-  if (tid < 32 * nsl) {
-    double sa = 0.0, sb = 0.0;
-    for (int q = 0; q < nparts; ++q) {
-      sa += sp[(((tid >> 5) * nparts + q) * 32 + g) * 2];
-      sb += sp[(((tid >> 5) * nparts + q) * 32 + g) * 2 + 1];
-    }
-    const double cnt = (double)Tn * (double)cpg;
-    const double mean = sa / cnt;
-    double var = sb / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    smr[tid * 2] = (float)mean;
-    smr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)r.eps));
-  }
-  __syncthreads();
-}
-
 
 // ----------------------------------------------------------------------------- in-launch GroupNorm statistics ("tail", include/mmd.h)
 // A partial sum p (fp32) enters a 64-bit integer accumulator pair exactly: hi = rint(p 2^H), lo = rint((p - hi 2^-H) 2^(H+24)) - both

@@ -29,9 +29,6 @@ struct ConvGemmParams {
   const float* gn_a; const float* gn_b;      // [S, Cin]; contiguous slices of gn_rows rows (>= BM), Cin <= 256
   int gn_act, gn_S;
   int64_t gn_rows;
-  // or (row-strip kernel): the affine computed in the block's prologue from the producers' quad records (include/mmd.h: mmd_gn_rec);
-  // gr.rec != nullptr switches it on, gn_act / gn_S / gn_rows as above, channels = Cin
-  mmd_gn_rec gr;
   // optional GroupNorm statistics of the OUTPUT for its consumer (mmd_gn_finalize_stats): per (64-row record, column) the sum and
   // sum of squares of the stored values, stats[(m / 64) * stats_ld + column] = float2; M % 64 == 0
   float* stats; int64_t stats_ld;
@@ -1340,8 +1337,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 // (halfwave_total - the DPP fold of the quad statistics - lives in mmd_common.h: the fused VideoConv kernel shares it.)
 template <int KS, int RF, int CC, int GNM, int STM>   // STM: output statistics 0 none / 1 per-column records / 2 in-launch tail (compile
                                              // time: the runtime branches cost the K = 128 instance 30 spilled registers).  GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
-                                             // normalisation in one kernel spill ~100 registers around the branch); 3 / 4 = 1 / 2 with
-                                             // the affine finalised HERE from the producers' records (p.gr) instead of read from p.gn_a / p.gn_b
+                                             // normalisation in one kernel spill ~100 registers around the branch)
 __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
   constexpr int K = 64 * KS;                 // input channels
   constexpr int NCG = 4 * KS;                // 16-channel k-steps (one MFMA each)
@@ -1428,7 +1424,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
   }
   // bias of the column range and the GroupNorm affine rows of the (at most two) slices of the strip -> LDS.  All global loads
   // first (branch-free: clamped indices, the zero page when there is no bias), then the LDS writes: one round trip for everything
-  constexpr bool gn = GNM != 0, GNR = GNM >= 3, SILU = GNM == 2 || GNM == 4;
+  constexpr bool gn = GNM != 0;
   float bias_v[8];                                       // Cs <= 2048
   {
     const float* bsrc = p.bias ? p.bias + cbase : (const float*)g_zero_page;
@@ -1440,43 +1436,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
 #pragma unroll
   for (int f = 0; f < RF; ++f) gsel[f] = 0;
   float tv[KS];                                          // entry i = tid + 256 e of [2 slices][a | b][K]
-  if constexpr (GNR) {
-    // finalize in the consumer: (mean, rstd) of the strip's one or two slices from the records (two barriers inside; the scratch
-    // aliases weight stage 1, which no DMA targets before the chunk loop), then every thread writes the K / 128 (slice, channel)
-    // pairs of the table it owns.  gamma / beta / FiLM are requested BEFORE the moments: one round trip, not two
-    constexpr int NP = KS / 2;                           // 2 K pairs over 256 threads
-    const int gnr = (int)p.gn_rows;
-    const int s0 = m0 / gnr;
-    const int nsl = (s0 + 1 < p.gn_S && (m0 + BR - 1) / gnr > s0) ? 2 : 1;      // block-uniform
-    float gm[NP], bt[NP], fsc[NP], fsh[NP];
-#pragma unroll
-    for (int e = 0; e < NP; ++e) {
-      const int i = tid + 256 * e, sl = i / K, c = i % K;
-      const int sidx = min(s0 + sl, p.gn_S - 1);
-      gm[e] = p.gr.gamma[c];
-      bt[e] = p.gr.beta[c];
-      fsc[e] = p.gr.film ? 1.f + p.gr.film[(int64_t)sidx * p.gr.film_ld + c] : 1.f;
-      fsh[e] = p.gr.film ? p.gr.film[(int64_t)sidx * p.gr.film_ld + K + c] : 0.f;
-    }
-    double* sp = (double*)(sW + STAGE_B);
-    float* smr = (float*)(sW + STAGE_B + 8 * 32 * 2 * 8);
-    gn_rec_moments(p.gr, K, gnr, s0, nsl, p.gn_S, sp, smr, tid);
-#pragma unroll
-    for (int e = 0; e < NP; ++e) {
-      const int i = tid + 256 * e, sl = i / K, c = i % K;
-      const int mi = (min(sl, nsl - 1) * 32 + c / (K / 32)) * 2;
-      float av = smr[mi + 1] * gm[e];
-      float bv = bt[e] - smr[mi] * av;
-      if (p.gr.film) {
-        av *= fsc[e];
-        bv = bv * fsc[e] + fsh[e];
-      }
-      sGN[sl * 2 * K + c] = av;
-      sGN[sl * 2 * K + K + c] = bv;
-    }
-#pragma unroll
-    for (int f = 0; f < RF; ++f) gsel[f] = min(rowc[f] / gnr - s0, 1) * 2 * K;
-  } else if (gn) {
+  if (gn) {
     const int gnr = (int)p.gn_rows;                      // < 2^31: gn_S * gn_rows == M
     const int s0 = m0 / gnr;                             // gn_rows >= BR: the strip touches at most two slices
 #pragma unroll
@@ -1496,7 +1456,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
 #pragma unroll
     for (int e = 0; e < 8; ++e) sAccT[tid + 256 * e] = 0;           // 16 KB (launcher: TAIL_B)
   }
-  if (gn && !GNR) {
+  if (gn) {
 #pragma unroll
     for (int e = 0; e < KS; ++e) sGN[tid + 256 * e] = tv[e];
   }
@@ -1517,7 +1477,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float y = x[e + k] * av[k] + bv[k];
-            x[e + k] = SILU ? silu_f(y) : y;
+            x[e + k] = GNM == 2 ? silu_f(y) : y;
           }
         }
         u32x4 y = Elt<__bf16>::pack(x);
@@ -1712,7 +1672,7 @@ static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
   const int Cs = p.Cout / nsplit;
   constexpr size_t REC_B = RF == 1 ? 2 * 4 * (CC / 32) * 2 * 32 * sizeof(float) : 0;
   constexpr size_t TAIL_B = 8 + 2048 * sizeof(long long);
-  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (GNM != 0 ? 4 * (size_t)(64 * KS) * 4 : 0) + REC_B + (p.gt.acc ? TAIL_B : 0);
+  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0) + REC_B + (p.gt.acc ? TAIL_B : 0);
   const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4 + REC_B + TAIL_B;
   if (lds > lds_max) return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): %d output channels per block", Cs);
   static bool attr_done[MMD_MAX_DEVICES] = {};
@@ -1728,11 +1688,6 @@ static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
 
 template <int KS, int RF, int CC, int STM>
 static int launch_conv1x1_strip_st(const ConvGemmParams& p, hipStream_t st) {
-  if constexpr (STM != 2) {        // (the records-in-the-consumer form is not built for the in-launch tail: two experiments, never combined)
-    if (p.gr.rec) return p.gn_act ? launch_conv1x1_strip_mode<KS, RF, CC, 4, STM>(p, st) : launch_conv1x1_strip_mode<KS, RF, CC, 3, STM>(p, st);
-  } else if (p.gr.rec) {
-    return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): GroupNorm from records and the in-launch tail are alternatives");
-  }
   if (!p.gn_a) return launch_conv1x1_strip_mode<KS, RF, CC, 0, STM>(p, st);
   return p.gn_act ? launch_conv1x1_strip_mode<KS, RF, CC, 2, STM>(p, st) : launch_conv1x1_strip_mode<KS, RF, CC, 1, STM>(p, st);
 }
@@ -1748,7 +1703,7 @@ static int launch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
 static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
   const int K = p.Cin * p.ntaps;
   const int rf = K <= 256 ? 2 : 1, cc = K <= 256 ? 64 : 32;
-  if ((K != 128 && K != 256 && K != 384 && K != 512) || p.Cin % 64 != 0 || p.Cout % cc != 0 || ((p.gn_a || p.gr.rec) && (p.ntaps != 1 || p.gn_rows < 128 * rf)) ||
+  if ((K != 128 && K != 256 && K != 384 && K != 512) || p.Cin % 64 != 0 || p.Cout % cc != 0 || (p.gn_a && (p.ntaps != 1 || p.gn_rows < 128 * rf)) ||
       (p.ntaps == 1 && (p.taps[0] || p.taps[1] || p.taps[2])))
     return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): needs ntaps * Cin in {128, 256, 384, 512}, Cin %% 64 == 0, Cout %% %d == 0, "
                          "fused GroupNorm only for 1x1 convs with slices of >= %d rows (got Cin=%d ntaps=%d Cout=%d)", cc, 128 * rf, p.Cin, p.ntaps, p.Cout);
@@ -1903,7 +1858,7 @@ static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st)
 static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                           void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
                           int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_S, int64_t gn_rows, float* stats,
-                          int64_t stats_ld, void* stream, const mmd_gn_tail* tail = nullptr, const mmd_gn_rec* grec = nullptr) {
+                          int64_t stats_ld, void* stream, const mmd_gn_tail* tail = nullptr) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_gemm: bad dtype %d", dtype);
   MMD_REQUIRE(A && W && Y && M > 0 && Cout > 0 && Cin > 0, "conv_gemm: null/empty argument");
@@ -1922,16 +1877,6 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   p.R = (const char*)R; p.ldr = ldr; p.Y = (char*)Y; p.ldy = ldy;
   p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
   p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = gn_act; p.gn_S = gn_S; p.gn_rows = gn_rows;
-  p.gr = mmd_gn_rec{};
-  if (grec) {
-    MMD_REQUIRE(!gn_a && tile == 131 && ntaps == 1 && dtype == MMD_BF16, "gn_conv1x1_rec: the row-strip main loop (tile 131, bf16 1x1 convs) only");
-    MMD_REQUIRE(grec->rec && grec->gamma && grec->beta && grec->eps > 0.f && (uintptr_t)grec->rec % 8 == 0, "gn_conv1x1_rec: null records / gamma / beta");
-    MMD_REQUIRE(gn_S > 0 && gn_rows >= 128 && gn_rows % 64 == 0 && (int64_t)gn_S * gn_rows == M && Cin % 128 == 0 && grec->rec_ld >= Cin / 4 &&
-                    (!grec->film || grec->film_ld >= 2 * Cin),
-                "gn_conv1x1_rec: S slices of rows_per_slice rows (a multiple of 64) must cover M, Cin %% 128 == 0 (groups of whole quads), "
-                "rec_ld >= Cin / 4 (got S=%d rows=%ld Cin=%d M=%d)", gn_S, (long)gn_rows, Cin, M);
-    p.gr = *grec;
-  }
   MMD_REQUIRE(!stats || (M % 64 == 0 && Cout % 4 == 0 && stats_ld >= Cout / 4 && tile != 130 && tile != 133 && (uintptr_t)stats % 8 == 0),
               "conv_gemm: output statistics need M %% 64 == 0, Cout %% 4 == 0, stats_ld >= Cout / 4 (quads) and a row-tiled main loop (not tiles 130 / 133)");
   p.stats = stats; p.stats_ld = stats_ld;
@@ -2000,17 +1945,6 @@ extern "C" int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const
   MMD_REQUIRE(gn_a && gn_b && stats, "gn_conv1x1_stats: null GroupNorm affine / statistics buffer");
   return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, S,
                         rows_per_slice, stats, stats_ld, stream);
-}
-
-// mmd_gn_conv1x1 / mmd_gn_conv1x1_stats with the affine finalised in the blocks' prologues from the producers' quad records
-// (include/mmd.h: mmd_gn_rec): no mmd_gn_finalize_stats launch between the producer and this GEMM.  Row-strip main loop only.
-extern "C" int mmd_gn_conv1x1_rec(int dtype, const void* A, int64_t lda, const mmd_gn_rec* src, int act, int S, int64_t rows_per_slice,
-                                  const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy, int M, int Cout,
-                                  int Cin, float* stats, int64_t stats_ld, void* stream) {
-  static const int tap0[3] = {0, 0, 0};
-  MMD_REQUIRE(src, "gn_conv1x1_rec: null record source");
-  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, 131, nullptr, nullptr, act, S,
-                        rows_per_slice, stats, stats_ld, stream, nullptr, src);
 }
 
 // Spatial 3x3 conv of GroupNorm32(+FiLM)(+SiLU)'d rows on the halo tile (tile 130, bf16): the normalisation is applied to the staged

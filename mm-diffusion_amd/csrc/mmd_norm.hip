@@ -286,85 +286,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const char* __restrict__ 
   }
 }
 
-// gn_apply with the affine finalised in the block's prologue from the producers' quad records (include/mmd.h: mmd_gn_rec; contiguous
-// slices): the mmd_gn_finalize_stats launch between the producer and this pass disappears.  Block = R rows of ONE slice; gamma / beta /
-// FiLM of the thread's channel vector are requested before the moments (one round trip); the apply loop is gn_apply_kernel's.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_rec_kernel(const char* __restrict__ x, int64_t ldx, char* __restrict__ y, int64_t ldy,
-                                                           int C, int S, int Tn, const mmd_gn_rec r, int act, int R) {
-  constexpr int EPV = Elt<T>::EPV;
-  constexpr int ES = 16 / EPV;
-  __shared__ double sp[8 * 32 * 2];
-  __shared__ float smr[64];
-  const int s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int CV = C / EPV, CVB = min(CV, 256), RPP = 256 / CVB;
-  const int col0 = tid % CVB, rl = tid / CVB;
-  const int cpg = C / GN_GROUPS;
-  float gm[EPV], bt[EPV], fsc[EPV], fsh[EPV];
-  auto load_params = [&](int col) {
-#pragma unroll
-    for (int e = 0; e < EPV; e += 4) {
-      const int c = col * EPV + e;
-      const f32x4 g4 = *(const f32x4*)(r.gamma + c), b4 = *(const f32x4*)(r.beta + c);
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (r.film) {
-        sc = *(const f32x4*)(r.film + (int64_t)s * r.film_ld + c);
-        sh = *(const f32x4*)(r.film + (int64_t)s * r.film_ld + C + c);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { gm[e + k] = g4[k]; bt[e + k] = b4[k]; fsc[e + k] = 1.f + sc[k]; fsh[e + k] = sh[k]; }
-    }
-  };
-  load_params(col0);
-  gn_rec_moments(r, C, Tn, s, 1, S, sp, smr, tid);
-  if (rl >= RPP) return;
-  for (int cp = 0; cp < CV; cp += 256) {
-    const int col = col0 + cp;
-    if (col >= CV) break;
-    if (cp) load_params(col);
-    float av[EPV], bv[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      const int gi = (col * EPV + e) / cpg;
-      float a1 = smr[gi * 2 + 1] * gm[e];
-      float b1 = bt[e] - smr[gi * 2] * a1;
-      if (r.film) {
-        a1 *= fsc[e];
-        b1 = b1 * fsc[e] + fsh[e];
-      }
-      av[e] = a1;
-      bv[e] = b1;
-    }
-    const int64_t base = (int64_t)s * Tn;
-    const char* xp = x + (base * ldx + (int64_t)col * EPV) * ES;
-    char* yp = y + (base * ldy + (int64_t)col * EPV) * ES;
-    const int64_t xs = ldx * ES, ys = ldy * ES;
-    const int j0 = chunk * R, j1 = min(j0 + R, Tn);
-    for (int jb = j0 + rl; jb < j1; jb += 4 * RPP) {
-      u32x4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = jb + u * RPP;
-        if (j < j1) v[u] = *(const u32x4*)(xp + (int64_t)j * xs);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = jb + u * RPP;
-        if (j < j1) {
-          float f[EPV];
-          Elt<T>::unpack(v[u], f);
-#pragma unroll
-          for (int e = 0; e < EPV; ++e) {
-            const float w = f[e] * av[e] + bv[e];
-            f[e] = act ? silu_f(w) : w;
-          }
-          *(u32x4*)(yp + (int64_t)j * ys) = Elt<T>::pack(f);
-        }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // One-pass GroupNorm32 (+SiLU) for SHORT slices (Tn <= 16 rows: the temporal-attention norm over the 16 frames of a pixel,
 // unet:489-490 -> nn.py:16-33): statistics pass + finalize + apply cost three launches and read the tensor twice; here a thread owns
@@ -564,17 +485,6 @@ __global__ __launch_bounds__(256) void gn_finalize_rec_kernel(const float* __res
   const int nrec = Tn / 64;
   const float* base = rec + ((int64_t)s * nrec * rec_ld + (int64_t)gi * qpg) * 2;
   const int total = nrec * qpg;
-  // what does not depend on the records is requested first (gamma / beta / FiLM of this thread's channel): one round trip, not two
-  float gm = 0.f, bt = 0.f, fsc = 1.f, fsh = 0.f;
-  if (tid < cpg) {
-    const int c = gi * cpg + tid;
-    gm = gamma[c];
-    bt = beta[c];
-    if (film) {
-      fsc = 1.f + film[(int64_t)s * film_ld + c];
-      fsh = film[(int64_t)s * film_ld + C + c];
-    }
-  }
   double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < total; i += 1024) {
 #pragma unroll
@@ -609,11 +519,13 @@ __global__ __launch_bounds__(256) void gn_finalize_rec_kernel(const float* __res
   __syncthreads();
   if (tid < cpg) {
     const int c = gi * cpg + tid;
-    float av = s_mr[1] * gm;
-    float bv = bt - s_mr[0] * av;
+    float av = s_mr[1] * gamma[c];
+    float bv = beta[c] - s_mr[0] * av;
     if (film) {
-      av *= fsc;
-      bv = bv * fsc + fsh;
+      const float sc = 1.f + film[(int64_t)s * film_ld + c];
+      const float sh = film[(int64_t)s * film_ld + C + c];
+      av *= sc;
+      bv = bv * sc + sh;
     }
     a_out[(int64_t)s * C + c] = av;
     b_out[(int64_t)s * C + c] = bv;
@@ -652,27 +564,6 @@ extern "C" int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int6
   else
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, g, a, b, act, R);
   return mmd_check_launch("gn_apply");
-}
-
-// mmd_gn_apply for S contiguous slices of Tn rows with the affine taken from the producers' records (include/mmd.h: mmd_gn_rec).
-extern "C" int mmd_gn_apply_rec(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn,
-                                const mmd_gn_rec* src, int act, void* stream) {
-  int rc = check_geom("gn_apply_rec", dtype, C, S, Tn, 1);
-  if (rc) return rc;
-  MMD_REQUIRE(x && y && src && src->rec && src->gamma && src->beta && rows > 0, "gn_apply_rec: null pointer / empty");
-  MMD_REQUIRE(rows == (int64_t)S * Tn && Tn % 64 == 0 && C % (4 * GN_GROUPS) == 0 && src->rec_ld >= C / 4 && src->eps > 0.f &&
-                  (!src->film || src->film_ld >= 2 * C) && (uintptr_t)src->rec % 8 == 0,
-              "gn_apply_rec: S slices of Tn rows (a multiple of 64) must tile the rows, C %% 128 == 0 (groups of whole quads), rec_ld >= C / 4 "
-              "(got S=%d Tn=%d C=%d rows=%ld)", S, Tn, C, (long)rows);
-  // every block re-reads its slice's records: blocks of >= 64 rows (128 when the records of a slice pass 16 KB)
-  const int R = (int64_t)(Tn / 64) * C * 2 <= 16384 ? 64 : 128;
-  dim3 grid(cdiv(Tn, R), S);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == MMD_BF16)
-    hipLaunchKernelGGL(gn_apply_rec_kernel<__bf16>, grid, dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, S, Tn, *src, act, R);
-  else
-    hipLaunchKernelGGL(gn_apply_rec_kernel<float>, grid, dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, S, Tn, *src, act, R);
-  return mmd_check_launch("gn_apply_rec");
 }
 
 extern "C" int mmd_add_rowbias(int dtype, void* x, int64_t ld, int64_t rows, int C, int64_t rows_per_sample, const float* e,

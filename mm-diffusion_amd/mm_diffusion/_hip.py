@@ -24,12 +24,6 @@ class GnTail(C.Structure):
                 ("film_ld", C.c_longlong), ("eps", f32), ("a_out", vp), ("b_out", vp)]
 
 
-class GnRec(C.Structure):
-    """include/mmd.h: mmd_gn_rec - the record source of a GroupNorm whose affine the CONSUMER kernel finalises in its prologue.
-    Read (copied into the kernel arguments) at call time."""
-    _fields_ = [("rec", vp), ("rec_ld", C.c_longlong), ("gamma", vp), ("beta", vp), ("film", vp), ("film_ld", C.c_longlong), ("eps", f32)]
-
-
 _PROTOS = {
     "mmd_version": (C.c_int, []),
     "mmd_last_error": (C.c_char_p, []),
@@ -58,8 +52,6 @@ _PROTOS = {
     "mmd_gn_conv1x1": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "mmd_conv_gemm_stats": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp, i64, vp]),
     "mmd_gn_conv1x1_stats": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
-    "mmd_gn_apply_rec": (i32, [i32, vp, i64, vp, i64, i64, i32, i32, i32, C.POINTER(GnRec), i32, vp]),
-    "mmd_gn_conv1x1_rec": (i32, [i32, vp, i64, C.POINTER(GnRec), i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]),
     "mmd_gn_conv_gemm": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_vconv2d1d_weight_bytes": (i64, [i32]),
     "mmd_vconv2d1d_pack": (i32, [vp, vp, vp, i32, i32, vp]),

@@ -302,26 +302,11 @@ class UNetEngine:
             # short slices (the temporal-attention norm: 16 frames of a pixel): one launch, one read of the tensor
             y = self._alloc(x.shape[0], C) if out is None else out
             return ops.gn_small(x, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), geom, act=act, out=y)
-        src = self._gn_rec_src(x, prefix, geom, film)
-        y = self._alloc(x.shape[0], C) if out is None else out
-        if src is not None:                         # few records per slice: the apply pass finalises them itself (no finalize launch)
-            return ops.gn_apply_rec(x, src, geom, act=act, out=y)
         a, b = self._gn_affine(x, prefix, geom, film)
+        y = self._alloc(x.shape[0], C) if out is None else out
         ops.gn_apply(x, a, b, geom, act=act, out=y)
         self._release(a, b)
         return y
-
-    def _gn_rec_src(self, x, prefix, geom, film):
-        """The record source of a GroupNorm over x when its CONSUMER should finalise it (ops.gn_rec_ok: contiguous slices with few
-        records), else None: the finalize launch / the statistics pass (_gn_affine)."""
-        if self.tail_enabled:
-            return None
-        rec = self._rec_ready(x, geom)
-        if rec is None or not ops.gn_rec_ok(rec, geom):
-            return None
-        src = ops.RecAffine(rec, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), film)
-        self.keep.append(src)
-        return src
 
     def _gn_affine(self, x, prefix, geom, film):
         """Fused per-(slice, channel) affine of GroupNorm32(+FiLM): from the producers' epilogue statistics when x has them, else
@@ -356,13 +341,9 @@ class UNetEngine:
             y = self._pw(n1, wkey, bkey, residual=residual, out=out)
             self._release(n1)
             return y
-        y = self._alloc(x.shape[0], Cout) if out is None else out
-        skw = self._stats_kw(y)
-        src = self._gn_rec_src(x, gn_prefix, geom, film) if ops.strip_tile_pinned(x, Cout, stats=skw.get("stats"), geom=geom) else None
-        if src is not None:                         # the strip GEMM finalises the norm in its prologue (no finalize launch)
-            return ops.gn_conv1x1_rec(x, src, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, stats=skw.get("stats"))
         a, b = self._gn_affine(x, gn_prefix, geom, film)
-        ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, **skw)
+        y = self._alloc(x.shape[0], Cout) if out is None else out
+        ops.gn_conv1x1(x, a, b, geom, act, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, **self._stats_kw(y))
         self._release(a, b)
         return y
 

@@ -157,78 +157,6 @@ def gn_apply(x, a, b, geom: Geom, act=True, out=None):
     return out
 
 
-# Finalize in the consumer (include/mmd.h: mmd_gn_rec): where a slice has few records, the kernel that APPLIES the norm (gn_apply_rec, the
-# row-strip GEMM with fused GroupNorm) turns them into the affine in its prologue and the mmd_gn_finalize_stats launch - a 7 us link
-# of the dependency chain - disappears.  Every block re-reads its slice's records, so the rule is a byte bound on one slice's records;
-# like every kernel choice here it is a function of the layer's geometry only.  MMD_GN_REC=0: always the finalize launch (A/B).
-_GN_REC = os.environ.get("MMD_GN_REC", "1") != "0"
-GN_REC_MAX_BYTES = int(os.environ.get("MMD_GN_REC_MAX_BYTES", str(64 * 1024)))
-GN_REC_MAX_ROWS = int(os.environ.get("MMD_GN_REC_MAX_ROWS", str(16384)))
-
-
-class RecAffine:
-    """The record source of one GroupNorm instance: rec = fp32 view [rows / 64, C / 4, 2] over exactly the normalised channels."""
-    __slots__ = ("rec", "gamma", "beta", "film", "struct", "C")
-
-    def __init__(self, rec, gamma, beta, film=None):
-        self.rec, self.gamma, self.beta, self.film = rec, gamma, beta, film
-        self.C = rec.shape[1] * 4
-        if rec.dtype != torch.float32 or rec.stride(1) != 2 or rec.stride(2) != 1 or self.C % 128:
-            raise H.MMDError(f"RecAffine: expected an fp32 [rows/64, C/4, 2] record view over a multiple of 128 channels, got {tuple(rec.shape)}")
-        st = H.GnRec()
-        st.rec, st.rec_ld = rec.data_ptr(), rec.stride(0) // 2
-        st.gamma, st.beta = gamma.data_ptr(), beta.data_ptr()
-        st.film, st.film_ld = (None, 0) if film is None else (film.data_ptr(), film.stride(0))
-        st.eps = GN_EPS
-        self.struct = st
-
-
-def _rec_geom_ok(rec, geom: Geom):
-    return (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn % 64 == 0
-            and rec.shape[0] * 64 == geom.S * geom.Tn)
-
-
-def gn_rec_ok(rec, geom: Geom):
-    """Whether the consumer should finalise this norm itself: contiguous slices of whole records, one slice's records within the bound."""
-    return (_GN_REC and rec is not None and _rec_geom_ok(rec, geom) and (geom.Tn // 64) * rec.shape[1] * 8 <= GN_REC_MAX_BYTES
-            and geom.S * geom.Tn <= GN_REC_MAX_ROWS)
-
-
-def gn_apply_rec(x, src: RecAffine, geom: Geom, act=True, out=None):
-    """gn_finalize_stats + gn_apply in one launch (include/mmd.h: mmd_gn_apply_rec)."""
-    import ctypes
-    _chk2d(x)
-    out = alloc(x.shape, dtype=x.dtype, device=x.device) if out is None else out
-    _chk2d(out)
-    if x.shape[1] != src.C or x.shape[0] != geom.S * geom.Tn or not _rec_geom_ok(src.rec, geom):
-        raise H.MMDError(f"gn_apply_rec: records over {src.C} channels / geometry do not match x {tuple(x.shape)}")
-    _dispatch("mmd_gn_apply_rec", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], geom.S, geom.Tn,
-              ctypes.pointer(src.struct), 1 if act else 0,
-              meta=(f"gn_apply_rec[S={geom.S},Tn={geom.Tn},C={src.C}]", 0, 2 * x.shape[0] * x.shape[1] * x.element_size()))
-    return out
-
-
-def gn_conv1x1_rec(x, src: RecAffine, geom: Geom, act, w, bias, residual=None, out=None, stats=None):
-    """gn_finalize_stats + gn_conv1x1 (row-strip main loop) in one launch (include/mmd.h: mmd_gn_conv1x1_rec)."""
-    import ctypes
-    _chk2d(x)
-    M, Cin = x.shape
-    Cout = w.shape[0]
-    if w.dtype != x.dtype or w.shape[1] != Cin or not w.is_contiguous() or Cin != src.C:
-        raise H.MMDError(f"gn_conv1x1_rec: weight {tuple(w.shape)} {w.dtype} / records over {src.C} channels do not match input {tuple(x.shape)} {x.dtype}")
-    if not strip_tile_ok(x, Cout, stats=stats, geom=geom) or not _rec_geom_ok(src.rec, geom):
-        raise H.MMDError("gn_conv1x1_rec: the row-strip kernel cannot take this launch (bf16, Cin in {128, 256, 384, 512}, slices >= one strip)")
-    out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
-    _chk2d(out)
-    es = x.element_size()
-    sp, sld = (None, 0) if stats is None else _stats_args(stats, M, Cout)
-    nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
-    _dispatch("mmd_gn_conv1x1_rec", H.dt_of(x), x.data_ptr(), x.stride(0), ctypes.pointer(src.struct), 1 if act else 0, geom.S, geom.Tn,
-              w.data_ptr(), H.ptr(bias), H.ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0),
-              M, Cout, Cin, sp, sld, meta=(f"gn_conv1x1<bf16,strip,rec>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes))
-    return out
-
-
 def zero(t):
     """hipMemsetAsync(0) of a device tensor on the launch stream (a memset node in a captured plan): the once-per-forward reset of the
     GroupNorm tail accumulators and counters."""
