@@ -89,6 +89,7 @@ class UNetEngine:
         # the fused VideoConv 2d+1d launch (ops.vconv_fused_ok) writes quad RECORDS, not tails: with the tail experiment on, the layer
         # keeps its two-launch form
         self._vconv_fused = dtype == torch.bfloat16 and not self.tail_enabled
+        self._tattn_fused = dtype == torch.bfloat16 and not self.tail_enabled
         self.tail_max = (1 << 62) if tmode == "all" else int(os.environ.get("MMD_GN_TAIL_MAX", str(1 << 21)))
         self._tails = {}              # buffer storage -> entry (slice geometry, accumulator offset, producer structs)
         self._tail_structs = []       # every GnTail handed to a producer launch: (struct, entry)
@@ -364,6 +365,12 @@ class UNetEngine:
             geom = Geom.temporal(N, F, Hh * Hh)
         else:
             geom = Geom.per_sample(N, rows // N)
+        if kind == "temporal" and self._tattn_fused and ops.tattn_fused_ok(x, heads, N, F, Hh * Hh):
+            # the whole block in one launch: norm over a pixel's frames, qkv, attention, proj_out + residual (mmd_tattn_block)
+            wf = self._packed("tattn", prefix, lambda: ops.tattn_pack(self._gemm_w(prefix + ".qkv.weight"), self._gemm_w(prefix + ".proj_out.weight")))
+            return ops.tattn_block(x, wf, self._f32(prefix + ".qkv.bias"), self._f32(prefix + ".proj_out.bias"),
+                                   self._f32(prefix + ".norm.GroupNorm.weight"), self._f32(prefix + ".norm.GroupNorm.bias"), heads, N, F, Hh * Hh,
+                                   out=out, stats=self._stats_for(out, perm_unit=rows // N))
         qkv = self._gn_pw(x, prefix + ".norm", geom, False, prefix + ".qkv.weight", prefix + ".qkv.bias")
         att = self._alloc(rows, C)
         if kind == "temporal":

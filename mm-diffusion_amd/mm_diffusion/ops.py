@@ -584,6 +584,53 @@ def vconv2d1d(x, wf, bias_s, bias_t, N, F, Hh, Ww, a=None, b=None, geom=None, ac
     return out
 
 
+# The temporal-attention block in one launch (include/mmd.h: mmd_tattn_block): GroupNorm over a pixel's frames, qkv, attention over the
+# frames, proj_out and the residual - instead of gn_small + qkv GEMM + attn_small + proj_out GEMM.  Built for the ds2 level of the
+# headline model (256 channels, 4 heads, 16 frames); like every kernel choice it depends on the layer's geometry only.
+# MMD_TATTN_FUSED=0: the four-launch path (A/B).
+_TATTN_FUSED = os.environ.get("MMD_TATTN_FUSED", "1") != "0"
+
+
+def tattn_shape_ok(x, heads, N, F, HW):
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and heads == 4 and F == 16 and HW % 16 == 0
+            and x.shape[0] == N * F * HW and x.stride(1) == 1 and x.stride(0) % 8 == 0)
+
+
+def tattn_fused_ok(x, heads, N, F, HW):
+    return _TATTN_FUSED and tattn_shape_ok(x, heads, N, F, HW)
+
+
+def tattn_pack(wqkv, wproj):
+    """qkv weight [3 C, C] and proj_out weight [C, C] (bf16, contiguous GEMM matrices) -> the kernel's weight image (mmd_tattn_pack)."""
+    H.require_cuda(wqkv, wproj)
+    if (wqkv.dtype != torch.bfloat16 or wproj.dtype != torch.bfloat16 or tuple(wqkv.shape) != (768, 256) or tuple(wproj.shape) != (256, 256)
+            or not wqkv.is_contiguous() or not wproj.is_contiguous()):
+        raise H.MMDError(f"tattn_pack: expected contiguous bf16 [768, 256] / [256, 256], got {tuple(wqkv.shape)} / {tuple(wproj.shape)}")
+    out = torch.empty(H.lib().mmd_tattn_weight_bytes() // 2, dtype=torch.bfloat16, device=wqkv.device)
+    H.call("mmd_tattn_pack", wqkv.data_ptr(), wproj.data_ptr(), out.data_ptr(), H.stream_handle())
+    return out
+
+
+def tattn_block(x, wf, bias_qkv, bias_proj, gamma, beta, heads, N, F, HW, out=None, stats=None):
+    """x [N*F*HW, 256] bf16 -> x + proj_out(temporal attention(qkv(GroupNorm32(x)))) (include/mmd.h: mmd_tattn_block).  stats: the
+    output's record view [M / 64, 64, 2] (records in the kernel's own row order inside a sample)."""
+    _chk2d(x)
+    M, C = x.shape
+    if not tattn_shape_ok(x, heads, N, F, HW):
+        raise H.MMDError(f"tattn_block: unsupported launch (x {tuple(x.shape)} {x.dtype}, heads={heads} N={N} F={F} HW={HW})")
+    out = alloc(M, C, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    if out.data_ptr() == x.data_ptr():
+        raise H.MMDError("tattn_block: in-place is not supported")
+    sp, sld = (None, 0) if stats is None else _stats_args(stats, M, C)
+    flops = 2 * M * C * 4 * C + 4 * M * F * C
+    nbytes = 2 * (3 * M * C) + 2 * 4 * C * C
+    _dispatch("mmd_tattn_block", x.data_ptr(), x.stride(0), wf.data_ptr(), bias_qkv.data_ptr(), bias_proj.data_ptr(), gamma.data_ptr(),
+              beta.data_ptr(), GN_EPS, out.data_ptr(), out.stride(0), N, F, HW, C, heads, sp, sld,
+              meta=(f"tattn_block<bf16>[M={M},C={C}]", flops, nbytes))
+    return out
+
+
 def attn(q, kv, out, heads, ch, nb, G, q_rows_per_batch, q_per_group, k_rows_per_batch, k_per_group, win,
          q_off=0, k_off=None, v_off=None, shift_dev=None, impl=0):
     """See include/mmd.h: mmd_attn_fwd.  q/kv are qkv GEMM outputs [rows, 3C]; out [q rows, C]."""

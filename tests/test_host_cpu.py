@@ -385,3 +385,14 @@ def test_noise_schedule_vp_matches_reference_fixture():
         np.testing.assert_allclose(inv.numpy(), g[f"{tag}_inv"], rtol=2e-7, atol=1e-9, err_msg=f"{tag} inverse_lambda")
     with pytest.raises(ValueError):
         NoiseScheduleVP("quadratic")
+
+
+def test_tattn_register_model():
+    """tools/tattn_model.py: the lane-level model of the fused temporal-attention kernel's register algebra (accumulators packed straight
+    into the next MFMA's operands, v^T by swapping the operands, the K-permuted proj_out weight) reproduces the block's math."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tattn_model.py")
+    spec = importlib.util.spec_from_file_location("tattn_model", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check(seed=1) < 1e-12

@@ -1,0 +1,175 @@
+"""The fused temporal-attention block (include/mmd.h: mmd_tattn_block; mmd_tattn.hip) through the C-ABI.
+
+One launch for  y = x + proj_out(attention over the 16 frames of a pixel(qkv(GroupNorm32(x))))  -
+/root/reference/mm_diffusion/multimodal_unet.py:246-287 as used at :485-493.  Checked against (1) a float64 torch restatement of those
+lines (tolerance of the bf16 path), (2) the four-launch path it replaces (gn_small, qkv GEMM, attn_small, proj_out GEMM + residual -
+each pinned against torch / the oracle elsewhere; same rounding points, so close to the last bit), (3) its own statistics records
+against the stored output, (4) bitwise repeatability and batch invariance."""
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+C, HEADS, F = 256, 4, 16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from mm_diffusion import ops as o
+    return o
+
+
+def _case(N, HW, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    M = N * F * HW
+    # per-pixel offsets and scales so that the per-(pixel, group) moments differ
+    x = torch.randn(N, F, HW, C, device="cuda", generator=g)
+    x = x * (0.5 + torch.rand(N, 1, HW, 1, device="cuda", generator=g)) + 0.5 * torch.randn(N, 1, HW, C, device="cuda", generator=g)
+    x = x.reshape(M, C).to(BF)
+    wqkv = (torch.randn(3 * C, C, device="cuda", generator=g) * C ** -0.5).to(BF)
+    wproj = (torch.randn(C, C, device="cuda", generator=g) * C ** -0.5).to(BF)
+    bqkv = 0.3 * torch.randn(3 * C, device="cuda", generator=g)
+    bproj = 0.3 * torch.randn(C, device="cuda", generator=g)
+    gamma = 1 + 0.2 * torch.randn(C, device="cuda", generator=g)
+    beta = 0.2 * torch.randn(C, device="cuda", generator=g)
+    return x, wqkv, wproj, bqkv, bproj, gamma, beta
+
+
+def _torch_ref(x, wqkv, wproj, bqkv, bproj, gamma, beta, N, HW, eps):
+    """unet:246-287 on sequences (n, pixel) x frames, float64."""
+    xd = x.double().view(N, F, HW, C)
+    g = xd.view(N, F, HW, 32, C // 32)
+    mean = g.mean(dim=(1, 4), keepdim=True)
+    var = g.var(dim=(1, 4), unbiased=False, keepdim=True)
+    h = ((g - mean) / torch.sqrt(var + eps)).view(N, F, HW, C) * gamma.double() + beta.double()
+    qkv = h @ wqkv.double().t() + bqkv.double()                              # [N, F, HW, 3C]
+    ch = C // HEADS
+    q, k, v = (t.view(N, F, HW, HEADS, ch).permute(0, 2, 3, 1, 4) for t in qkv.split(C, dim=-1))      # [N, HW, heads, F, ch]
+    w = torch.softmax((q @ k.transpose(-1, -2)) * ch ** -0.5, dim=-1)
+    a = (w @ v).permute(0, 3, 1, 2, 4).reshape(N, F, HW, C)
+    return (xd + a @ wproj.double().t() + bproj.double()).view(N * F * HW, C)
+
+
+def _four_launch(ops, x, wqkv, wproj, bqkv, bproj, gamma, beta, N, HW):
+    geom = ops.Geom.temporal(N, F, HW)
+    n1 = ops.gn_small(x, gamma, beta, geom, act=False)
+    qkv = ops.conv_gemm(n1, wqkv, bqkv)
+    att = torch.empty_like(x)
+    ops.attn_small(qkv, att, C, HEADS, geom)
+    return ops.conv_gemm(att, wproj, bproj, residual=x)
+
+
+@pytest.mark.parametrize("N,HW", [(1, 16), (2, 64), (1, 1024), (3, 48)])
+def test_tattn_block_vs_torch_and_the_four_launch_path(ops, N, HW):
+    x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(N, HW, 100 * N + HW)
+    wf = ops.tattn_pack(wqkv, wproj)
+    y = torch.full_like(x, float("nan"))
+    ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, HEADS, N, F, HW, out=y)
+    assert torch.isfinite(y.float()).all()
+    ref = _torch_ref(x, wqkv, wproj, bqkv, bproj, gamma, beta, N, HW, ops.GN_EPS)
+    assert rel_l2(y.double().cpu(), ref.cpu().numpy()) < 1e-2
+    y4 = _four_launch(ops, x, wqkv, wproj, bqkv, bproj, gamma, beta, N, HW)
+    # the attention branch alone (the residual dominates y): same rounding points, different summation orders
+    d_fused, d_four = y.double() - x.double(), y4.double() - x.double()
+    assert rel_l2(d_fused.cpu(), d_four.cpu().numpy()) < 1.5e-2
+    assert rel_l2(y.double().cpu(), y4.double().cpu().numpy()) < 4e-3
+    # and the fused result is at least as close to float64 as the four-launch one (within 20 %)
+    e_fused = rel_l2(d_fused.cpu(), (ref - x.double()).cpu().numpy())
+    e_four = rel_l2(d_four.cpu(), (ref - x.double()).cpu().numpy())
+    assert e_fused < 1.2 * e_four + 1e-3, (e_fused, e_four)
+
+
+def test_tattn_statistics_records(ops):
+    N, HW = 2, 64
+    x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(N, HW, 7)
+    wf = ops.tattn_pack(wqkv, wproj)
+    M = N * F * HW
+    rec = torch.full((M // 64, C // 4, 2), float("nan"), device="cuda")
+    y = ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, HEADS, N, F, HW, stats=rec)
+    y0 = ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, HEADS, N, F, HW)
+    assert torch.equal(y, y0)                               # the statistics epilogue does not touch the output
+    # record n * HW / 4 + (pixel >> 2): the 16 frames of 4 consecutive pixels
+    v = y.double().view(N, F, HW // 4, 4, C // 4, 4)
+    want = torch.stack([v.sum(dim=(1, 3, 5)), (v * v).sum(dim=(1, 3, 5))], dim=-1).view(M // 64, C // 4, 2)
+    assert torch.isfinite(rec).all()
+    assert (rec.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    # a per-sample GroupNorm finalised from them = the norm of y
+    g2, b2 = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    geom = ops.Geom.per_sample(N, F * HW)
+    a, b = ops.gn_finalize_stats(rec, g2, b2, geom)
+    grp = y.double().view(N, F * HW, 32, C // 32)
+    mean, var = grp.mean(dim=(1, 3)), grp.var(dim=(1, 3), unbiased=False)
+    rstd = 1 / torch.sqrt(var + ops.GN_EPS)
+    assert (a.double().view(N, 32, -1)[:, :, 0] - rstd).abs().max().item() <= 1e-4 * rstd.abs().max().item()
+    assert (b.double().view(N, 32, -1)[:, :, 0] + mean * rstd).abs().max().item() <= 1e-4 * (mean * rstd).abs().max().item() + 1e-5
+
+
+def test_tattn_repeatable_and_batch_invariant(ops):
+    N, HW = 2, 256
+    x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(N, HW, 11)
+    wf = ops.tattn_pack(wqkv, wproj)
+    y = ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, HEADS, N, F, HW).clone()
+    for _ in range(5):
+        assert torch.equal(y, ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, HEADS, N, F, HW))
+    M1 = F * HW
+    for n in range(N):
+        y1 = ops.tattn_block(x[n * M1:(n + 1) * M1], wf, bqkv, bproj, gamma, beta, HEADS, 1, F, HW)
+        assert torch.equal(y1, y[n * M1:(n + 1) * M1])
+    # a strided view of a wider buffer in and out (the engine's skip-concat buffers)
+    wide_in = torch.zeros(N * M1, 384, device="cuda", dtype=BF)
+    wide_in[:, 64:320] = x
+    wide_out = torch.zeros(N * M1, 512, device="cuda", dtype=BF)
+    ops.tattn_block(wide_in[:, 64:320], wf, bqkv, bproj, gamma, beta, HEADS, N, F, HW, out=wide_out[:, 256:])
+    assert torch.equal(wide_out[:, 256:], y) and not wide_out[:, :256].any()
+
+
+def test_tattn_rejects_unsupported(ops):
+    H = ops.H
+    x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(1, 16, 3)
+    wf = ops.tattn_pack(wqkv, wproj)
+    with pytest.raises(H.MMDError):
+        ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, 8, 1, F, 16)                    # 8 heads
+    with pytest.raises(H.MMDError):
+        ops.tattn_block(x[:8 * 16], wf, bqkv, bproj, gamma, beta, HEADS, 1, 8, 16)       # 8 frames
+    with pytest.raises(H.MMDError):
+        ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, HEADS, 1, F, 16, out=x)         # in place
+    with pytest.raises(H.MMDError):
+        ops.tattn_block(x[:, :128], wf, bqkv, bproj, gamma, beta, HEADS, 1, F, 16)       # 128 channels
+    with pytest.raises(H.MMDError):
+        ops.tattn_pack(wqkv[:, :128].contiguous(), wproj)
+    with pytest.raises(H.MMDError):                                                       # HW % 16 (straight through the C-ABI)
+        H.call("mmd_tattn_block", x.data_ptr(), 256, wf.data_ptr(), bqkv.data_ptr(), bproj.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+               1e-5, torch.empty_like(x).data_ptr(), 256, 1, 16, 24, 256, 4, None, 0, H.stream_handle())
+
+
+def test_engine_plan_uses_the_fused_temporal_attention(monkeypatch):
+    """The headline architecture (batch 1) with and without MMD_TATTN_FUSED: the default plan carries mmd_tattn_block at the ds2 level
+    and three launches fewer per block.  Two bf16 plans of this depth differ by ~1e-2 whatever the reason (synthetic weights amplify
+    rounding noise), so each is measured against the fp32 engine: the fused plan must not be further from it than the unfused one."""
+    from helpers import flags, inputs
+    from mm_diffusion import multimodal_script_util as msu, ops as o
+    from mm_diffusion.synth import synth_init_
+    import random
+    outs = []
+    for fp16, on in ((False, True), (True, True), (True, False)):
+        fl = flags("full", use_fp16=fp16)
+        monkeypatch.setattr(o, "_TATTN_FUSED", on)
+        model, _ = msu.create_model_and_diffusion(**fl)
+        synth_init_(model)
+        model.cuda().eval()
+        v, a = inputs(fl, 1, 3)
+        random.seed(5)
+        with torch.no_grad():
+            ov, oa = model(v.cuda(), a.cuda(), torch.tensor([417]).cuda())
+        names = [e[2] for e in next(iter(model._engines.values())).plan]
+        outs.append((ov.float().cpu(), oa.float().cpu(), names.count("mmd_tattn_block"), names.count("mmd_attn_small_fwd"), len(names)))
+        model.release_engines()
+    ref, fused, unfused = outs
+    assert ref[2] == 0 and fused[2] > 0 and unfused[2] == 0 and fused[3] == unfused[3] - fused[2], [o_[2:] for o_ in outs]
+    assert fused[4] <= unfused[4] - 3 * fused[2]
+    for k in (0, 1):
+        e_f, e_u = rel_l2(fused[k], ref[k].numpy()), rel_l2(unfused[k], ref[k].numpy())
+        assert e_f < 1.3 * e_u + 2e-3 and e_f < 3e-2, (k, e_f, e_u)
