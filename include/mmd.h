@@ -209,15 +209,20 @@ int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, const float* gn
  * mmd_gn_small + mmd_conv_gemm (qkv) + mmd_attn_small_fwd + mmd_conv_gemm (proj_out, residual): the normalised tensor, the qkv tensor
  * and the attention output never exist in HBM (q, k, v and the attention output are rounded to bf16 exactly where the unfused path
  * stores them).  bf16; X / Y rows (n, f, pixel) x C with row strides ldx / ldy, Y != X; built for F == 16, C == 256, heads == 4,
- * HW % 16 == 0.  Wf: the image of mmd_tattn_pack (mmd_tattn_weight_bytes() bytes) built from the qkv weight [3 C, C] (rows q | k | v,
+ * HW % 16 == 0.  Wf: the image of mmd_tattn_pack (mmd_tattn_weight_bytes(with_pre) bytes) built from the qkv weight [3 C, C] (rows q | k | v,
  * head h = rows h ch .. of each third) and the proj_out weight [C, C], both bf16 row-major.  bias_qkv [3 C], bias_proj / gamma / beta
  * [C] fp32.  stats (nullable): quad statistics records of Y for the GroupNorm that consumes it, one per 64 rows in THIS kernel's
  * row order inside a sample (record = 16-pixel group * 4 + wave), so only norms over whole samples may finalize from them. */
-int64_t mmd_tattn_weight_bytes(void);
-int mmd_tattn_pack(const void* Wqkv, const void* Wproj, void* out, void* stream);
-int mmd_tattn_block(const void* X, int64_t ldx, const void* Wf, const float* bias_qkv, const float* bias_proj, const float* gamma,
-                    const float* beta, float eps, void* Y, int64_t ldy, int N, int F, int HW, int C, int heads, float* stats,
-                    int64_t stats_ld, void* stream);
+int64_t mmd_tattn_weight_bytes(int with_pre);
+int mmd_tattn_pack(const void* Wpre, const void* Wqkv, const void* Wproj, void* out, void* stream);
+/* Optional front stage (A != NULL, Wf packed with Wpre [C, C]): the block's input is x = X + A Wpre^T + bias_pre, i.e. the proj_out
+ * 1x1 conv + residual of the SPATIAL attention block that precedes the temporal one (unet:485-490) rides in the same launch; MID
+ * [rows, C] (distinct from X, A, Y) receives x, rounded to bf16 like the tensor the unfused path stores, and is re-read as the
+ * residual of the last stage.  A == NULL: Wpre == NULL at pack time, MID / bias_pre unused. */
+int mmd_tattn_block(const void* X, int64_t ldx, const void* A, int64_t lda, void* MID, int64_t ldm, const void* Wf,
+                    const float* bias_pre, const float* bias_qkv, const float* bias_proj, const float* gamma, const float* beta,
+                    float eps, void* Y, int64_t ldy, int N, int F, int HW, int C, int heads, float* stats, int64_t stats_ld,
+                    void* stream);
 
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).

@@ -51,6 +51,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct TAttnParams {
   const char* X; int64_t ldx;
+  // optional front stage (A != nullptr): the block's input is x = X + pre(A) + bias_pre - the proj_out 1x1 conv + residual of the
+  // SPATIAL attention block that precedes the temporal one (unet:485-490) -, written to MID (bf16: what the unfused path stores) and
+  // re-read from there as the residual of the last stage
+  const char* A; int64_t lda;
+  char* MID; int64_t ldm;
+  const float* bpre;
   const char* Wf; int wf_bytes;
   const float* bqkv; const float* bproj;
   const float* gamma; const float* beta;
@@ -81,14 +87,16 @@ __device__ __forceinline__ float ta_pair_sum(float x) {
 
 // RF = 32-row fragments per wave (1 in every built instance; 2 = the 64-row waves of the measurement above), NW = waves per workgroup
 // (rows per workgroup = 32 RF NW), NST = weight stages in LDS.
-template <int RF, int NW, int NST>
+template <int RF, int NW, int NST, bool PRE>
 __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(const TAttnParams p) {
+  constexpr int CB = PRE ? 4 : 0;                         // chunks of the front stage
+  constexpr int NCH = TA_NCHUNK + CB;
   constexpr int NP = 32 / NW;                             // 1 KB DMA pieces per wave and chunk
   constexpr int PPB = 2 * RF * NW;                        // pixels per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;                                        // [3 stages][4 planes][64 rows][128 B]
   float* sB = (float*)(smem + NST * TA_STAGE_B);          // [q 256 | k 256 | v 256 | proj 256] biases
-  float* sG = sB + 1024;                                  // [gamma 256 | beta 256]
+  float* sG = sB + 1280;                                  // (sB[1024 ..]: bias of the front stage)  [gamma 256 | beta 256]
   float* sR = sG + 512;                                   // RF = 1: [2 parities][4 wave pairs][4 (a, j2)][2 halves][2 quads][2] half-record statistics
 
   const int tid = threadIdx.x;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
 #pragma unroll
   for (int f = 0; f < RF; ++f) {
     rowi[f] = ((int64_t)n * 16 + (l31 & 15)) * p.HW + pix0 + 2 * RF * wave + 2 * f + (l31 >> 4);
-    const char* ap = p.X + (rowi[f] * p.ldx + half * 8) * 2;
+    const char* ap = PRE ? p.A + (rowi[f] * p.lda + half * 8) * 2 : p.X + (rowi[f] * p.ldx + half * 8) * 2;
 #pragma unroll
     for (int cg = 0; cg < 16; ++cg) xa[f][cg] = *(const u32x4*)(ap + cg * 32);
   }
@@ -124,40 +132,10 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
     const float g0 = p.gamma[tid], g1 = p.beta[tid];
     sB[tid] = b0; sB[256 + tid] = b1; sB[512 + tid] = b2; sB[768 + tid] = b3;
     sG[tid] = g0; sG[256 + tid] = g1;
+    if (PRE) sB[1024 + tid] = p.bpre[tid];
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-
-  // ---- GroupNorm32 over (16 frames, 8 channels) of a pixel, two-pass like mmd_gn_small, applied in place
-#pragma unroll
-  for (int f = 0; f < RF; ++f)
-#pragma unroll
-    for (int cg = 0; cg < 16; ++cg) {
-      float x[8];
-      Elt<__bf16>::unpack(xa[f][cg], x);
-      float s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-      s = ta_row16_total(s);
-      const float mean = s * (1.f / 128.f);
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
-      q = ta_row16_total(q);
-      const float rstd = rsqrtf(q * (1.f / 128.f) + p.eps);
-      const float* gp = sG + cg * 16 + half * 8;
-#pragma unroll
-      for (int e = 0; e < 8; e += 4) {
-        const f32x4 g4 = *(const f32x4*)(gp + e), b4 = *(const f32x4*)(gp + 256 + e);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float av = rstd * g4[k];
-          const float bv = b4[k] - mean * av;
-          x[e + k] = x[e + k] * av + bv;
-        }
-      }
-      u32x4 y = Elt<__bf16>::pack(x);
-      asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));     // pin: keep the arithmetic here, not sunk into the MFMA loop
-      xa[f][cg] = y;
-    }
 
   // ---- chunk pipeline
   const int xsw = (l31 >> 1) & 7;
@@ -167,14 +145,14 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
   for (int c4 = 0; c4 < 4; ++c4) choff[c4] = ((2 * c4 + half) ^ xsw) * 16;
 
   auto chunk_top = [&](int c) __attribute__((always_inline)) {      // chunk c landed for every wave; the oldest stage is free again
-    if (NST == 3 && c <= 12) {                            // (one younger chunk of NP DMA instructions stays in flight)
+    if (NST == 3 && c <= NCH - 4) {                            // (one younger chunk of NP DMA instructions stays in flight)
       if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (c + NST - 1 < TA_NCHUNK) issue((c + NST - 1) % NST, c + NST - 1);
+    if (c + NST - 1 < NCH) issue((c + NST - 1) % NST, c + NST - 1);
   };
   // acc[a][f] (+)= the chunk's sub-tile a (32 weight rows) against fragment f of B over K = 256.  SWAP: A = rows, B = weights.
   // The weight fragments of K step st + 1 are requested BEFORE the MFMAs of step st (two register sets; sched_barrier pins the
@@ -210,13 +188,94 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
 
   u32x4 oo[RF][16];                                        // the attention output as B operands of the projection: [f][4 h + 2 a + s]
   f32x16 acc[2][RF];
+  const char* resid = PRE ? (const char*)p.MID : p.X;      // residual of the last stage
+  const int64_t ldres = PRE ? p.ldm : p.ldx;
+
+  // ---- front stage: x = X + pre(A) + bias: four chunks of 64 output channels; the epilogue's 8-consecutive-channel form IS the
+  // operand layout of x (k-step 4 j + 2 a + j2), so the rounded result goes to MID and straight into the fragments
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      chunk_top(j);
+      gemm(j % NST, xa, acc, false);
+      u32x4 rres[2][2][RF];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+          for (int f = 0; f < RF; ++f)
+            rres[a][j2][f] = *(const u32x4*)(p.X + (rowi[f] * p.ldx + 64 * j + 32 * a + 16 * j2 + 8 * half) * 2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+          const int col = 64 * j + 32 * a + 16 * j2 + 8 * half;
+          const f32x4 b0 = *(const f32x4*)(sB + 1024 + col), b1 = *(const f32x4*)(sB + 1024 + col + 4);
+#pragma unroll
+          for (int f = 0; f < RF; ++f) {
+            float v[8];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][f][8 * j2 + jj]), __float_as_uint(acc[a][f][8 * j2 + 4 + jj]),
+                                                               false, false);
+              v[jj] = __uint_as_float(sw[0]);
+              v[4 + jj] = __uint_as_float(sw[1]);
+            }
+            float rf[8];
+            Elt<__bf16>::unpack(rres[a][j2][f], rf);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { v[jj] = (v[jj] + b0[jj]) + rf[jj]; v[4 + jj] = (v[4 + jj] + b1[jj]) + rf[4 + jj]; }
+            const u32x4 pk = Elt<__bf16>::pack(v);
+            *(u32x4*)(p.MID + (rowi[f] * p.ldm + col) * 2) = pk;
+            oo[f][4 * j + 2 * a + j2] = pk;                  // (parked in the registers of the attention output, free until the first head)
+          }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+      for (int cg = 0; cg < 16; ++cg) xa[f][cg] = oo[f][cg];
+  }
+
+  // ---- GroupNorm32 over (16 frames, 8 channels) of a pixel, two-pass like mmd_gn_small, applied in place
+#pragma unroll
+  for (int f = 0; f < RF; ++f)
+#pragma unroll
+    for (int cg = 0; cg < 16; ++cg) {
+      float x[8];
+      Elt<__bf16>::unpack(xa[f][cg], x);
+      float s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+      s = ta_row16_total(s);
+      const float mean = s * (1.f / 128.f);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
+      q = ta_row16_total(q);
+      const float rstd = rsqrtf(q * (1.f / 128.f) + p.eps);
+      const float* gp = sG + cg * 16 + half * 8;
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) {
+        const f32x4 g4 = *(const f32x4*)(gp + e), b4 = *(const f32x4*)(gp + 256 + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float av = rstd * g4[k];
+          const float bv = b4[k] - mean * av;
+          x[e + k] = x[e + k] * av + bv;
+        }
+      }
+      u32x4 y = Elt<__bf16>::pack(x);
+      asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));     // pin: keep the arithmetic here, not sunk into the MFMA loop
+      xa[f][cg] = y;
+    }
+
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     u32x4 qo[RF][2][2], ko[RF][2][2], vo[RF][2][2];        // [f][a][s]
     // q and k: lane (row, half) holds channels 8 q + 4 half + j (i = 4 q + j); bias is a vector over i
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int c = 3 * h + t;
+      const int c = CB + 3 * h + t;
       chunk_top(c);
       gemm(c % NST, xa, acc, false);
 #pragma unroll
@@ -238,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
     }
     // v^T: operands swapped - lane (channel l31, half) holds keys 8 q + 4 half + j; bias is a lane scalar
     {
-      const int c = 3 * h + 2;
+      const int c = CB + 3 * h + 2;
       chunk_top(c);
       gemm(c % NST, xa, acc, true);
 #pragma unroll
@@ -330,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
   };
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int c = 12 + j;
+    const int c = CB + 12 + j;
     chunk_top(c);
     if (RF == 1 && j > 0) flush(j - 1);
     u32x4 rres[2][2][RF];                                  // [a][j2][f]: the residual (RF = 2: requested before the MFMAs; RF = 1 has
@@ -342,7 +401,7 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
         for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
           for (int f = 0; f < RF; ++f)
-            rres[a][j2][f] = *(const u32x4*)(p.X + (rowi[f] * p.ldx + 64 * j + 32 * a + 16 * j2 + 8 * half) * 2);
+            rres[a][j2][f] = *(const u32x4*)(resid + (rowi[f] * ldres + 64 * j + 32 * a + 16 * j2 + 8 * half) * 2);
     };
     if (RF == 2) load_res();
     gemm(c % NST, oo, acc, false);
@@ -410,17 +469,21 @@ __global__ __launch_bounds__(64 * NW, (NST == 2 ? 2 : 1)) void tattn_kernel(cons
   }
 }
 
-// Weight image of mmd_tattn_block: 16 chunks x [4 planes][64 rows][8 chunks of 16 B], chunk pc of a row holds logical chunk
-// pc ^ ((row >> 1) & 7).  Chunks 3 h + {0, 1, 2}: rows h 64 .. + 64 of the q / k / v third of the qkv weight [768, 256]; chunks
-// 12 + j: rows 64 j .. of proj_out [256, 256] with the 16 K columns of every 16-block in the order 8 (e >> 2) + 4 half + (e & 3).
-__global__ __launch_bounds__(256) void tattn_pack_kernel(const uint16_t* __restrict__ Wqkv, const uint16_t* __restrict__ Wproj, uint16_t* __restrict__ out) {
+// Weight image of mmd_tattn_block: (4 +) 16 chunks x [4 planes][64 rows][8 chunks of 16 B], chunk pc of a row holds logical chunk
+// pc ^ ((row >> 1) & 7).  With a front stage, first: rows 64 j .. of ITS weight [256, 256] (plain K order).  Then chunks 3 h +
+// {0, 1, 2}: rows h 64 .. + 64 of the q / k / v third of the qkv weight [768, 256]; then chunks 12 + j: rows 64 j .. of proj_out
+// [256, 256] with the 16 K columns of every 16-block in the order 8 (e >> 2) + 4 half + (e & 3).
+__global__ __launch_bounds__(256) void tattn_pack_kernel(const uint16_t* __restrict__ Wpre, const uint16_t* __restrict__ Wqkv,
+                                                         const uint16_t* __restrict__ Wproj, uint16_t* __restrict__ out, int nchunk) {
   const int o = blockIdx.x * 256 + threadIdx.x;            // one 16-byte chunk
-  if (o >= TA_NCHUNK * 2048) return;
-  const int c = o >> 11, r = o & 2047;
+  if (o >= nchunk * 2048) return;
+  const int cb = nchunk - TA_NCHUNK;
+  const int c = (o >> 11) - cb, r = o & 2047;              // c < 0: front stage
   const int pl = r >> 9, row = (r >> 3) & 63, pc = r & 7;
   const int lc = pc ^ ((row >> 1) & 7);
   const uint16_t* src;
-  if (c < 12) src = Wqkv + ((int64_t)((c % 3) * 256 + (c / 3) * 64 + row)) * 256;
+  if (c < 0) src = Wpre + ((int64_t)(64 * (c + cb) + row)) * 256;
+  else if (c < 12) src = Wqkv + ((int64_t)((c % 3) * 256 + (c / 3) * 64 + row)) * 256;
   else src = Wproj + ((int64_t)(64 * (c - 12) + row)) * 256;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -429,32 +492,42 @@ __global__ __launch_bounds__(256) void tattn_pack_kernel(const uint16_t* __restr
   }
 }
 
-extern "C" int64_t mmd_tattn_weight_bytes(void) { return (int64_t)TA_NCHUNK * TA_STAGE_B; }
+extern "C" int64_t mmd_tattn_weight_bytes(int with_pre) { return (int64_t)(TA_NCHUNK + (with_pre ? 4 : 0)) * TA_STAGE_B; }
 
-// Wqkv [768, 256] / Wproj [256, 256]: bf16, row-major (the 1x1 conv weights of SingleModalAtten.qkv / .proj_out, unet:263-266)
-extern "C" int mmd_tattn_pack(const void* Wqkv, const void* Wproj, void* out, void* stream) {
+// Wqkv [768, 256] / Wproj [256, 256] / Wpre [256, 256] (nullable: no front stage): bf16, row-major - the 1x1 conv weights of
+// SingleModalAtten.qkv / .proj_out of the temporal block (unet:263-266) and .proj_out of the spatial block in front of it
+extern "C" int mmd_tattn_pack(const void* Wpre, const void* Wqkv, const void* Wproj, void* out, void* stream) {
   MMD_REQUIRE(Wqkv && Wproj && out, "tattn_pack: null pointer");
-  hipLaunchKernelGGL(tattn_pack_kernel, dim3(TA_NCHUNK * 2048 / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Wqkv,
-                     (const uint16_t*)Wproj, (uint16_t*)out);
+  const int nchunk = TA_NCHUNK + (Wpre ? 4 : 0);
+  hipLaunchKernelGGL(tattn_pack_kernel, dim3(nchunk * 2048 / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Wpre,
+                     (const uint16_t*)Wqkv, (const uint16_t*)Wproj, (uint16_t*)out, nchunk);
   return mmd_check_launch("tattn_pack");
 }
 
 // X / Y: rows (n, f, pixel) x C bf16 (Y may not alias X: other workgroups' residual reads); Wf from mmd_tattn_pack; bias_qkv [768],
 // bias_proj / gamma / beta [256] fp32; stats (nullable): quad records of Y, one per 64 rows in THIS kernel's row order inside a sample
-// (16-pixel group x 4 waves), stats[rec * stats_ld + quad] = (sum, sum of squares).
-extern "C" int mmd_tattn_block(const void* X, int64_t ldx, const void* Wf, const float* bias_qkv, const float* bias_proj,
-                               const float* gamma, const float* beta, float eps, void* Y, int64_t ldy, int N, int F, int HW, int C,
-                               int heads, float* stats, int64_t stats_ld, void* stream) {
+// (the 16 frames of 4 consecutive pixels), stats[rec * stats_ld + quad] = (sum, sum of squares).
+// Front stage (A != NULL; Wf packed with Wpre): the block's input is x = X + A Wpre^T + bias_pre - the spatial attention block's
+// proj_out + residual - and MID [rows, C] receives it (scratch the kernel re-reads; also what the unfused path calls the spatial
+// block's output).
+extern "C" int mmd_tattn_block(const void* X, int64_t ldx, const void* A, int64_t lda, void* MID, int64_t ldm, const void* Wf,
+                               const float* bias_pre, const float* bias_qkv, const float* bias_proj, const float* gamma,
+                               const float* beta, float eps, void* Y, int64_t ldy, int N, int F, int HW, int C, int heads, float* stats,
+                               int64_t stats_ld, void* stream) {
   MMD_REQUIRE(X && Wf && bias_qkv && bias_proj && gamma && beta && Y, "tattn_block: null pointer");
   MMD_REQUIRE(F == 16 && C == 256 && heads == 4, "tattn_block: built for 16 frames, 256 channels, 4 heads (got F=%d C=%d heads=%d)", F, C, heads);
   MMD_REQUIRE(N > 0 && HW > 0 && HW % 16 == 0, "tattn_block: the pixels of a frame must be a multiple of 16 (N=%d HW=%d)", N, HW);
   MMD_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C && ((uintptr_t)X | (uintptr_t)Y | (uintptr_t)Wf) % 16 == 0,
               "tattn_block: 16-byte aligned rows");
   MMD_REQUIRE(X != Y, "tattn_block: in-place is not supported (the residual is re-read)");
+  MMD_REQUIRE(!A || (MID && bias_pre && lda % 8 == 0 && ldm % 8 == 0 && lda >= C && ldm >= C && ((uintptr_t)A | (uintptr_t)MID) % 16 == 0 &&
+                     MID != Y && MID != X && MID != A),
+              "tattn_block: the front stage needs A, a scratch MID (distinct from X, A and Y) and bias_pre, 16-byte aligned rows");
   MMD_REQUIRE(!stats || (stats_ld >= C / 4 && (uintptr_t)stats % 8 == 0), "tattn_block: statistics buffer");
   MMD_REQUIRE(eps > 0.f, "tattn_block: eps");
   TAttnParams p;
-  p.X = (const char*)X; p.ldx = ldx; p.Wf = (const char*)Wf; p.wf_bytes = TA_NCHUNK * TA_STAGE_B;
+  p.X = (const char*)X; p.ldx = ldx; p.A = (const char*)A; p.lda = lda; p.MID = (char*)MID; p.ldm = ldm; p.bpre = bias_pre;
+  p.Wf = (const char*)Wf; p.wf_bytes = (TA_NCHUNK + (A ? 4 : 0)) * TA_STAGE_B;
   p.bqkv = bias_qkv; p.bproj = bias_proj; p.gamma = gamma; p.beta = beta;
   p.Y = (char*)Y; p.ldy = ldy; p.N = N; p.HW = HW; p.eps = eps;
   p.sc = 1.44269504088896f * (1.0f / sqrtf(64.f));
@@ -462,17 +535,25 @@ extern "C" int mmd_tattn_block(const void* X, int64_t ldx, const void* Wf, const
   // MMD_TATTN_CFG (read once; A/B - the arithmetic per row is the same): 0 = 128-row workgroups of 4 waves, two per CU, two weight
   // stages (default); 1 = 256-row workgroups of 8 waves, three stages
   static const int cfg = [] { const char* e = getenv("MMD_TATTN_CFG"); return e ? atoi(e) : 0; }();
-  const size_t lds3 = 3 * (size_t)TA_STAGE_B + (1536 + 256) * sizeof(float), lds2 = 2 * (size_t)TA_STAGE_B + (1536 + 256) * sizeof(float);
+  constexpr size_t TAB = (1280 + 512 + 256) * sizeof(float);
+  const size_t lds3 = 3 * (size_t)TA_STAGE_B + TAB, lds2 = 2 * (size_t)TA_STAGE_B + TAB;
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)tattn_kernel<1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tattn_kernel<1, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipError_t e = hipFuncSetAttribute((const void*)tattn_kernel<1, 8, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tattn_kernel<1, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tattn_kernel<1, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tattn_kernel<1, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "tattn_block: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (cfg == 1) hipLaunchKernelGGL((tattn_kernel<1, 8, 3>), dim3(N * (HW / 16)), dim3(512), lds3, st, p);
-  else hipLaunchKernelGGL((tattn_kernel<1, 4, 2>), dim3(N * (HW / 8)), dim3(256), lds2, st, p);
+  if (cfg == 1) {
+    if (A) hipLaunchKernelGGL((tattn_kernel<1, 8, 3, true>), dim3(N * (HW / 16)), dim3(512), lds3, st, p);
+    else hipLaunchKernelGGL((tattn_kernel<1, 8, 3, false>), dim3(N * (HW / 16)), dim3(512), lds3, st, p);
+  } else {
+    if (A) hipLaunchKernelGGL((tattn_kernel<1, 4, 2, true>), dim3(N * (HW / 8)), dim3(256), lds2, st, p);
+    else hipLaunchKernelGGL((tattn_kernel<1, 4, 2, false>), dim3(N * (HW / 8)), dim3(256), lds2, st, p);
+  }
   return mmd_check_launch("tattn_block");
 }

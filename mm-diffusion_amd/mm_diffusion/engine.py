@@ -353,8 +353,10 @@ class UNetEngine:
         return ops.conv_gemm(x, self._gemm_w(wkey), self._f32(bkey), residual=residual, out=y, **self._stats_kw(y))
 
     # ------------------------------------------------------------------ blocks
-    def _self_attn(self, x, prefix, kind, Hh, out):
-        """SingleModalAtten on rows x [rows, C]: kind in {'spatial','temporal','audio'} (unet:246-287,485-493)."""
+    def _self_attn(self, x, prefix, kind, Hh, out, pre=None, no_proj=False):
+        """SingleModalAtten on rows x [rows, C]: kind in {'spatial','temporal','audio'} (unet:246-287,485-493).  no_proj: stop after the
+        attention and return its output (the caller fuses proj_out + residual into the next launch); pre = (att, spatial prefix): this
+        temporal block's input is x + proj_out_spatial(att) (the fused kernel's front stage)."""
         N, F, C = self.N, self.F, x.shape[1]
         heads = self.model.num_heads
         ch = C // heads
@@ -366,11 +368,22 @@ class UNetEngine:
         else:
             geom = Geom.per_sample(N, rows // N)
         if kind == "temporal" and self._tattn_fused and ops.tattn_fused_ok(x, heads, N, F, Hh * Hh):
-            # the whole block in one launch: norm over a pixel's frames, qkv, attention, proj_out + residual (mmd_tattn_block)
-            wf = self._packed("tattn", prefix, lambda: ops.tattn_pack(self._gemm_w(prefix + ".qkv.weight"), self._gemm_w(prefix + ".proj_out.weight")))
-            return ops.tattn_block(x, wf, self._f32(prefix + ".qkv.bias"), self._f32(prefix + ".proj_out.bias"),
-                                   self._f32(prefix + ".norm.GroupNorm.weight"), self._f32(prefix + ".norm.GroupNorm.bias"), heads, N, F, Hh * Hh,
-                                   out=out, stats=self._stats_for(out, perm_unit=rows // N))
+            # the whole block in one launch: norm over a pixel's frames, qkv, attention, proj_out + residual (mmd_tattn_block) - and,
+            # with `pre`, the spatial block's proj_out + residual in front of it
+            pk = None
+            if pre is not None:
+                att, sp = pre
+                mid = self._alloc(rows, C)
+                pk = (att, self._f32(sp + ".proj_out.bias"), mid)
+            wf = self._packed("tattn_pre" if pre is not None else "tattn", prefix, lambda: ops.tattn_pack(
+                self._gemm_w(prefix + ".qkv.weight"), self._gemm_w(prefix + ".proj_out.weight"),
+                wpre=self._gemm_w(pre[1] + ".proj_out.weight") if pre is not None else None))
+            ops.tattn_block(x, wf, self._f32(prefix + ".qkv.bias"), self._f32(prefix + ".proj_out.bias"),
+                            self._f32(prefix + ".norm.GroupNorm.weight"), self._f32(prefix + ".norm.GroupNorm.bias"), heads, N, F, Hh * Hh,
+                            out=out, stats=self._stats_for(out, perm_unit=rows // N), pre=pk)
+            if pk is not None:
+                self._release(pk[2])
+            return out
         qkv = self._gn_pw(x, prefix + ".norm", geom, False, prefix + ".qkv.weight", prefix + ".qkv.bias")
         att = self._alloc(rows, C)
         if kind == "temporal":
@@ -382,6 +395,8 @@ class UNetEngine:
             G = F if kind == "spatial" else 1
             ops.attn(qkv, qkv, att, heads, ch, N, G, G * T, T, G * T, T, 1)
         self._release(qkv)
+        if no_proj:
+            return att
         self._pw(att, prefix + ".proj_out.weight", prefix + ".proj_out.bias", residual=x, out=out)
         self._release(att)
         return out
@@ -475,7 +490,13 @@ class UNetEngine:
             if xs is not x:
                 self._release(xs)
             if attn_here:
-                if vid:
+                if vid and self._tattn_fused and ops._TATTN_PRE and ops.tattn_fused_ok(dest, self.model.num_heads, N, F, Ho * Ho):
+                    # spatial block up to its attention; its proj_out + residual ride in the fused temporal block's launch
+                    att = self._self_attn(dest, p + ".spatial_attention_block", "spatial", Ho, None, no_proj=True)
+                    fin = out if out is not None else self._alloc(rows_out, cout, stats=True, unit=rows_out // N)
+                    self._self_attn(dest, p + ".temporal_attention_block", "temporal", Ho, fin, pre=(att, p + ".spatial_attention_block"))
+                    self._release(att, dest)
+                elif vid:
                     mid = self._self_attn(dest, p + ".spatial_attention_block", "spatial", Ho, self._alloc(rows_out, cout))
                     self._release(dest)
                     fin = out if out is not None else self._alloc(rows_out, cout, stats=True, unit=rows_out // N)

@@ -589,6 +589,8 @@ def vconv2d1d(x, wf, bias_s, bias_t, N, F, Hh, Ww, a=None, b=None, geom=None, ac
 # headline model (256 channels, 4 heads, 16 frames); like every kernel choice it depends on the layer's geometry only.
 # MMD_TATTN_FUSED=0: the four-launch path (A/B).
 _TATTN_FUSED = os.environ.get("MMD_TATTN_FUSED", "1") != "0"
+# the spatial block's proj_out + residual as the front stage of the same launch (MMD_TATTN_PRE=0: its own strip GEMM; A/B)
+_TATTN_PRE = os.environ.get("MMD_TATTN_PRE", "1") != "0"
 
 
 def tattn_shape_ok(x, heads, N, F, HW):
@@ -600,20 +602,23 @@ def tattn_fused_ok(x, heads, N, F, HW):
     return _TATTN_FUSED and tattn_shape_ok(x, heads, N, F, HW)
 
 
-def tattn_pack(wqkv, wproj):
-    """qkv weight [3 C, C] and proj_out weight [C, C] (bf16, contiguous GEMM matrices) -> the kernel's weight image (mmd_tattn_pack)."""
+def tattn_pack(wqkv, wproj, wpre=None):
+    """qkv weight [3 C, C] and proj_out weight [C, C] of the temporal block - and, for the front stage, the proj_out weight [C, C] of the
+    spatial block before it - (bf16, contiguous GEMM matrices) -> the kernel's weight image (mmd_tattn_pack)."""
     H.require_cuda(wqkv, wproj)
-    if (wqkv.dtype != torch.bfloat16 or wproj.dtype != torch.bfloat16 or tuple(wqkv.shape) != (768, 256) or tuple(wproj.shape) != (256, 256)
-            or not wqkv.is_contiguous() or not wproj.is_contiguous()):
-        raise H.MMDError(f"tattn_pack: expected contiguous bf16 [768, 256] / [256, 256], got {tuple(wqkv.shape)} / {tuple(wproj.shape)}")
-    out = torch.empty(H.lib().mmd_tattn_weight_bytes() // 2, dtype=torch.bfloat16, device=wqkv.device)
-    H.call("mmd_tattn_pack", wqkv.data_ptr(), wproj.data_ptr(), out.data_ptr(), H.stream_handle())
+    mats = [(wqkv, (768, 256)), (wproj, (256, 256))] + ([(wpre, (256, 256))] if wpre is not None else [])
+    for w, shape in mats:
+        if w.dtype != torch.bfloat16 or tuple(w.shape) != shape or not w.is_contiguous():
+            raise H.MMDError(f"tattn_pack: expected contiguous bf16 {shape}, got {tuple(w.shape)} {w.dtype}")
+    out = torch.empty(H.lib().mmd_tattn_weight_bytes(0 if wpre is None else 1) // 2, dtype=torch.bfloat16, device=wqkv.device)
+    H.call("mmd_tattn_pack", H.ptr(wpre), wqkv.data_ptr(), wproj.data_ptr(), out.data_ptr(), H.stream_handle())
     return out
 
 
-def tattn_block(x, wf, bias_qkv, bias_proj, gamma, beta, heads, N, F, HW, out=None, stats=None):
+def tattn_block(x, wf, bias_qkv, bias_proj, gamma, beta, heads, N, F, HW, out=None, stats=None, pre=None):
     """x [N*F*HW, 256] bf16 -> x + proj_out(temporal attention(qkv(GroupNorm32(x)))) (include/mmd.h: mmd_tattn_block).  stats: the
-    output's record view [M / 64, 64, 2] (records in the kernel's own row order inside a sample)."""
+    output's record view [M / 64, 64, 2] (records in the kernel's own row order inside a sample).  pre = (att, bias_pre, mid): the
+    front stage - the block's input is x + att Wpre^T + bias_pre (wf packed with wpre), written to the scratch `mid`."""
     _chk2d(x)
     M, C = x.shape
     if not tattn_shape_ok(x, heads, N, F, HW):
@@ -622,12 +627,23 @@ def tattn_block(x, wf, bias_qkv, bias_proj, gamma, beta, heads, N, F, HW, out=No
     _chk2d(out)
     if out.data_ptr() == x.data_ptr():
         raise H.MMDError("tattn_block: in-place is not supported")
+    att = bpre = mid = None
+    if pre is not None:
+        att, bpre, mid = pre
+        _chk2d(att), _chk2d(mid)
+        if (att.shape != x.shape or mid.shape != x.shape or att.dtype != x.dtype or mid.dtype != x.dtype
+                or len({t.data_ptr() for t in (x, att, mid, out)}) != 4 or wf.numel() * 2 != H.lib().mmd_tattn_weight_bytes(1)):
+            raise H.MMDError("tattn_block: the front stage needs att / mid of x's shape, four distinct buffers and weights packed with wpre")
+    elif wf.numel() * 2 != H.lib().mmd_tattn_weight_bytes(0):
+        raise H.MMDError("tattn_block: weights packed with a front stage need pre=(att, bias_pre, mid)")
     sp, sld = (None, 0) if stats is None else _stats_args(stats, M, C)
-    flops = 2 * M * C * 4 * C + 4 * M * F * C
-    nbytes = 2 * (3 * M * C) + 2 * 4 * C * C
-    _dispatch("mmd_tattn_block", x.data_ptr(), x.stride(0), wf.data_ptr(), bias_qkv.data_ptr(), bias_proj.data_ptr(), gamma.data_ptr(),
+    npre = 0 if pre is None else 1
+    flops = 2 * M * C * (4 + npre) * C + 4 * M * F * C
+    nbytes = 2 * ((3 + 2 * npre) * M * C) + 2 * (4 + npre) * C * C
+    _dispatch("mmd_tattn_block", x.data_ptr(), x.stride(0), H.ptr(att), 0 if att is None else att.stride(0), H.ptr(mid),
+              0 if mid is None else mid.stride(0), wf.data_ptr(), H.ptr(bpre), bias_qkv.data_ptr(), bias_proj.data_ptr(), gamma.data_ptr(),
               beta.data_ptr(), GN_EPS, out.data_ptr(), out.stride(0), N, F, HW, C, heads, sp, sld,
-              meta=(f"tattn_block<bf16>[M={M},C={C}]", flops, nbytes))
+              meta=(f"tattn_block<bf16{',pre' if npre else ''}>[M={M},C={C}]", flops, nbytes))
     return out
 
 

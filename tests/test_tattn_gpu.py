@@ -82,6 +82,30 @@ def test_tattn_block_vs_torch_and_the_four_launch_path(ops, N, HW):
     assert e_fused < 1.2 * e_four + 1e-3, (e_fused, e_four)
 
 
+@pytest.mark.parametrize("N,HW", [(1, 16), (2, 256)])
+def test_tattn_front_stage_is_the_spatial_proj_out(ops, N, HW):
+    """pre = (att, bias, mid): the block's input is x + att Wpre^T + bias, i.e. the spatial block's proj_out 1x1 conv + residual in
+    front (unet:485-490).  Same K order, same epilogue arithmetic and the same bf16 rounding as the row-strip GEMM, then the same
+    kernel: `mid` and the output are BITWISE the two-launch sequence's."""
+    x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(N, HW, 9 * N + HW)
+    g = torch.Generator(device="cuda").manual_seed(HW)
+    att = torch.randn(x.shape, device="cuda", generator=g).to(BF)
+    wpre = (torch.randn(C, C, device="cuda", generator=g) * C ** -0.5).to(BF)
+    bpre = 0.3 * torch.randn(C, device="cuda", generator=g)
+    mid0 = ops.conv_gemm(att, wpre, bpre, residual=x)
+    y0 = ops.tattn_block(mid0, ops.tattn_pack(wqkv, wproj), bqkv, bproj, gamma, beta, HEADS, N, F, HW)
+    wf = ops.tattn_pack(wqkv, wproj, wpre=wpre)
+    M = x.shape[0]
+    rec0, rec1 = torch.zeros(M // 64, C // 4, 2, device="cuda"), torch.full((M // 64, C // 4, 2), float("nan"), device="cuda")
+    ops.tattn_block(mid0, ops.tattn_pack(wqkv, wproj), bqkv, bproj, gamma, beta, HEADS, N, F, HW, stats=rec0)
+    for _ in range(2):
+        mid1, y1 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, HEADS, N, F, HW, out=y1, stats=rec1, pre=(att, bpre, mid1))
+        assert torch.equal(mid0.view(torch.int16), mid1.view(torch.int16))
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+        assert torch.equal(rec0, rec1)
+
+
 def test_tattn_statistics_records(ops):
     N, HW = 2, 64
     x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(N, HW, 7)
@@ -141,8 +165,12 @@ def test_tattn_rejects_unsupported(ops):
     with pytest.raises(H.MMDError):
         ops.tattn_pack(wqkv[:, :128].contiguous(), wproj)
     with pytest.raises(H.MMDError):                                                       # HW % 16 (straight through the C-ABI)
-        H.call("mmd_tattn_block", x.data_ptr(), 256, wf.data_ptr(), bqkv.data_ptr(), bproj.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-               1e-5, torch.empty_like(x).data_ptr(), 256, 1, 16, 24, 256, 4, None, 0, H.stream_handle())
+        H.call("mmd_tattn_block", x.data_ptr(), 256, None, 0, None, 0, wf.data_ptr(), None, bqkv.data_ptr(), bproj.data_ptr(), gamma.data_ptr(),
+               beta.data_ptr(), 1e-5, torch.empty_like(x).data_ptr(), 256, 1, 16, 24, 256, 4, None, 0, H.stream_handle())
+    with pytest.raises(H.MMDError):                                                       # weights packed with a front stage, none given
+        ops.tattn_block(x, ops.tattn_pack(wqkv, wproj, wpre=wproj), bqkv, bproj, gamma, beta, HEADS, 1, F, 16)
+    with pytest.raises(H.MMDError):                                                       # the scratch aliases the input
+        ops.tattn_block(x, ops.tattn_pack(wqkv, wproj, wpre=wproj), bqkv, bproj, gamma, beta, HEADS, 1, F, 16, pre=(x.clone(), bproj, x))
 
 
 def test_engine_plan_uses_the_fused_temporal_attention(monkeypatch):
@@ -169,7 +197,7 @@ def test_engine_plan_uses_the_fused_temporal_attention(monkeypatch):
         model.release_engines()
     ref, fused, unfused = outs
     assert ref[2] == 0 and fused[2] > 0 and unfused[2] == 0 and fused[3] == unfused[3] - fused[2], [o_[2:] for o_ in outs]
-    assert fused[4] <= unfused[4] - 3 * fused[2]
+    assert fused[4] <= unfused[4] - 3 * fused[2]          # (4 per block with the spatial proj_out riding along, MMD_TATTN_PRE)
     for k in (0, 1):
         e_f, e_u = rel_l2(fused[k], ref[k].numpy()), rel_l2(unfused[k], ref[k].numpy())
         assert e_f < 1.3 * e_u + 2e-3 and e_f < 3e-2, (k, e_f, e_u)

@@ -55,14 +55,32 @@ def main():
         def fused():
             ops.tattn_block(x, wf, bqkv, bproj, gamma, beta, heads, N, F, HW, out=y1, stats=rec)
 
+        att_s = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
+        wpre, bpre = (torch.randn(C, C, device="cuda", generator=g) * C ** -0.5).to(torch.bfloat16), torch.randn(C, device="cuda", generator=g)
+        wf5 = ops.tattn_pack(wqkv, wproj, wpre=wpre)
+        mid = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+
+        def five():                     # the spatial block's proj_out + residual in front
+            ops.conv_gemm(att_s, wpre, bpre, residual=x, out=mid)
+            ops.gn_small(mid, gamma, beta, geom, act=False, out=n1)
+            ops.conv_gemm(n1, wqkv, bqkv, out=qkv)
+            ops.attn_small(qkv, att, C, heads, geom)
+            ops.conv_gemm(att, wproj, bproj, residual=mid, out=y0, stats=rec)
+
+        def fused_pre():
+            ops.tattn_block(x, wf5, bqkv, bproj, gamma, beta, heads, N, F, HW, out=y1, stats=rec, pre=(att_s, bpre, mid))
+
         four(); fused()
         err = float((y1.float() - y0.float()).norm() / y0.float().norm())
-        t4 = tf = 1e9
+        t4 = tf = t5 = tp = 1e9
         for _ in range(3):
             t4 = min(t4, timed(four))
             tf = min(tf, timed(fused))
+            t5 = min(t5, timed(five))
+            tp = min(tp, timed(fused_pre))
         flops = 2.0 * M * C * 4 * C + 4.0 * M * F * C
-        print(f"N={N} HW={HW:5d} M={M:6d} | four launches {t4:7.1f} us | fused {tf:7.1f} us  {flops / tf / 1e6:6.0f} TF/s  {3 * M * C * 2 / tf / 1e3:6.0f} GB/s (x + residual + y) | rel-L2 {err:.1e}")
+        print(f"N={N} HW={HW:5d} M={M:6d} | four launches {t4:7.1f} us | fused {tf:7.1f} us  {flops / tf / 1e6:6.0f} TF/s  {3 * M * C * 2 / tf / 1e3:6.0f} GB/s (x + residual + y) | rel-L2 {err:.1e}"
+              f" || with the spatial proj_out in front: five launches {t5:7.1f} us | fused {tp:7.1f} us")
 
 
 if __name__ == "__main__":
