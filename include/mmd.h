@@ -224,6 +224,19 @@ int mmd_tattn_block(const void* X, int64_t ldx, const void* A, int64_t lda, void
                     float eps, void* Y, int64_t ldy, int N, int F, int HW, int C, int heads, float* stats, int64_t stats_ld,
                     void* stream);
 
+/* The temporal half of VideoConv '2d+1d' (unet:83-99: the per-pixel k = 3 conv along the frames, after the per-frame 3x3 conv) with
+ * the activations stationary in registers (round 4): rows are gathered per pixel, the 16 frames of a pixel are the 16 lanes of a DPP
+ * row, and the operand of tap df is the x fragment shifted by df lanes (zeros shifted in = the conv's zero padding in time), so every
+ * activation row is loaded once instead of once per tap.  Bitwise equal to mmd_conv_gemm with the temporal taps.  bf16; X / Y rows
+ * (n, f, pixel) x Cin / Cout (Y != X); F == 16, Cin in {256, 384, 512}, Cout % 64 == 0 (<= 512), HW % 8 == 0.  Wf: the image of
+ * mmd_tconv_pack (mmd_tconv_weight_bytes(Cin, Cout) bytes) built from the packed GEMM matrix [Cout][3 * Cin] (K = tap * Cin + ci, taps
+ * df = -1, 0, +1) that mmd_conv_gemm takes.  stats (nullable): quad statistics records of Y, one per 64 rows in THIS kernel's row
+ * order inside a sample (record n HW / 4 + (pixel >> 2): the 16 frames of 4 consecutive pixels) - for norms over whole samples. */
+int64_t mmd_tconv_weight_bytes(int Cin, int Cout);
+int mmd_tconv_pack(const void* W, void* out, int Cin, int Cout, void* stream);
+int mmd_tconv(const void* X, int64_t ldx, const void* Wf, const float* bias, void* Y, int64_t ldy, int N, int F, int HW, int Cin,
+              int Cout, float* stats, int64_t stats_ld, void* stream);
+
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).
  * For batch n, group g (< G): queries = Q rows n*q_rows_per_batch + g*q_per_group + [0, q_per_group) (the last

@@ -53,6 +53,9 @@ _PROTOS = {
     "mmd_conv_gemm_stats": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp, i64, vp]),
     "mmd_gn_conv1x1_stats": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
     "mmd_gn_conv_gemm": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
+    "mmd_tconv_weight_bytes": (i64, [i32, i32]),
+    "mmd_tconv_pack": (i32, [vp, vp, i32, i32, vp]),
+    "mmd_tconv": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp]),
     "mmd_tattn_weight_bytes": (i64, [i32]),
     "mmd_tattn_pack": (i32, [vp, vp, vp, vp, vp]),
     "mmd_tattn_block": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp]),

@@ -90,6 +90,7 @@ class UNetEngine:
         # keeps its two-launch form
         self._vconv_fused = dtype == torch.bfloat16 and not self.tail_enabled
         self._tattn_fused = dtype == torch.bfloat16 and not self.tail_enabled
+        self._tconv = dtype == torch.bfloat16 and not self.tail_enabled
         self.tail_max = (1 << 62) if tmode == "all" else int(os.environ.get("MMD_GN_TAIL_MAX", str(1 << 21)))
         self._tails = {}              # buffer storage -> entry (slice geometry, accumulator offset, producer structs)
         self._tail_structs = []       # every GnTail handed to a producer launch: (struct, entry)
@@ -449,9 +450,15 @@ class UNetEngine:
                                        dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
                     self._release(t0)
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
-                ops.conv_gemm(t1, self._gemm_w(f"{p}.video_in_layers.2.video_conv_temporal.weight"),
-                              self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), **self._temporal(Hh),
-                              out=h, **self._stats_kw(h))
+                wtk = f"{p}.video_in_layers.2.video_conv_temporal.weight"
+                if self._tconv and ops.tconv_ok(t1, cout, N, F, Hh * Hh):
+                    # the k = 3 conv along the frames with stationary activations (tap shift = DPP lane shift): bitwise the GEMM below
+                    ops.tconv(t1, self._packed("tconv", wtk, lambda: ops.tconv_pack(self._gemm_w(wtk))),
+                              self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), cout, N, F, Hh * Hh, out=h,
+                              stats=self._stats_for(h, perm_unit=rows_in // N))
+                else:
+                    ops.conv_gemm(t1, self._gemm_w(wtk), self._f32(f"{p}.video_in_layers.2.video_conv_temporal.bias"), **self._temporal(Hh),
+                                  out=h, **self._stats_kw(h))
                 self._release(t1)
             else:
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)

@@ -584,6 +584,51 @@ def vconv2d1d(x, wf, bias_s, bias_t, N, F, Hh, Ww, a=None, b=None, geom=None, ac
     return out
 
 
+# The temporal k = 3 conv of VideoConv with stationary activations (include/mmd.h: mmd_tconv): per-pixel row order, tap shift = DPP lane
+# shift.  Bitwise equal to conv_gemm with TAPS_TEMPORAL, so the switch (MMD_TCONV=0: the tiled / strip GEMM) is a pure speed choice -
+# except for the ORDER of the statistics records (the kernel's own inside a sample), which the engine accounts for (perm_unit).
+_TCONV = os.environ.get("MMD_TCONV", "1") != "0"
+
+
+def tconv_shape_ok(x, Cout, N, F, HW):
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (256, 384, 512) and Cout % 64 == 0 and 0 < Cout <= 512 and F == 16
+            and HW % 8 == 0 and x.shape[0] == N * F * HW and x.stride(1) == 1 and x.stride(0) % 8 == 0)
+
+
+def tconv_ok(x, Cout, N, F, HW):
+    return _TCONV and tconv_shape_ok(x, Cout, N, F, HW)
+
+
+def tconv_pack(w):
+    """The packed temporal GEMM matrix [Cout, 3 * Cin] (bf16, K = tap * Cin + ci) -> the kernel's weight image (mmd_tconv_pack)."""
+    H.require_cuda(w)
+    Cout, Cin = w.shape[0], w.shape[1] // 3
+    if w.dtype != torch.bfloat16 or w.dim() != 2 or w.shape[1] != 3 * Cin or not w.is_contiguous():
+        raise H.MMDError(f"tconv_pack: expected a contiguous bf16 [Cout, 3 Cin] matrix, got {tuple(w.shape)} {w.dtype}")
+    out = torch.empty(H.lib().mmd_tconv_weight_bytes(Cin, Cout) // 2, dtype=torch.bfloat16, device=w.device)
+    H.call("mmd_tconv_pack", w.data_ptr(), out.data_ptr(), Cin, Cout, H.stream_handle())
+    return out
+
+
+def tconv(x, wf, bias, Cout, N, F, HW, out=None, stats=None):
+    """x [N*F*HW, Cin] bf16 -> [.., Cout]: the k = 3 conv along the frames of every pixel (include/mmd.h: mmd_tconv).  stats: the
+    output's record view [M / 64, Cout / 4, 2] (records in the kernel's own row order inside a sample)."""
+    _chk2d(x)
+    M, Cin = x.shape
+    if not tconv_shape_ok(x, Cout, N, F, HW):
+        raise H.MMDError(f"tconv: unsupported launch (x {tuple(x.shape)} {x.dtype}, Cout={Cout} N={N} F={F} HW={HW})")
+    if wf.numel() * 2 != H.lib().mmd_tconv_weight_bytes(Cin, Cout):
+        raise H.MMDError("tconv: the weight image does not match Cin / Cout")
+    out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    if out.data_ptr() == x.data_ptr():
+        raise H.MMDError("tconv: in-place is not supported")
+    sp, sld = (None, 0) if stats is None else _stats_args(stats, M, Cout)
+    _dispatch("mmd_tconv", x.data_ptr(), x.stride(0), wf.data_ptr(), H.ptr(bias), out.data_ptr(), out.stride(0), N, F, HW, Cin, Cout, sp, sld,
+              meta=(f"tconv<bf16>[M={M},K={3 * Cin},N={Cout}]", 2 * M * Cout * 3 * Cin, 2 * (M * Cin + M * Cout + Cout * 3 * Cin) + 4 * Cout))
+    return out
+
+
 # The temporal-attention block in one launch (include/mmd.h: mmd_tattn_block): GroupNorm over a pixel's frames, qkv, attention over the
 # frames, proj_out and the residual - instead of gn_small + qkv GEMM + attn_small + proj_out GEMM.  Built for the ds2 level of the
 # headline model (256 channels, 4 heads, 16 frames); like every kernel choice it depends on the layer's geometry only.
