@@ -208,17 +208,18 @@ int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, const float* gn
  * (16 frames, C / 32 channels) of a pixel, qkv / proj_out 1x1 convs, QKVAttention unet:290-330 with 1 / sqrt(ch) scaling).  Replaces
  * mmd_gn_small + mmd_conv_gemm (qkv) + mmd_attn_small_fwd + mmd_conv_gemm (proj_out, residual): the normalised tensor, the qkv tensor
  * and the attention output never exist in HBM (q, k, v and the attention output are rounded to bf16 exactly where the unfused path
- * stores them).  bf16; X / Y rows (n, f, pixel) x C with row strides ldx / ldy, Y != X; built for F == 16, C == 256, heads == 4,
- * HW % 16 == 0.  Wf: the image of mmd_tattn_pack (mmd_tattn_weight_bytes(with_pre) bytes) built from the qkv weight [3 C, C] (rows q | k | v,
- * head h = rows h ch .. of each third) and the proj_out weight [C, C], both bf16 row-major.  bias_qkv [3 C], bias_proj / gamma / beta
- * [C] fp32.  stats (nullable): quad statistics records of Y for the GroupNorm that consumes it, one per 64 rows in THIS kernel's
- * row order inside a sample (record = 16-pixel group * 4 + wave), so only norms over whole samples may finalize from them. */
-int64_t mmd_tattn_weight_bytes(int with_pre);
-int mmd_tattn_pack(const void* Wpre, const void* Wqkv, const void* Wproj, void* out, void* stream);
-/* Optional front stage (A != NULL, Wf packed with Wpre [C, C]): the block's input is x = X + A Wpre^T + bias_pre, i.e. the proj_out
+ * stores them).  bf16; X / Y rows (n, f, pixel) x C with row strides ldx / ldy, Y != X; built for F == 16, heads == 4, C in {256, 384,
+ * 512} (head widths 64 / 96 / 128), HW % 8 == 0.  Wf: the image of mmd_tattn_pack (mmd_tattn_weight_bytes(C, with_pre) bytes) built
+ * from the qkv weight [3 C, C] (rows q | k | v, head h = rows h ch .. of each third) and the proj_out weight [C, C], both bf16
+ * row-major.  bias_qkv [3 C], bias_proj / gamma / beta [C] fp32.  stats (nullable): quad statistics records of Y for the GroupNorm
+ * that consumes it, one per 64 rows in THIS kernel's row order inside a sample (record n HW / 4 + (pixel >> 2): the 16 frames of 4
+ * consecutive pixels), so only norms over whole samples may finalize from them.
+ * Optional front stage (A != NULL, Wf packed with Wpre [C, C]): the block's input is x = X + A Wpre^T + bias_pre, i.e. the proj_out
  * 1x1 conv + residual of the SPATIAL attention block that precedes the temporal one (unet:485-490) rides in the same launch; MID
- * [rows, C] (distinct from X, A, Y) receives x, rounded to bf16 like the tensor the unfused path stores, and is re-read as the
- * residual of the last stage.  A == NULL: Wpre == NULL at pack time, MID / bias_pre unused. */
+ * [rows, C] (distinct from X, A, Y) receives x, rounded to bf16 like the tensor the unfused path stores, and is re-read as operand
+ * and as the residual of the last stage.  A == NULL: Wpre == NULL at pack time, MID / bias_pre unused. */
+int64_t mmd_tattn_weight_bytes(int C, int with_pre);
+int mmd_tattn_pack(const void* Wpre, const void* Wqkv, const void* Wproj, void* out, int C, void* stream);
 int mmd_tattn_block(const void* X, int64_t ldx, const void* A, int64_t lda, void* MID, int64_t ldm, const void* Wf,
                     const float* bias_pre, const float* bias_qkv, const float* bias_proj, const float* gamma, const float* beta,
                     float eps, void* Y, int64_t ldy, int N, int F, int HW, int C, int heads, float* stats, int64_t stats_ld,

@@ -630,39 +630,44 @@ def tconv(x, wf, bias, Cout, N, F, HW, out=None, stats=None):
 
 
 # The temporal-attention block in one launch (include/mmd.h: mmd_tattn_block): GroupNorm over a pixel's frames, qkv, attention over the
-# frames, proj_out and the residual - instead of gn_small + qkv GEMM + attn_small + proj_out GEMM.  Built for the ds2 level of the
-# headline model (256 channels, 4 heads, 16 frames); like every kernel choice it depends on the layer's geometry only.
+# frames, proj_out and the residual - instead of gn_small + qkv GEMM + attn_small + proj_out GEMM.  Built for 256 / 384 / 512 channels,
+# 4 heads, 16 frames; used where it pays (_TATTN_LEVELS); like every kernel choice it depends on the layer's geometry only.
 # MMD_TATTN_FUSED=0: the four-launch path (A/B).
 _TATTN_FUSED = os.environ.get("MMD_TATTN_FUSED", "1") != "0"
 # the spatial block's proj_out + residual as the front stage of the same launch (MMD_TATTN_PRE=0: its own strip GEMM; A/B)
 _TATTN_PRE = os.environ.get("MMD_TATTN_PRE", "1") != "0"
+# channel counts (levels) the engine uses the fused block at: 256 = ds2.  The kernel is also built and tested for 384 / 512 channels (ds4 /
+# ds8: head widths 96 / 128 need one wave per SIMD), measured round 4: ds4 50 vs 63 us alone, neutral in the step; ds8 74 vs 44 us, a
+# loss (MMD_TATTN_LEVELS=256,384,512: A/B)
+_TATTN_LEVELS = tuple(int(v) for v in os.environ.get("MMD_TATTN_LEVELS", "256").split(",") if v)
 
 
 def tattn_shape_ok(x, heads, N, F, HW):
-    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and heads == 4 and F == 16 and HW % 16 == 0
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (256, 384, 512) and heads == 4 and F == 16 and HW % 8 == 0
             and x.shape[0] == N * F * HW and x.stride(1) == 1 and x.stride(0) % 8 == 0)
 
 
 def tattn_fused_ok(x, heads, N, F, HW):
-    return _TATTN_FUSED and tattn_shape_ok(x, heads, N, F, HW)
+    return _TATTN_FUSED and tattn_shape_ok(x, heads, N, F, HW) and x.shape[1] in _TATTN_LEVELS
 
 
 def tattn_pack(wqkv, wproj, wpre=None):
     """qkv weight [3 C, C] and proj_out weight [C, C] of the temporal block - and, for the front stage, the proj_out weight [C, C] of the
     spatial block before it - (bf16, contiguous GEMM matrices) -> the kernel's weight image (mmd_tattn_pack)."""
     H.require_cuda(wqkv, wproj)
-    mats = [(wqkv, (768, 256)), (wproj, (256, 256))] + ([(wpre, (256, 256))] if wpre is not None else [])
+    C = wproj.shape[0]
+    mats = [(wqkv, (3 * C, C)), (wproj, (C, C))] + ([(wpre, (C, C))] if wpre is not None else [])
     for w, shape in mats:
-        if w.dtype != torch.bfloat16 or tuple(w.shape) != shape or not w.is_contiguous():
-            raise H.MMDError(f"tattn_pack: expected contiguous bf16 {shape}, got {tuple(w.shape)} {w.dtype}")
-    out = torch.empty(H.lib().mmd_tattn_weight_bytes(0 if wpre is None else 1) // 2, dtype=torch.bfloat16, device=wqkv.device)
-    H.call("mmd_tattn_pack", H.ptr(wpre), wqkv.data_ptr(), wproj.data_ptr(), out.data_ptr(), H.stream_handle())
+        if C not in (256, 384, 512) or w.dtype != torch.bfloat16 or tuple(w.shape) != shape or not w.is_contiguous():
+            raise H.MMDError(f"tattn_pack: expected contiguous bf16 {shape} with C in (256, 384, 512), got {tuple(w.shape)} {w.dtype}")
+    out = torch.empty(H.lib().mmd_tattn_weight_bytes(C, 0 if wpre is None else 1) // 2, dtype=torch.bfloat16, device=wqkv.device)
+    H.call("mmd_tattn_pack", H.ptr(wpre), wqkv.data_ptr(), wproj.data_ptr(), out.data_ptr(), C, H.stream_handle())
     return out
 
 
 def tattn_block(x, wf, bias_qkv, bias_proj, gamma, beta, heads, N, F, HW, out=None, stats=None, pre=None):
-    """x [N*F*HW, 256] bf16 -> x + proj_out(temporal attention(qkv(GroupNorm32(x)))) (include/mmd.h: mmd_tattn_block).  stats: the
-    output's record view [M / 64, 64, 2] (records in the kernel's own row order inside a sample).  pre = (att, bias_pre, mid): the
+    """x [N*F*HW, C] bf16 (C = 256 / 384 / 512) -> x + proj_out(temporal attention(qkv(GroupNorm32(x)))) (include/mmd.h:
+    mmd_tattn_block).  stats: the output's record view [M / 64, C / 4, 2] (records in the kernel's own row order inside a sample).  pre = (att, bias_pre, mid): the
     front stage - the block's input is x + att Wpre^T + bias_pre (wf packed with wpre), written to the scratch `mid`."""
     _chk2d(x)
     M, C = x.shape
@@ -677,9 +682,9 @@ def tattn_block(x, wf, bias_qkv, bias_proj, gamma, beta, heads, N, F, HW, out=No
         att, bpre, mid = pre
         _chk2d(att), _chk2d(mid)
         if (att.shape != x.shape or mid.shape != x.shape or att.dtype != x.dtype or mid.dtype != x.dtype
-                or len({t.data_ptr() for t in (x, att, mid, out)}) != 4 or wf.numel() * 2 != H.lib().mmd_tattn_weight_bytes(1)):
+                or len({t.data_ptr() for t in (x, att, mid, out)}) != 4 or wf.numel() * 2 != H.lib().mmd_tattn_weight_bytes(C, 1)):
             raise H.MMDError("tattn_block: the front stage needs att / mid of x's shape, four distinct buffers and weights packed with wpre")
-    elif wf.numel() * 2 != H.lib().mmd_tattn_weight_bytes(0):
+    elif wf.numel() * 2 != H.lib().mmd_tattn_weight_bytes(C, 0):
         raise H.MMDError("tattn_block: weights packed with a front stage need pre=(att, bias_pre, mid)")
     sp, sld = (None, 0) if stats is None else _stats_args(stats, M, C)
     npre = 0 if pre is None else 1

@@ -31,8 +31,8 @@ def timed(fn, n=20):
 
 
 def main():
-    C, heads, F = 256, 4, 16
-    for N, HW in ((4, 1024), (1, 1024), (4, 256)):
+    heads, F = 4, 16
+    for N, HW, C in ((4, 1024, 256), (4, 256, 384), (4, 64, 512), (1, 1024, 256)):
         M = N * F * HW
         g = torch.Generator(device="cuda").manual_seed(0)
         x = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
@@ -79,7 +79,7 @@ def main():
             t5 = min(t5, timed(five))
             tp = min(tp, timed(fused_pre))
         flops = 2.0 * M * C * 4 * C + 4.0 * M * F * C
-        print(f"N={N} HW={HW:5d} M={M:6d} | four launches {t4:7.1f} us | fused {tf:7.1f} us  {flops / tf / 1e6:6.0f} TF/s  {3 * M * C * 2 / tf / 1e3:6.0f} GB/s (x + residual + y) | rel-L2 {err:.1e}"
+        print(f"N={N} HW={HW:5d} C={C} M={M:6d} | four launches {t4:7.1f} us | fused {tf:7.1f} us  {flops / tf / 1e6:6.0f} TF/s  {3 * M * C * 2 / tf / 1e3:6.0f} GB/s (x + residual + y) | rel-L2 {err:.1e}"
               f" || with the spatial proj_out in front: five launches {t5:7.1f} us | fused {tp:7.1f} us")
 
 

@@ -46,13 +46,14 @@ def std_k(h, e):
     return 8 * h + e
 
 
-def check(seed=0, verbose=False):
+def check(seed=0, verbose=False, C=256):
     rng = np.random.default_rng(seed)
-    C, CH, HEADS = 256, 64, 4
+    HEADS = 4
+    CH = C // HEADS                                        # 64 / 96 / 128: 2 / 3 / 4 sub-tiles of 32 channels per head
     x = rng.standard_normal((32, C))                       # normalised rows of the fragment (the GroupNorm is elementwise bookkeeping)
-    Wqkv = rng.standard_normal((3 * C, C)) / 16
+    Wqkv = rng.standard_normal((3 * C, C)) / np.sqrt(C)
     bqkv = rng.standard_normal(3 * C) / 4
-    Wp = rng.standard_normal((C, C)) / 16
+    Wp = rng.standard_normal((C, C)) / np.sqrt(C)
     scale = CH ** -0.5
 
     # ---- reference
@@ -115,7 +116,7 @@ def check(seed=0, verbose=False):
             ops_ = acc_to_operands(oT)                           # lane = query row, elements = channel crow(s, h, e) of sub-tile a
             for s in range(2):
                 o_ops[(hd, a, s)] = ops_[s]
-    # projection: K step (hd, a, s) covers channels 64 hd + 32 a + crow(s, h, e) = a 16-channel block [64 hd + 32 a + 16 s, + 16) in the
+    # projection: K step (hd, a, s) covers channels CH hd + 32 a + crow(s, h, e) = a 16-channel block [CH hd + 32 a + 16 s, + 16) in the
     # order pi(h, e) = 8 (e // 4) + 4 h + e % 4; the packed Wp stores, at standard position 8 h + e, the column of that channel
     perm = np.zeros(C, dtype=np.int64)
     for blk in range(C // 16):
@@ -129,7 +130,7 @@ def check(seed=0, verbose=False):
         for hd in range(HEADS):
             for a in range(CH // 32):
                 for s in range(2):
-                    cg = (64 * hd + 32 * a + 16 * s) // 16
+                    cg = (CH * hd + 32 * a + 16 * s) // 16
                     acc = mfma(wfrag(Wp_packed, 32 * mt, cg), o_ops[(hd, a, s)], acc)
         for l in range(L):
             for i in range(16):
@@ -142,4 +143,5 @@ def check(seed=0, verbose=False):
 
 
 if __name__ == "__main__":
-    check(verbose=True)
+    for C_ in (256, 384, 512):
+        check(verbose=True, C=C_)
