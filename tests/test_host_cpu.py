@@ -396,3 +396,14 @@ def test_tattn_register_model():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(seed=1) < 1e-12
+
+
+def test_tconv_register_model():
+    """tools/tconv_model.py: the temporal conv's tap shift as a DPP lane shift of the stationary operand fragments (zeros shifted in =
+    the zero padding in time), in the kernel's K order, against a float64 conv1d."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tconv_model.py")
+    spec = importlib.util.spec_from_file_location("tconv_model", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check(seed=2) < 1e-12
