@@ -258,6 +258,12 @@ int mmd_attn_small_fwd(int dtype, const void* QKV, int64_t ld, void* O, int64_t 
  * (unet:133-208: video (1,2,2); audio F=1,H=1,W=L, fw=4).  H, W describe the INPUT. */
 int mmd_resample(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int NF, int H, int W, int fh, int fw,
                  int mode, float scale, void* stream);   /* y = scale * resample(x): backward of one mode is the other mode, rescaled */
+/* The same resampling (bf16, scale 1) with the GroupNorm statistics of the OUTPUT in the epilogue: stats / stats_ld as in
+ * mmd_conv_gemm_stats - one (sum, sum of squares) record per 64 output rows and QUAD of channels, of the values as stored.  The norms
+ * that follow a resample (the out_layers norm of a down ResBlock, every norm over an up ResBlock's output: unet:441-448 + nn.py:16-33)
+ * then finalize with mmd_gn_finalize_stats instead of a statistics pass.  Output rows % 64 == 0, C % 8 == 0, C <= 2048. */
+int mmd_resample_stats(const void* x, int64_t ldx, void* y, int64_t ldy, int C, int NF, int H, int W, int fh, int fw, int mode,
+                       float* stats, int64_t stats_ld, void* stream);
 /* 2-D strided copy (skip-connection concat th.cat, unet:1093-1094). */
 int mmd_copy2d(const void* x, int64_t ldx_bytes, void* y, int64_t ldy_bytes, int64_t rows, int64_t row_bytes, void* stream);
 
@@ -269,6 +275,18 @@ int mmd_stem_conv(int dtype, const float* x, const float* w, const float* bias, 
  * (video_out Conv3d 3x3x3 / audio_out Conv1d k3, unet:1003-1012). */
 int mmd_head_conv(int dtype, const void* x, int64_t ldx, const float* w, const float* bias, float* y, int N, int F, int Cin,
                   int H, int W, int Co, int ntaps, const int* taps, void* stream);
+/* The same head for few output channels as GEMM + gather (round 5; bf16, Cin = 128, ntaps * Co <= 96): mmd_head_gemm computes the
+ * per-row products P[tap Co + co][m] = sum_ci W[tap][ci][co] act(x[m][ci] a + b) on the matrix cores - the GroupNorm32 + SiLU of
+ * video_out.0/.1 (unet:1003-1006) applied in registers from the fused affine a / b [S, Cin] (S slices of gn_rows rows, gn_rows % 128
+ * == 0), x read once, nothing normalised written - and mmd_head_gather sums them over the taps into the API layout
+ * y[N, F, Co, H, W] (+ bias; zero padding outside (F, H, W)).  wimg: the bf16 (hi, lo) weight image in MFMA fragment order,
+ * mmd_head_gemm_weight_bytes(Cin) bytes, packed by the host mirror (ops.head_gemm_pack); P: fp32 workspace [ntaps * Co][M]. */
+int64_t mmd_head_gemm_weight_bytes(int Cin);
+int64_t mmd_head_gemm_workspace_bytes(int64_t M, int ntaps, int Co);
+int mmd_head_gemm(const void* x, int64_t ldx, int64_t M, int Cin, const float* gn_a, const float* gn_b, int S, int64_t gn_rows, int act,
+                  const void* wimg, float* P, int NO, void* stream);
+int mmd_head_gather(const float* P, const float* bias, float* y, int N, int F, int H, int W, int Co, int ntaps, const int* taps,
+                    void* stream);
 
 /* One DDPM ancestral step for one stream (p_mean_variance + p_sample, multimodal_gaussian_diffusion.py:231-343,
  * 415-474) on API-layout fp32 tensors x/noise/out [N,F,C,HW], model_out [N,F,Cm,HW] (Cm = 2C with flag 4).

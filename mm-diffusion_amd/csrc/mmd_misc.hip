@@ -115,6 +115,75 @@ __global__ __launch_bounds__(256) void resample_kernel(const char* __restrict__ 
   }
 }
 
+// The same resampling (bf16) with the GroupNorm statistics of the OUTPUT in the epilogue (round 5): one block owns one 64-row RECORD of the
+// output, writes its rows and leaves (sum, sum of squares) of the values AS STORED per quad of channels - the record format of the GEMM
+// epilogues (mmd_conv_gemm_stats) - so a norm that follows a resample (the out_layers norm of the down ResBlocks, every norm that reads
+// an up ResBlock's output, unet:441-448) finalizes from records instead of paying a statistics pass over the tensor.
+// Thread (rg, cv) owns channel vector cv (8 channels = two quads) of the rows rg, rg + RGN, ...: per-thread sums in row order, then the
+// row groups are folded in ascending order by the rg == 0 threads - a fixed order, bitwise repeatable and independent of the grid.
+__global__ __launch_bounds__(256) void resample_stats_kernel(const char* __restrict__ x, int64_t ldx, char* __restrict__ y, int64_t ldy, int C,
+                                                             int NF, int H, int W, int fh, int fw, int mode, float* __restrict__ stats,
+                                                             int64_t stats_ld, int nrec, int lcvp) {
+  __shared__ float sPart[256 * 4];
+  const int tid = threadIdx.x, CV = C >> 3;
+  const int cv = tid & ((1 << lcvp) - 1), rg = tid >> lcvp, rgn = 256 >> lcvp;
+  const int Ho = mode == 0 ? H / fh : H * fh, Wo = mode == 0 ? W / fw : W * fw;
+  const float inv = 1.f / (float)(fh * fw);
+  for (int rec = blockIdx.x; rec < nrec; rec += gridDim.x) {
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (cv < CV) {
+#pragma unroll 4
+      for (int r = rg; r < 64; r += rgn) {
+        const int orow = rec * 64 + r;                     // < 2^31 (checked by the launcher)
+        const int wo = orow % Wo, t = orow / Wo, ho = t % Ho, nf = t / Ho;
+        u32x4 v;
+        if (mode == 0) {
+          float acc[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+          for (int a = 0; a < fh; ++a)
+            for (int b = 0; b < fw; ++b) {
+              const int64_t irow = ((int64_t)nf * H + ho * fh + a) * W + wo * fw + b;
+              float f[8];
+              Elt<__bf16>::unpack(*(const u32x4*)(x + (irow * ldx + (int64_t)cv * 8) * 2), f);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[e] += f[e];
+            }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] *= inv;
+          v = Elt<__bf16>::pack(acc);
+        } else {
+          const int64_t irow = ((int64_t)nf * H + ho / fh) * W + wo / fw;
+          v = *(const u32x4*)(x + (irow * ldx + (int64_t)cv * 8) * 2);
+        }
+        *(u32x4*)(y + ((int64_t)orow * ldy + (int64_t)cv * 8) * 2) = v;
+        float f[8];
+        Elt<__bf16>::unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0 += f[j];
+          s1 += f[4 + j];
+          q0 += f[j] * f[j];
+          q1 += f[4 + j] * f[4 + j];
+        }
+      }
+    }
+    *(f32x4*)(sPart + tid * 4) = f32x4{s0, s1, q0, q1};
+    __syncthreads();
+    if (rg == 0 && cv < CV) {
+      for (int g = 1; g < rgn; ++g) {
+        const f32x4 o = *(const f32x4*)(sPart + ((g << lcvp) + cv) * 4);
+        s0 += o[0];
+        s1 += o[1];
+        q0 += o[2];
+        q1 += o[3];
+      }
+      *(f32x4*)(stats + ((int64_t)rec * stats_ld + 2 * cv) * 2) = f32x4{s0, q0, s1, q1};     // quads 2 cv, 2 cv + 1: (sum, sum of squares)
+    }
+    __syncthreads();
+  }
+}
+
 // strided 2-D copy of 16-byte vecs (skip-connection concat: write a tensor into a column slice)
 __global__ __launch_bounds__(256) void copy2d_kernel(const char* __restrict__ x, int64_t ldx_b, char* __restrict__ y, int64_t ldy_b,
                                                      int64_t rows, int vecs) {
@@ -456,6 +525,24 @@ extern "C" int mmd_resample(int dtype, const void* x, int64_t ldx, void* y, int6
   else
     hipLaunchKernelGGL(resample_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)x, ldx, (char*)y, ldy, C, NF, H, W, fh, fw, mode, scale);
   return mmd_check_launch("resample");
+}
+
+extern "C" int mmd_resample_stats(const void* x, int64_t ldx, void* y, int64_t ldy, int C, int NF, int H, int W, int fh, int fw, int mode,
+                                  float* stats, int64_t stats_ld, void* stream) {
+  MMD_REQUIRE(x && y && stats && C > 0 && C % 8 == 0 && C <= 2048 && NF > 0 && H > 0 && W > 0 && fh > 0 && fw > 0 && (mode == 0 || mode == 1),
+              "resample_stats: bad argument (bf16 rows of 8 .. 2048 channels in whole 16-byte vectors)");
+  MMD_REQUIRE(mode == 1 || (H % fh == 0 && W % fw == 0), "resample_stats: pooled dims must divide (%d/%d, %d/%d)", H, fh, W, fw);
+  const int64_t orows = mode == 0 ? (int64_t)NF * (H / fh) * (W / fw) : (int64_t)NF * H * fh * W * fw;
+  MMD_REQUIRE(orows % 64 == 0 && orows < ((int64_t)1 << 31), "resample_stats: %ld output rows (records are 64 rows; < 2^31)", (long)orows);
+  MMD_REQUIRE((uintptr_t)stats % 16 == 0 && stats_ld % 2 == 0 && stats_ld >= C / 4, "resample_stats: the record view must start on an even quad "
+              "of a 16-byte aligned buffer (ld %ld quads)", (long)stats_ld);
+  MMD_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "resample_stats: unaligned rows");
+  int lcvp = 0;
+  while ((1 << lcvp) < C / 8) ++lcvp;
+  const int nrec = (int)(orows / 64);
+  hipLaunchKernelGGL(resample_stats_kernel, dim3(min(nrec, 8192)), dim3(256), 0, (hipStream_t)stream, (const char*)x, ldx, (char*)y, ldy, C, NF, H,
+                     W, fh, fw, mode, stats, stats_ld, nrec, lcvp);
+  return mmd_check_launch("resample_stats");
 }
 
 extern "C" int mmd_copy2d(const void* x, int64_t ldx_bytes, void* y, int64_t ldy_bytes, int64_t rows, int64_t row_bytes, void* stream) {
@@ -870,6 +957,186 @@ static int launch_head(const HeadConvParams& p, hipStream_t st) {
   else if (CO == 4) hipLaunchKernelGGL((head_conv_kernel<T, 4>), dim3(grid), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((head_conv_kernel<T, 8>), dim3(grid), dim3(256), lds, st, p);
   return mmd_check_launch("head_conv");
+}
+
+// ----------------------------------------------------------------------------- head conv as GEMM + gather (round 5, bf16)
+// The head (GroupNorm32 + SiLU + Conv3d 3x3x3, 128 -> 3 channels, unet:1003-1012) was the video stream's LAST launch pair and its
+// slowest HBM-side kernel: gn_apply wrote the normalised tensor (134 MB of traffic) and head_conv_strip read it 27 times through L1 / L2
+// (0.45 TB/s).  A convolution with few output channels factors the other way round: FIRST the per-row products
+//     P[o, m] = sum_ci W[tap, ci, co] act(norm(x))[m, ci],   o = tap Co + co   (a GEMM with N = ntaps Co = 81 columns, K = Cin),
+// with the norm applied in registers on the way into the MFMA operand (x is read ONCE, nothing normalised is written), THEN
+//     y[n, f, co, h, w] = bias[co] + sum_tap P[tap Co + co, m + offset(tap)]    (zero outside the frame),
+// a pure gather over fp32 planes P[o][m] that are contiguous in m (coalesced along w) and read exactly once.
+// Weights enter the matrix pipe as a bf16 (hi, lo) pair, so the products keep the fp32 weights to 2^-17 (the direct kernel uses fp32
+// weights); the activations are rounded to bf16 exactly where gn_apply used to store them.
+struct HeadGemmParams {
+  const char* x; int64_t ldx; int64_t M;
+  const float* gn_a; const float* gn_b; int64_t gn_rows; int gn_S; int act;
+  const char* wimg;          // [2 hi/lo][3 blocks of 32 outputs][KS k-steps][64 lanes][16 B]: lane (l31, half) = W[32 ob + l31][16 cg + 8 half .. + 8]
+  float* P;                  // [NO][M] fp32 planes
+  int NO;                    // ntaps * Co <= 96
+  int per_block;             // consecutive 128-row groups per block
+};
+template <int KS>
+__global__ __launch_bounds__(256, 2) void head_gemm_kernel(const HeadGemmParams p) {
+  constexpr int C = 16 * KS, WIMG_B = 2 * 3 * KS * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;
+  float* sGN = (float*)(smem + WIMG_B);                  // [a | b][C] of the current slice
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  for (int i = tid; i < WIMG_B / 16; i += 256) *(u32x4*)(sW + i * 16) = *(const u32x4*)(p.wimg + i * 16);
+  const int64_t ngroups = (p.M + 127) / 128;
+  const int64_t g0 = (int64_t)blockIdx.x * p.per_block, g1 = min(g0 + p.per_block, ngroups);
+  int cur_slice = -1;
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t m = g * 128 + wave * 32 + l31;
+    const bool ok = m < p.M;
+    const int64_t mc = ok ? m : p.M - 1;
+    u32x4 xa[KS];
+    const char* ap = p.x + (mc * p.ldx + half * 8) * 2;
+#pragma unroll
+    for (int cg = 0; cg < KS; ++cg) xa[cg] = *(const u32x4*)(ap + cg * 32);
+    const int slice = (int)((g * 128) / p.gn_rows);       // gn_rows % 128 == 0: a 128-row group lies inside one slice (block-uniform)
+    if (slice != cur_slice) {
+      __syncthreads();                                     // every wave is past its reads of the previous table (and of nothing, first time)
+      for (int i = tid; i < 2 * C; i += 256) sGN[i] = (i < C ? p.gn_a : p.gn_b)[(int64_t)slice * C + (i < C ? i : i - C)];
+      cur_slice = slice;
+      __syncthreads();                                     // (also covers the weight image on the first pass)
+    }
+#pragma unroll
+    for (int cg = 0; cg < KS; ++cg) {
+      float v[8];
+      Elt<__bf16>::unpack(xa[cg], v);
+      const float* a4 = sGN + cg * 16 + half * 8;
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) {
+        const f32x4 av = *(const f32x4*)(a4 + e), bv = *(const f32x4*)(a4 + C + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float y = v[e + k] * av[k] + bv[k];
+          v[e + k] = p.act ? silu_f(y) : y;
+        }
+      }
+      u32x4 y = Elt<__bf16>::pack(v);
+      asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));      // keep the normalisation here (see the strip GEMM)
+      xa[cg] = y;
+    }
+#pragma unroll
+    for (int ob = 0; ob < 3; ++ob) {
+      if (ob * 32 >= p.NO) break;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+        for (int cg = 0; cg < KS; ++cg) {
+          const u32x4 fw = *(const u32x4*)(sW + (((hl * 3 + ob) * KS + cg) * 64 + lane) * 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw), __builtin_bit_cast(bf16x8, xa[cg]), acc, 0, 0, 0);
+        }
+      // acc[4 q + j] = output 32 ob + 8 q + 4 half + j of row m: lanes 0 - 31 of a register are 32 consecutive m of one plane (128 bytes)
+      if (ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int o = ob * 32 + 8 * q + 4 * half + j;
+            if (o < p.NO) p.P[(int64_t)o * p.M + m] = acc[4 * q + j];
+          }
+      }
+    }
+  }
+}
+
+struct HeadGatherParams {
+  const float* P; int64_t M; const float* bias; float* y;
+  int N, F, H, W, Co, ntaps;
+  int taps[27 * 3];
+};
+template <int CO>
+__global__ __launch_bounds__(256) void head_gather_kernel(const HeadGatherParams p) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= p.M) return;
+  const int w = (int)(m % p.W), h = (int)((m / p.W) % p.H);
+  const int64_t nf = m / ((int64_t)p.W * p.H);
+  const int f = (int)(nf % p.F);
+  const int64_t HW = (int64_t)p.H * p.W;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = p.bias ? p.bias[c] : 0.f;
+  // nine taps per trip: their 9 CO loads are independent and issue together (branch-free: a tap outside the frame reads the centre
+  // element and is multiplied by zero); the sum runs in tap order
+  for (int t0 = 0; t0 < p.ntaps; t0 += 9) {
+    float v[9][CO], k[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int t = min(t0 + u, p.ntaps - 1);
+      const int df = p.taps[3 * t], dh = p.taps[3 * t + 1], dw = p.taps[3 * t + 2];
+      const bool ok = t0 + u < p.ntaps && (unsigned)(f + df) < (unsigned)p.F && (unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w + dw) < (unsigned)p.W;
+      const int64_t src = ok ? m + df * HW + dh * p.W + dw : m;
+      k[u] = ok ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) v[u][c] = p.P[(int64_t)(t * CO + c) * p.M + src];
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] += k[u] * v[u][c];
+  }
+  const int64_t n = nf / p.F;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) p.y[(((n * p.F + f) * CO + c) * p.H + h) * (int64_t)p.W + w] = acc[c];
+}
+
+extern "C" int64_t mmd_head_gemm_weight_bytes(int Cin) { return (Cin == 128) ? 2 * 3 * (Cin / 16) * 1024 : 0; }
+extern "C" int64_t mmd_head_gemm_workspace_bytes(int64_t M, int ntaps, int Co) { return (int64_t)ntaps * Co * M * 4; }
+
+// P = W act(x a + b): x bf16 rows [M, Cin] (Cin = 128), a / b fp32 [S, Cin] = the fused GroupNorm affine over S slices of gn_rows rows
+// (gn_rows % 128 == 0; a == NULL is not supported: the head always follows its norm), wimg = the packed (hi, lo) weight image
+// (mmd_head_gemm_weight_bytes; packed by the host mirror), P fp32 [ntaps * Co][M].
+extern "C" int mmd_head_gemm(const void* x, int64_t ldx, int64_t M, int Cin, const float* gn_a, const float* gn_b, int S, int64_t gn_rows,
+                             int act, const void* wimg, float* P, int NO, void* stream) {
+  MMD_REQUIRE(x && gn_a && gn_b && wimg && P && M > 0, "head_gemm: null pointer / empty");
+  MMD_REQUIRE(Cin == 128, "head_gemm: built for 128 input channels (got %d)", Cin);
+  MMD_REQUIRE(NO >= 1 && NO <= 96, "head_gemm: 1 .. 96 outputs (taps x channels), got %d", NO);
+  MMD_REQUIRE(S > 0 && gn_rows > 0 && gn_rows % 128 == 0 && (int64_t)S * gn_rows == M, "head_gemm: S x gn_rows must tile the rows in multiples of 128");
+  MMD_REQUIRE(((uintptr_t)x | (uintptr_t)wimg) % 16 == 0 && ldx % 8 == 0 && (uintptr_t)P % 4 == 0, "head_gemm: unaligned operand");
+  HeadGemmParams p;
+  p.x = (const char*)x; p.ldx = ldx; p.M = M; p.gn_a = gn_a; p.gn_b = gn_b; p.gn_rows = gn_rows; p.gn_S = S; p.act = act;
+  p.wimg = (const char*)wimg; p.P = P; p.NO = NO;
+  const int64_t ngroups = (M + 127) / 128;
+  p.per_block = (int)max((int64_t)1, (ngroups + 1023) / 1024);          // <= 1024 blocks: two per CU, each a run of consecutive row groups
+  const int grid = (int)((ngroups + p.per_block - 1) / p.per_block);
+  const size_t lds = 2 * 3 * 8 * 1024 + 2 * 128 * sizeof(float);
+  static bool attr_done[MMD_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mmd_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)head_gemm_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "head_gemm: set LDS attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(head_gemm_kernel<8>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  return mmd_check_launch("head_gemm");
+}
+
+// y[n, f, co, h, w] = bias[co] + sum_tap P[tap Co + co][m + offset(tap)] (zero outside (F, H, W)); y fp32 API layout [N, F, Co, H, W].
+extern "C" int mmd_head_gather(const float* P, const float* bias, float* y, int N, int F, int H, int W, int Co, int ntaps, const int* taps,
+                               void* stream) {
+  MMD_REQUIRE(P && y && taps && N > 0 && F > 0 && H > 0 && W > 0 && ntaps >= 1 && ntaps <= 27, "head_gather: bad argument");
+  MMD_REQUIRE(Co == 1 || Co == 2 || Co == 3 || Co == 4 || Co == 6, "head_gather: Co in {1, 2, 3, 4, 6} (got %d)", Co);
+  HeadGatherParams p;
+  p.P = P; p.M = (int64_t)N * F * H * W; p.bias = bias; p.y = y; p.N = N; p.F = F; p.H = H; p.W = W; p.Co = Co; p.ntaps = ntaps;
+  for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
+  const int grid = (int)((p.M + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (Co) {
+    case 1: hipLaunchKernelGGL(head_gather_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL(head_gather_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL(head_gather_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+    case 4: hipLaunchKernelGGL(head_gather_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL(head_gather_kernel<6>, dim3(grid), dim3(256), 0, st, p); break;
+  }
+  return mmd_check_launch("head_gather");
 }
 
 extern "C" int mmd_head_conv(int dtype, const void* x, int64_t ldx, const float* w, const float* bias, float* y, int N, int F,

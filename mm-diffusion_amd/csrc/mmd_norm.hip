@@ -479,20 +479,29 @@ __global__ __launch_bounds__(256) void gn_finalize_rec_kernel(const float* __res
                                                               const float* __restrict__ film, int64_t film_ld, float eps,
                                                               float* __restrict__ a_out, float* __restrict__ b_out, float* __restrict__ mr_out) {
   __shared__ double s_a[4], s_b[4];
-  __shared__ float s_mr[2];
   const int gi = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / GN_GROUPS, qpg = cpg / 4;           // records are per QUAD of 4 channels (round 3)
   const int nrec = Tn / 64;
   const float* base = rec + ((int64_t)s * nrec * rec_ld + (int64_t)gi * qpg) * 2;
   const int total = nrec * qpg;
+  // round 5: the affine / FiLM operands are requested BEFORE the records (they do not depend on the reduction): the launch is a chain of
+  // memory round trips (kernel arguments -> records -> gamma / beta / film -> store) and this takes one of them out; the (mean, rstd) of
+  // the group is computed by every writer thread itself instead of one thread + a second barrier (same operations, same bits)
+  const int c = gi * cpg + min(tid, cpg - 1);
+  const float gv = gamma[c], bv0 = beta[c];
+  float fsc = 0.f, fsh = 0.f;
+  if (film) {
+    fsc = film[(int64_t)s * film_ld + c];
+    fsh = film[(int64_t)s * film_ld + C + c];
+  }
   double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < total; i += 1024) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {          // branch-free: clamped address, masked value -> the four loads issue together
       const int k = i + 256 * u;
       const int kk = min(k, total - 1);
-      const int r = kk / qpg, c = kk - r * qpg;
-      const float2 v = *(const float2*)(base + ((int64_t)r * rec_ld + c) * 2);
+      const int r = kk / qpg, cq = kk - r * qpg;
+      const float2 v = *(const float2*)(base + ((int64_t)r * rec_ld + cq) * 2);
       const double m = k < total ? 1.0 : 0.0;
       a[u] += m * (double)v.x;
       b[u] += m * (double)v.y;
@@ -503,29 +512,23 @@ __global__ __launch_bounds__(256) void gn_finalize_rec_kernel(const float* __res
   tb = wave_sum_d(tb);
   if ((tid & 63) == 0) { s_a[tid >> 6] = ta; s_b[tid >> 6] = tb; }
   __syncthreads();
-  if (tid == 0) {
+  if (tid < cpg) {
     const double sa = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]), sb = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
     const double cnt = (double)Tn * (double)cpg;
     const double mean = sa / cnt;
     double var = sb / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
-    s_mr[0] = (float)mean;
-    s_mr[1] = (float)(1.0 / sqrt(var + (double)eps));
-    if (mr_out) {
-      mr_out[((int64_t)s * GN_GROUPS + gi) * 2] = s_mr[0];
-      mr_out[((int64_t)s * GN_GROUPS + gi) * 2 + 1] = s_mr[1];
+    const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+    if (mr_out && tid == 0) {
+      mr_out[((int64_t)s * GN_GROUPS + gi) * 2] = mean_f;
+      mr_out[((int64_t)s * GN_GROUPS + gi) * 2 + 1] = rstd_f;
     }
-  }
-  __syncthreads();
-  if (tid < cpg) {
-    const int c = gi * cpg + tid;
-    float av = s_mr[1] * gamma[c];
-    float bv = beta[c] - s_mr[0] * av;
+    float av = rstd_f * gv;
+    float bv = bv0 - mean_f * av;
     if (film) {
-      const float sc = 1.f + film[(int64_t)s * film_ld + c];
-      const float sh = film[(int64_t)s * film_ld + C + c];
+      const float sc = 1.f + fsc;
       av *= sc;
-      bv = bv * sc + sh;
+      bv = bv * sc + fsh;
     }
     a_out[(int64_t)s * C + c] = av;
     b_out[(int64_t)s * C + c] = bv;

@@ -70,9 +70,14 @@ _PROTOS = {
     "mmd_attn_fwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, i64, i32, i64, i32, i32, vp, i32, vp]),
     "mmd_attn_small_fwd": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "mmd_resample": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "mmd_resample_stats": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "mmd_copy2d": (i32, [vp, i64, vp, i64, i64, i64, vp]),
     "mmd_stem_conv": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
     "mmd_head_conv": (i32, [i32, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
+    "mmd_head_gemm_weight_bytes": (i64, [i32]),
+    "mmd_head_gemm_workspace_bytes": (i64, [i64, i32, i32]),
+    "mmd_head_gemm": (i32, [vp, i64, i64, i32, vp, vp, i32, i64, i32, vp, vp, i32, vp]),
+    "mmd_head_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32), vp]),
     "mmd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_loss_workspace_bytes": (i64, [i32]),
     "mmd_loss_terms": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),

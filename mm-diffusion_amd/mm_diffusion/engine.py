@@ -23,6 +23,14 @@ from .ops import Geom
 
 _EMB_ON_AUDIO_STREAM = os.environ.get("MMD_EMB_AUX", "1") != "0"
 _POOL_NOREUSE = os.environ.get("MMD_POOL_NOREUSE") == "1"      # diagnostics (tools/determinism_graph.py): every tensor keeps its own buffer
+# round 5: the out layers of the up ResBlocks at the input resolution (one upsample of the block's result instead of two of its operands);
+# MMD_UP_LOWRES=0: the reference's order of operations (A/B)
+_UP_LOWRES = os.environ.get("MMD_UP_LOWRES", "1") != "0"
+# round 5: a cross-attention block's audio-side attention runs behind its video-side attention and the video stream does not wait for it;
+# MMD_CROSS_SERIAL=0: both start together and each stream waits for the other's (A/B)
+_CROSS_SERIAL = os.environ.get("MMD_CROSS_SERIAL", "1") != "0"
+# round 5: GroupNorm statistics of resampled tensors from the resample launch's epilogue (mmd_resample_stats); =0: statistics passes (A/B)
+_RESAMPLE_STATS = os.environ.get("MMD_RESAMPLE_STATS", "1") != "0"
 
 
 class _Pool:
@@ -96,6 +104,7 @@ class UNetEngine:
         self._tail_structs = []       # every GnTail handed to a producer launch: (struct, entry)
         self._tail_bytes = 0          # bump allocator of the per-forward-zeroed arena (accumulators + counters)
         self._tail_static = []        # affine tables written by producers: never pooled (they are live from the producer launch on)
+        self._deferred = []           # video-stream buffers a launch of the AUDIO stream still reads (see _cross): released at the next sync
         H.reap()
         self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
         self.aux = self._aux.torch          # audio-chain launches
@@ -174,6 +183,16 @@ class UNetEngine:
 
     def _has_stats(self, out):
         return self._tail_slice(out)[0] is not None or self._rec_slice(out)[0] is not None
+
+    def _resample_stats(self, out):
+        """The record view a resample writing `out` fills (None: no record buffer, or a column slice its 16-byte record stores cannot
+        address; MMD_RESAMPLE_STATS=0: the statistics pass - A/B)."""
+        if not _RESAMPLE_STATS:
+            return None
+        ent, c0 = self._rec_slice(out)
+        if ent is None or c0 % 8 or out.shape[1] % 8 or ent["C"] % 8:
+            return None
+        return self._stats_for(out)
 
     def _stats_kw(self, out):
         """Keyword arguments for the GEMM that writes `out`: {"tail": struct} (filled in when the consumer norm is recorded; left
@@ -418,7 +437,13 @@ class UNetEngine:
             gin = Geom.per_sample(N, rows_in // N)
             # h feeds the out_layers GroupNorm directly unless it is resampled first (up / down blocks) or shifted by the embedding
             # (non-FiLM blocks): then its producer's epilogue statistics would describe a different tensor
-            hstats = fh == 1 and ss
+            # Up blocks (round 5): everything behind the nearest upsample is pointwise - the out_layers norm (the statistics of a tensor whose
+            # every element is repeated fh * fw times ARE the statistics of the tensor), FiLM, SiLU, the 1x1x1 out conv, the skip
+            # connection (identity or 1x1x1 conv) and their sum - so up(skip(x)) + out_conv(act(norm(up(h)))) == up(skip(x) + out_conv(act(norm(h)))):
+            # the out layers run at the INPUT resolution (a quarter of the rows, h's producer statistics instead of a statistics pass) and ONE
+            # upsample writes the block's output (unet:441-448, 457-476; equal up to the rounding of the statistics sums)
+            low_out = layer["up"] and ss and _UP_LOWRES
+            hstats = (fh == 1 or low_out) and ss
             t0 = t1 = h = None
             if vid and self._vconv_fused and ops.vconv_fused_ok(x, cout, N, F, Hh, Hh):
                 # in_layers norm + SiLU, spatial 3x3 and temporal k=3 in ONE launch (ds1 level): the intermediate stays in LDS
@@ -467,20 +492,29 @@ class UNetEngine:
                               dims=(L, 1, 1), out=h, **self._stats_kw(h))
                 self._release(t0)
             xs = x
+            rs = (N * F, Hh, Hh, 2, 2, mode) if vid else (N, 1, L, 1, 4, mode)
+            conv = "video_conv" if vid else "audio_conv"
+            if low_out:
+                sk = x if cin == cout else self._pw(x, f"{p}.{mod}_skip_connection.{conv}.weight", f"{p}.{mod}_skip_connection.{conv}.bias")
+                ylow = self._alloc(rows_in, cout)
+                self._gn_pw(h, f"{p}.{mod}_out_layers.0", gin, True, f"{p}.{mod}_out_layers.3.{conv}.weight",
+                            f"{p}.{mod}_out_layers.3.{conv}.bias", film=film, residual=sk, out=ylow)
+                self._release(h)
+                if sk is not x:
+                    self._release(sk)
+                dest = self._alloc(rows_out, cout, stats=True, unit=rows_out // N) if out is None else out
+                ops.resample(ylow, dest, *rs, stats=self._resample_stats(dest))
+                self._release(ylow)
+                return dest
             if fh != 1:        # conv at the input resolution, THEN resample both h and x (unet:441-448)
-                hp, xp = self._alloc(rows_out, cout), self._alloc(rows_out, cin)
-                if vid:
-                    ops.resample(h, hp, N * F, Hh, Hh, 2, 2, mode)
-                    ops.resample(x, xp, N * F, Hh, Hh, 2, 2, mode)
-                else:
-                    ops.resample(h, hp, N, 1, L, 1, 4, mode)
-                    ops.resample(x, xp, N, 1, L, 1, 4, mode)
+                hp, xp = self._alloc(rows_out, cout, stats=ss, unit=rows_out // N), self._alloc(rows_out, cin)
+                ops.resample(h, hp, *rs, stats=self._resample_stats(hp))     # (the out_layers norm finalizes from the resample's records)
+                ops.resample(x, xp, *rs)
                 self._release(h)
                 h, xs = hp, xp
             geom = Geom.per_sample(N, rows_out // N)
             if not ss:
                 ops.add_rowbias(h, film, rows_out // N)
-            conv = "video_conv" if vid else "audio_conv"
             if cin != cout:
                 sk = self._pw(xs, f"{p}.{mod}_skip_connection.{conv}.weight", f"{p}.{mod}_skip_connection.{conv}.bias")
             else:
@@ -538,16 +572,33 @@ class UNetEngine:
         aqkv = self._gn_pw(a, p + ".a_norm", Geom.per_sample(N, L), False, p + ".a_qkv.weight", p + ".a_qkv.bias")
         ops.record_sync(1, 0)      # video queries need the audio k/v ...
         ops.record_sync(0, 1)      # ... and vice versa
+        # the video stream has now waited for everything recorded on the audio stream: the video qkv buffers that earlier blocks' AUDIO
+        # attentions were still reading go back to the video pool
+        self._release(*self._deferred)
+        self._deferred = []
         sh = self.shift_dev[layer["shift_idx"]: layer["shift_idx"] + 1] if layer["shift"] else None
         ops.cur_sid = 0
         vatt = self._alloc(N * F * HW, C)
         ops.attn(vqkv, aqkv, vatt, heads, ch, N, F, F * HW, HW, L, apf, win, shift_dev=sh)
-        ops.cur_sid = 1
-        aatt = self._alloc(N * L, C)
-        ops.attn(aqkv, vqkv, aatt, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
-        ops.record_sync(0, 1)      # both attentions retired before either stream recycles the other's qkv buffer
-        ops.record_sync(1, 0)
-        self._release(vqkv, aqkv)
+        if _CROSS_SERIAL:
+            # Round 5.  The two attentions of a block used to start together and each stream then waited for the OTHER's (buffer recycling):
+            # two MFMA-bound kernels shared the chip and the video chain - the critical path - paid for both.  Now the audio stream's
+            # attention starts BEHIND the video stream's (the audio chain has ~6 ms of slack per step), the video stream never waits for it
+            # (its proj_out follows its own attention at once), and the video qkv buffer the audio attention reads is parked until the
+            # next point where the video stream has waited for the audio stream anyway (the next block's first sync)
+            ops.record_sync(0, 1)
+            ops.cur_sid = 1
+            aatt = self._alloc(N * L, C)
+            ops.attn(aqkv, vqkv, aatt, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
+            self._release(aqkv)    # audio pool: its readers are audio-stream launches and the video attention this stream has waited for
+            self._deferred.append(vqkv)
+        else:
+            ops.cur_sid = 1
+            aatt = self._alloc(N * L, C)
+            ops.attn(aqkv, vqkv, aatt, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
+            ops.record_sync(0, 1)      # both attentions retired before either stream recycles the other's qkv buffer
+            ops.record_sync(1, 0)
+            self._release(vqkv, aqkv)
         ops.cur_sid = 0
         vo = out_v if out_v is not None else self._alloc(N * F * HW, C, stats=True, unit=F * HW)
         self._pw(vatt, p + ".video_proj_out.video_conv.weight", p + ".video_proj_out.video_conv.bias", residual=v, out=vo)
@@ -717,9 +768,20 @@ class UNetEngine:
 
         # ---- heads: GN -> SiLU -> conv (unet:1003-1012), fp32 API-layout outputs
         ops.cur_sid = 0
-        hv = self._gn(v, "video_out.0", Geom.per_sample(N, F * Hh * Hh), act=True)
-        ops.head_conv(hv, self._edge_w("video_out.2.video_conv.weight"), self._f32("video_out.2.video_conv.bias"),
-                      self.out_video, N, F, Hh, Hh, ops.TAPS_3D)
+        gh = Geom.per_sample(N, F * Hh * Hh)
+        hw = self._edge_w("video_out.2.video_conv.weight")
+        hv = None
+        if ops.head_gemm_ok(v, hw, gh):
+            # norm + SiLU in the operand registers of a GEMM over (tap, channel) outputs, then a gather over the taps (round 5)
+            ga, gb = self._gn_affine(v, "video_out.0", gh, None)
+            NO = hw.shape[0] * hw.shape[2]
+            P = self._alloc(NO, v.shape[0], torch.float32)
+            ops.head_gemm(v, ga, gb, gh, True, self._packed("head_gemm", "video_out.2.video_conv.weight", lambda: ops.head_gemm_pack(hw)), P, NO)
+            ops.head_gather(P, self._f32("video_out.2.video_conv.bias"), self.out_video, N, F, Hh, Hh, hw.shape[2], ops.TAPS_3D)
+            self._release(ga, gb, P)
+        else:
+            hv = self._gn(v, "video_out.0", gh, act=True)
+            ops.head_conv(hv, hw, self._f32("video_out.2.video_conv.bias"), self.out_video, N, F, Hh, Hh, ops.TAPS_3D)
         ops.cur_sid = 1
         ha = self._gn(a, "audio_out.0", Geom.per_sample(N, L), act=True)
         ops.head_conv(ha, self._edge_w("audio_out.2.audio_conv.weight"), self._f32("audio_out.2.audio_conv.bias"),

@@ -727,11 +727,20 @@ def attn_small_bwd(qkv, dout, dqkv, C, heads, geom: Geom):
     return dqkv
 
 
-def resample(x, out, NF, Hh, Ww, fh, fw, mode, scale=1.0):
-    """mode 0 avg-pool / 1 nearest-upsample by (1, fh, fw); Hh, Ww describe the input rows (nf, h, w)."""
+def resample(x, out, NF, Hh, Ww, fh, fw, mode, scale=1.0, stats=None):
+    """mode 0 avg-pool / 1 nearest-upsample by (1, fh, fw); Hh, Ww describe the input rows (nf, h, w).  stats (bf16, scale 1): the
+    record view [out rows / 64, C / 4, 2] that receives the GroupNorm statistics of the output (include/mmd.h: mmd_resample_stats)."""
     _chk2d(x), _chk2d(out)
+    nbytes = (x.shape[0] + out.shape[0]) * x.shape[1] * x.element_size()
+    if stats is not None:
+        if x.dtype != torch.bfloat16 or out.dtype != torch.bfloat16 or float(scale) != 1.0:
+            raise H.MMDError("resample: output statistics need bf16 rows and scale 1")
+        sp, sld = _stats_args(stats, out.shape[0], x.shape[1])
+        _dispatch("mmd_resample_stats", x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], NF, Hh, Ww, fh, fw, mode, sp, sld,
+                  meta=("resample", 0, nbytes))
+        return out
     _dispatch("mmd_resample", H.dt_of(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[1], NF, Hh, Ww,
-           fh, fw, mode, float(scale), meta=("resample", 0, (x.shape[0] + out.shape[0]) * x.shape[1] * x.element_size()))
+           fh, fw, mode, float(scale), meta=("resample", 0, nbytes))
     return out
 
 
@@ -774,6 +783,57 @@ def head_conv(x, w, bias, out, N, F, Hh, Ww, taps):
     _dispatch("mmd_head_conv", H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), out.data_ptr(), N, F,
            x.shape[1], Hh, Ww, w.shape[2], nt, arr,
            meta=("head_conv", 2 * x.shape[0] * x.shape[1] * w.shape[2] * nt, x.shape[0] * x.shape[1] * x.element_size() + out.numel() * 4))
+    return out
+
+
+# The head for few output channels as GEMM + gather (include/mmd.h: mmd_head_gemm / mmd_head_gather): GroupNorm + SiLU in the GEMM's
+# operand registers, per-row products on the matrix cores, then a coalesced gather over the taps.  MMD_HEAD_GEMM=0: gn_apply + the direct
+# kernel (A/B).
+_HEAD_GEMM = os.environ.get("MMD_HEAD_GEMM", "1") != "0"
+
+
+def head_gemm_ok(x, w, geom: Geom):
+    """Launches the GEMM + gather head accepts: bf16 rows of 128 channels, ntaps * Co <= 96, Co in (1, 2, 3, 4, 6), contiguous slices that
+    are multiples of 128 rows."""
+    return (_HEAD_GEMM and x.dtype == torch.bfloat16 and x.shape[1] == 128 and w.shape[0] * w.shape[2] <= 96 and w.shape[2] in (1, 2, 3, 4, 6)
+            and geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn % 128 == 0 and geom.S * geom.Tn == x.shape[0]
+            and x.stride(0) % 8 == 0)
+
+
+def head_gemm_pack(w):
+    """w fp32 [ntaps, Cin, Co] (pack_edge_weight) -> the (hi, lo) bf16 weight image of mmd_head_gemm: [2][3][Cin / 16][64 lanes][8],
+    lane (l31, half) of (block ob, k-step cg) = W[32 ob + l31][16 cg + 8 half .. + 8] with W[tap Co + co][ci] = w[tap][ci][co]."""
+    H.require_cuda(w)
+    nt, Cin, Co = w.shape
+    if nt * Co > 96 or Cin != 128:
+        raise H.MMDError(f"head_gemm_pack: needs ntaps * Co <= 96 and Cin == 128, got {tuple(w.shape)}")
+    full = torch.zeros(96, Cin, dtype=torch.float32, device=w.device)
+    full[: nt * Co] = w.permute(0, 2, 1).reshape(nt * Co, Cin)
+    hi = full.to(torch.bfloat16)
+    lo = (full - hi.float()).to(torch.bfloat16)
+    img = torch.stack([hi, lo]).view(2, 3, 32, Cin // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()    # (hl, ob, cg, half, l31, e)
+    assert img.numel() * 2 == H.lib().mmd_head_gemm_weight_bytes(Cin)
+    return img.view(-1)
+
+
+def head_gemm(x, a, b, geom: Geom, act, wimg, P, NO):
+    """P[o, m] = sum_ci W[o, ci] act(x[m, ci] a + b) (include/mmd.h: mmd_head_gemm); P fp32 [NO, M]."""
+    _chk2d(x)
+    M, Cin = x.shape
+    if P.dtype != torch.float32 or P.numel() < NO * M or not P.is_contiguous():
+        raise H.MMDError("head_gemm: the workspace must be a contiguous fp32 buffer of ntaps * Co * M elements")
+    if wimg.numel() * 2 != H.lib().mmd_head_gemm_weight_bytes(Cin):
+        raise H.MMDError("head_gemm: the weight image does not match Cin")
+    _dispatch("mmd_head_gemm", x.data_ptr(), x.stride(0), M, Cin, a.data_ptr(), b.data_ptr(), geom.S, geom.Tn, 1 if act else 0, wimg.data_ptr(),
+              P.data_ptr(), NO, meta=(f"head_gemm[M={M},K={Cin},N={NO}]", 4 * M * Cin * 96, 2 * M * Cin + 4 * NO * M))
+    return P
+
+
+def head_gather(P, bias, out, N, F, Hh, Ww, Co, taps):
+    """out fp32 [N, F, Co, H, W] = bias + the tap sum of the product planes P [ntaps * Co, N F H W] (include/mmd.h: mmd_head_gather)."""
+    arr, nt = H.taps_array(taps)
+    _dispatch("mmd_head_gather", P.data_ptr(), H.ptr(bias), out.data_ptr(), N, F, Hh, Ww, Co, nt, arr,
+              meta=("head_gather", 0, 4 * nt * Co * N * F * Hh * Ww + out.numel() * 4))
     return out
 
 

@@ -44,7 +44,9 @@ def replay(model, shifts):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("tag,cfgname,keyset,over", [
-    ("tiny", "tiny", "tiny", {}), ("tiny_ls", "tiny", "tiny_learn_sigma", dict(learn_sigma=True)), ("mid", "mid", "tiny", {})])
+    ("tiny", "tiny", "tiny", {}), ("tiny_ls", "tiny", "tiny_learn_sigma", dict(learn_sigma=True)), ("mid", "mid", "tiny", {}),
+    # the shipped base model at full size (round 5): the fused VideoConv / temporal-attention / head kernels only run at these shapes
+    ("full", "full", "full", {})])
 def test_forward_matches_reference(dt, tag, cfgname, keyset, over):
     g = gold(tag + "_forward")
     fl, model, _ = build(cfgname, keyset, dt, **over)

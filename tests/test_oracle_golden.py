@@ -138,6 +138,7 @@ def test_cross_attention(nm):
     ("tiny", "tiny", "tiny", {}),
     ("tiny_ls", "tiny", "tiny_learn_sigma", dict(learn_sigma=True)),
     ("mid", "mid", "tiny", {}),          # mid shares the tiny parameter shapes (same channels)
+    ("full", "full", "full", {}),        # the shipped base model at full size, one sample (round 5)
 ])
 def test_forward(tag, cfgname, keyset, over):
     g = gold(tag + "_forward")

@@ -444,6 +444,9 @@ ALL = {
     "tiny_forward": lambda: gen_forward("tiny", 2, 11, [7, 812]),
     "tiny_ls_forward": lambda: gen_forward("tiny", 2, 12, [0, 999], learn_sigma=True),
     "mid_forward": lambda: gen_forward("mid", 1, 13, [431]),
+    # the shipped base model at full size, one sample: pins the kernels that only run at the full model's shapes (fused VideoConv,
+    # fused temporal attention, GEMM + gather head, ...) against the reference at the shapes bench.py times (round 5)
+    "full_forward": lambda: gen_forward("full", 1, 14, [417]),
     "tiny_psample": lambda: gen_psample("tiny", 2, 21, "2"),
     "tiny_psample4": lambda: gen_psample("tiny", 1, 22, "4"),
     "tiny_ls_psample": lambda: gen_psample("tiny", 2, 23, "2", learn_sigma=True),
