@@ -536,6 +536,11 @@ extern "C" int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, cons
   MMD_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= Cin && ldy >= Cout && ((uintptr_t)X | (uintptr_t)Wf | (uintptr_t)Y) % 16 == 0,
               "vconv2d1d: rows must be 16-byte aligned");
   MMD_REQUIRE(((int64_t)16 * H * W - 1) * ldx * 2 + (int64_t)Cin * 2 < 0x7fffffffLL, "vconv2d1d: one sample's rows must stay below 2 GB");
+  {  // in-place / overlapping X and Y: other blocks read 3x3 halo rows a neighbouring patch has already overwritten (silent corruption)
+    const int64_t M = (int64_t)N * 16 * H * W;
+    const uintptr_t x0 = (uintptr_t)X, x1 = x0 + (uintptr_t)(((M - 1) * ldx + Cin) * 2), y0 = (uintptr_t)Y, y1 = y0 + (uintptr_t)(((M - 1) * ldy + Cout) * 2);
+    MMD_REQUIRE(x1 <= y0 || y1 <= x0, "vconv2d1d: X and Y overlap (in-place / slices of one buffer are not supported)");
+  }
   MMD_REQUIRE((gn_a == nullptr) == (gn_b == nullptr), "vconv2d1d: gn_a and gn_b come together");
   MMD_REQUIRE(!gn_a || (S > 0 && rows_per_slice > 0 && rows_per_slice % ((int64_t)16 * H * W) == 0 && (int64_t)S * rows_per_slice == (int64_t)N * 16 * H * W),
               "vconv2d1d: the fused input norm needs slices of whole samples covering the tensor (S=%d rows=%lld)", S, (long long)rows_per_slice);

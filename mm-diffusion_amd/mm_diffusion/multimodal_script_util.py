@@ -115,12 +115,11 @@ def add_dict_to_argparser(parser, default_dict):
 
 
 def args_to_dict(args, keys):
-    """The scripts turn their parsed flags into factory keywords with this (right after parse_args, long before the sampling loop):
-    the one place to say EARLY that a --ref_path run will get no FVD / KVD / FAD numbers at its end (evaluator.py)."""
-    if getattr(args, "ref_path", ""):
-        import warnings
-        from .evaluator import unavailable_message
-        warnings.warn(unavailable_message(args.ref_path) + "; the samples will be written, the metrics skipped", RuntimeWarning, stacklevel=2)
+    """The scripts turn their parsed flags into factory keywords with this, right after parse_args and long before the sampling loop - the
+    one call every unchanged script makes early enough to say that a --ref_path run will get no FVD / KVD / FAD numbers at its end
+    (evaluator.warn_metrics_unavailable: an explicit, once-per-path notice)."""
+    from .evaluator import warn_metrics_unavailable
+    warn_metrics_unavailable(getattr(args, "ref_path", ""))
     return {k: getattr(args, k) for k in keys}
 
 

@@ -575,6 +575,10 @@ def vconv2d1d(x, wf, bias_s, bias_t, N, F, Hh, Ww, a=None, b=None, geom=None, ac
         raise H.MMDError("vconv2d1d: the fused input norm needs contiguous slices of whole samples")
     out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
+    if out.data_ptr() == x.data_ptr() or tuple(out.shape) != (M, Cout) or out.dtype != x.dtype:
+        raise H.MMDError("vconv2d1d: the output must be a distinct bf16 [M, 128] tensor (in-place is not supported)")
+    if wf.numel() * wf.element_size() != H.lib().mmd_vconv2d1d_weight_bytes(Cin):
+        raise H.MMDError("vconv2d1d: the weight image does not match Cin (pack it with vconv_pack)")
     sp, sld = (None, 0) if stats is None else _stats_args(stats, M, Cout)
     flops = 2 * M * Cout * (9 * Cin + 3 * Cout)
     nbytes = 2 * (M * Cin + M * Cout + Cout * (9 * Cin + 3 * Cout)) + 8 * Cout

@@ -48,22 +48,37 @@ def test_script_import_surface_resolves(surface):
 
 
 def test_evaluator_counterpart_does_not_cost_the_samples(monkeypatch):
-    """The reference script calls eval_multimodal AFTER the sampling loop (sample_sr.py:268): the counterpart warns and returns no
-    metrics instead of throwing the finished samples away; MMD_EVAL_STRICT=1 makes it an error; the flag parser warns up front."""
+    """The reference sampling script calls eval_multimodal AFTER the sampling loop (sample_sr.py:268): there the counterpart logs an error,
+    warns and returns a sentinel (never an empty dict) instead of throwing the finished samples away; a metrics-only run (eval.py) and
+    MMD_EVAL_STRICT=1 make it an error; the flag parser gives the early notice once per path."""
     import argparse
     from mm_diffusion import evaluator, multimodal_script_util as msu
     monkeypatch.delenv("MMD_EVAL_STRICT", raising=False)
+    monkeypatch.setattr(sys, "argv", ["py_scripts/multimodal_sample_sr.py"])
     with pytest.warns(RuntimeWarning, match="out of scope"):
-        assert evaluator.eval_multimodal("/ref", "/fake", eval_num=8) == {}
+        assert evaluator.eval_multimodal("/ref", "/fake", eval_num=8) == {"unavailable": True}
+    monkeypatch.setattr(sys, "argv", ["py_scripts/eval.py"])            # nothing but the metrics at stake: fail
+    with pytest.raises(evaluator.EvaluatorUnavailable, match="out of scope"):
+        evaluator.eval_multimodal("/ref", "/fake", eval_num=8)
+    monkeypatch.setenv("MMD_EVAL_STRICT", "0")                           # explicit override
+    with pytest.warns(RuntimeWarning):
+        assert evaluator.eval_multimodal("/ref", "/fake")["unavailable"] is True
+    monkeypatch.setattr(sys, "argv", ["py_scripts/multimodal_sample_sr.py"])
     monkeypatch.setenv("MMD_EVAL_STRICT", "1")
     with pytest.raises(evaluator.EvaluatorUnavailable, match="out of scope"):
         evaluator.eval_multimodal("/ref", "/fake", eval_num=8)
     import inspect
     sig = inspect.signature(evaluator.eval_multimodal)
     assert list(sig.parameters) == ["real_path", "fake_path", "video_size", "eval_num"] and sig.parameters["eval_num"].default == 2048
+    evaluator._warned.clear()
     ns = argparse.Namespace(ref_path="/data/landscape/test", num_channels=128)
     with pytest.warns(RuntimeWarning, match="out of scope"):
         assert msu.args_to_dict(ns, ["num_channels"]) == {"num_channels": 128}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                  # the notice is given once per path
+        assert msu.args_to_dict(ns, ["num_channels"]) == {"num_channels": 128}
+        assert msu.args_to_dict(argparse.Namespace(num_channels=64), ["num_channels"]) == {"num_channels": 64}
 
 
 def test_bench_self_launches_its_ranks():

@@ -139,3 +139,23 @@ def test_vconv_rejects_unsupported(ops):
     x = torch.zeros(8 * 8 * 8, 64, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(H.MMDError):
         ops.vconv2d1d(x, x, None, None, 1, 8, 8, 8)
+
+
+def test_vconv_rejects_aliased_output_and_wrong_weight_image(ops):
+    """In-place / overlapping buffers would let a block read halo rows a neighbour has already overwritten; a weight image packed for
+    another Cin would be read past its end (round-4 advisor finding)."""
+    from mm_diffusion import _hip as H
+    N, F, Hh, Ww, C = 1, 16, 8, 8, 128
+    x = torch.zeros(N * F * Hh * Ww, C, device="cuda", dtype=torch.bfloat16)
+    ws = torch.zeros(128, 9 * C, device="cuda", dtype=torch.bfloat16)
+    wt = torch.zeros(128, 384, device="cuda", dtype=torch.bfloat16)
+    wf = ops.vconv_pack(ws, wt)
+    bs, bt = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
+    with pytest.raises(H.MMDError):
+        ops.vconv2d1d(x, wf, bs, bt, N, F, Hh, Ww, out=x)                         # in place
+    wide = torch.zeros(N * F * Hh * Ww, 2 * C, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(H.MMDError):
+        ops.vconv2d1d(wide[:, :C], wf, bs, bt, N, F, Hh, Ww, out=wide[:, C:])     # two slices of one buffer: rejected by the C side
+    with pytest.raises(H.MMDError):
+        ops.vconv2d1d(x, wf[: wf.numel() // 2], bs, bt, N, F, Hh, Ww)             # weight image of the wrong size
+    ops.vconv2d1d(x, wf, bs, bt, N, F, Hh, Ww)                                    # (the plain call still runs)
