@@ -208,8 +208,8 @@ int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, const float* gn
  * (16 frames, C / 32 channels) of a pixel, qkv / proj_out 1x1 convs, QKVAttention unet:290-330 with 1 / sqrt(ch) scaling).  Replaces
  * mmd_gn_small + mmd_conv_gemm (qkv) + mmd_attn_small_fwd + mmd_conv_gemm (proj_out, residual): the normalised tensor, the qkv tensor
  * and the attention output never exist in HBM (q, k, v and the attention output are rounded to bf16 exactly where the unfused path
- * stores them).  bf16; X / Y rows (n, f, pixel) x C with row strides ldx / ldy, Y != X; built for F == 16, heads == 4, C in {256, 384,
- * 512} (head widths 64 / 96 / 128), HW % 8 == 0.  Wf: the image of mmd_tattn_pack (mmd_tattn_weight_bytes(C, with_pre) bytes) built
+ * stores them).  bf16; X / Y rows (n, f, pixel) x C with row strides ldx / ldy, Y != X; built for F == 16, heads == 4, C == 256
+ * (head width 64: the ds2 level; the 384 / 512-channel instances of round 4 were removed in round 5), HW % 8 == 0.  Wf: the image of mmd_tattn_pack (mmd_tattn_weight_bytes(C, with_pre) bytes) built
  * from the qkv weight [3 C, C] (rows q | k | v, head h = rows h ch .. of each third) and the proj_out weight [C, C], both bf16
  * row-major.  bias_qkv [3 C], bias_proj / gamma / beta [C] fp32.  stats (nullable): quad statistics records of Y for the GroupNorm
  * that consumes it, one per 64 rows in THIS kernel's row order inside a sample (record n HW / 4 + (pixel >> 2): the 16 frames of 4

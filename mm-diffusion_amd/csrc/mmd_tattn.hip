@@ -1,4 +1,5 @@
-// Fused temporal-attention block of the video stream (bf16, 4 heads, 16 frames; C = 256 / 384 / 512 channels): ONE launch for
+// Fused temporal-attention block of the video stream (bf16, 4 heads, 16 frames; C = 256 channels - the ds2 level; the C = 384 / 512
+// instances of rounds 4 were REMOVED in round 5: built, tested and measured slower than the four launches at ds4 / ds8): ONE launch for
 //     y = x + proj_out( attention_over_frames( qkv( GroupNorm32(x) ) ) )
 // i.e. SingleModalAtten with the rows of a pixel as the sequence (/root/reference/mm_diffusion/multimodal_unet.py:246-287, used at
 // :485-493; GroupNorm32 = nn.py:16-33; QKVAttention = unet:290-330) - and, optionally, the proj_out + residual of the SPATIAL
@@ -16,10 +17,7 @@
 //     (lane (l31, half): channels 16 cg + 8 half .. + 8 of its row, cg < C / 16) - like the row-strip GEMM, the activations are
 //     stationary and the weights stream through LDS;
 //   * GroupNorm32 over (16 frames x C / 32 channels) of a pixel, two-pass like mmd_gn_small.  C = 256: a group is the lane's own
-//     8-channel vector and the 16 frames are the 16 lanes of a DPP row -> two row reductions per vector.  C = 384 / 512 (groups of 12 /
-//     16 channels = 3 / 4 quads that straddle vectors, half-waves and k-steps): per-quad row reductions, the quad totals of the wave's
-//     two pixels go through a wave-private LDS table, 64 lanes fold them into the 2 x 32 group moments, every lane reads back the two
-//     it needs per vector;
+//     8-channel vector and the 16 frames are the 16 lanes of a DPP row -> two row reductions per vector;
 //   * q, k   : D = W x^T (A = weight fragment, B = x): lane (row, half) ends up with channels 8 q + 4 half + j of its row (i = 4 q + j);
 //     packing i = 8 s .. 8 s + 7 gives the operand of k-step s, and q and k carry the SAME channel in the same (half, element) slot,
 //     which is all the contraction S^T = k q^T (A = k, B = q) needs;
@@ -45,9 +43,8 @@
 // s_barrier per chunk; the weight fragments of K step st + 1 are read before the MFMAs of step st.
 // Workgroup = 4 waves = 128 rows.  C = 256: 72 KB of LDS, <= 256 VGPRs, TWO workgroups per CU with independent barriers (measured,
 // tools/tattn_bench.py, 65536 rows: 50 us against 107 us for the four launches; 256-row workgroups of 8 waves with three stages:
-// 49 us there but 38 against 28 us at 16384 rows; 4 waves x 64 rows at one wave per SIMD: 56 us).  C = 384 / 512: x, the attention
-// output and a head's q / k / v are ~350 / ~430 VGPRs: one wave per SIMD - slower per row, but those levels have 16384 / 4096 rows
-// and their five launches cost 5 x (launch + first-operand latency); one launch does not.
+// 49 us there but 38 against 28 us at 16384 rows; 4 waves x 64 rows at one wave per SIMD: 56 us).  (C = 384 / 512 - head widths 96 / 128 -
+// needed ~350 / ~430 VGPRs, one wave per SIMD: ds4 50 vs 63 us alone and neutral in the step, ds8 74 vs 44 us; removed.)
 // SQ counters at C = 256 (profiles/r04_tattn_pmc_sq.txt): ~7.6 VALU instructions per MFMA (bias, pack, norm, softmax, epilogue), MFMA
 // pipe busy 25 % of the SIMD cycles: bound by VALU issue + dependency stalls at two waves per SIMD, not by the matrix pipe.
 #include "mmd_common.h"
@@ -274,7 +271,8 @@ __global__ __launch_bounds__(256, (C == 256 ? 2 : 1)) void tattn_kernel(const TA
   const int64_t ldres = PRE ? p.ldm : p.ldx;
 
   // ---- GroupNorm32 over (16 frames, C / 32 channels) of a pixel, two-pass like mmd_gn_small, applied in place
-  if constexpr (C == 256) {
+  static_assert(C == 256, "groups of 8 channels: one 8-channel vector per group (the 384 / 512-channel instances - groups of 12 / 16 channels through a wave-private LDS table - were removed in round 5: measured slower than the four launches at ds4 / ds8)");
+  {
 #pragma unroll
     for (int cg = 0; cg < NK; ++cg) {
       float x[8];
@@ -300,72 +298,6 @@ __global__ __launch_bounds__(256, (C == 256 ? 2 : 1)) void tattn_kernel(const TA
       }
       u32x4 y = Elt<__bf16>::pack(x);
       asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));     // pin: keep the arithmetic here, not sunk into the MFMA loop
-      xa[cg] = y;
-    }
-  } else {
-    constexpr int QPG = G::QPG, NQ = C / 4;
-    constexpr float inv_cnt = 1.f / (16.f * (float)(C / 32));
-    float* sQw = sQ + wave * 2 * NQ;                       // [2 pixels][NQ]
-    float* sMw = sM + wave * 2 * 32 * 2;                   // [2 pixels][32][mean, rstd]
-    const int pix = l31 >> 4;
-    const bool writer = (l31 & 15) == 0;
-    // pass 1: quad sums over the frames
-#pragma unroll
-    for (int cg = 0; cg < NK; ++cg) {
-      float x[8];
-      Elt<__bf16>::unpack(xa[cg], x);
-      const float s0 = ta_row16_total((x[0] + x[1]) + (x[2] + x[3])), s1 = ta_row16_total((x[4] + x[5]) + (x[6] + x[7]));
-      if (writer) { sQw[pix * NQ + 4 * cg + 2 * half] = s0; sQw[pix * NQ + 4 * cg + 2 * half + 1] = s1; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {                                                      // lane (pixel = half, group = l31): the group's mean
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < QPG; ++k) a += sQw[half * NQ + l31 * QPG + k];
-      sMw[(half * 32 + l31) * 2] = a * inv_cnt;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // pass 2: centred squares per quad
-#pragma unroll
-    for (int cg = 0; cg < NK; ++cg) {
-      float x[8];
-      Elt<__bf16>::unpack(xa[cg], x);
-      const int q0 = 4 * cg + 2 * half;
-      const float m0 = sMw[(pix * 32 + q0 / QPG) * 2], m1 = sMw[(pix * 32 + (q0 + 1) / QPG) * 2];
-      float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d0 = x[e] - m0, d1 = x[4 + e] - m1; t0 += d0 * d0; t1 += d1 * d1; }
-      t0 = ta_row16_total(t0);
-      t1 = ta_row16_total(t1);
-      if (writer) { sQw[pix * NQ + q0] = t0; sQw[pix * NQ + q0 + 1] = t1; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < QPG; ++k) a += sQw[half * NQ + l31 * QPG + k];
-      sMw[(half * 32 + l31) * 2 + 1] = rsqrtf(a * inv_cnt + p.eps);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int cg = 0; cg < NK; ++cg) {
-      float x[8];
-      Elt<__bf16>::unpack(xa[cg], x);
-      const int q0 = 4 * cg + 2 * half;
-      const float* gp = sG + cg * 16 + half * 8;
-#pragma unroll
-      for (int h4 = 0; h4 < 2; ++h4) {
-        const float2 mr = *(const float2*)(sMw + (pix * 32 + (q0 + h4) / QPG) * 2);
-        const f32x4 g4 = *(const f32x4*)(gp + 4 * h4), b4 = *(const f32x4*)(gp + C + 4 * h4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float av = mr.y * g4[k];
-          const float bv = b4[k] - mr.x * av;
-          x[4 * h4 + k] = x[4 * h4 + k] * av + bv;
-        }
-      }
-      u32x4 y = Elt<__bf16>::pack(x);
-      asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));
       xa[cg] = y;
     }
   }
@@ -511,7 +443,7 @@ static int tattn_nchunk(int C, int with_pre) {
 }
 
 extern "C" int64_t mmd_tattn_weight_bytes(int C, int with_pre) {
-  if (C != 256 && C != 384 && C != 512) return 0;
+  if (C != 256) return 0;
   return (int64_t)tattn_nchunk(C, with_pre) * (C / 64) * tattn_cch(C) * 128;
 }
 
@@ -519,7 +451,7 @@ extern "C" int64_t mmd_tattn_weight_bytes(int C, int with_pre) {
 // SingleModalAtten.qkv / .proj_out of the temporal block (unet:263-266) and .proj_out of the spatial block in front of it
 extern "C" int mmd_tattn_pack(const void* Wpre, const void* Wqkv, const void* Wproj, void* out, int C, void* stream) {
   MMD_REQUIRE(Wqkv && Wproj && out, "tattn_pack: null pointer");
-  MMD_REQUIRE(C == 256 || C == 384 || C == 512, "tattn_pack: C in {256, 384, 512} (got %d)", C);
+  MMD_REQUIRE(C == 256, "tattn_pack: built for C = 256 (got %d)", C);
   const int64_t chunks16 = mmd_tattn_weight_bytes(C, Wpre != nullptr) / 16;
   hipLaunchKernelGGL(tattn_pack_kernel, dim3((unsigned)((chunks16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Wpre,
                      (const uint16_t*)Wqkv, (const uint16_t*)Wproj, (uint16_t*)out, C, tattn_cch(C), Wpre ? 1 : 0);
@@ -551,8 +483,7 @@ extern "C" int mmd_tattn_block(const void* X, int64_t ldx, const void* A, int64_
                                const float* beta, float eps, void* Y, int64_t ldy, int N, int F, int HW, int C, int heads, float* stats,
                                int64_t stats_ld, void* stream) {
   MMD_REQUIRE(X && Wf && bias_qkv && bias_proj && gamma && beta && Y, "tattn_block: null pointer");
-  MMD_REQUIRE(F == 16 && (C == 256 || C == 384 || C == 512) && heads == 4,
-              "tattn_block: built for 16 frames, 4 heads, 256 / 384 / 512 channels (got F=%d C=%d heads=%d)", F, C, heads);
+  MMD_REQUIRE(F == 16 && C == 256 && heads == 4, "tattn_block: built for 16 frames, 4 heads, 256 channels (got F=%d C=%d heads=%d)", F, C, heads);
   MMD_REQUIRE(N > 0 && HW > 0 && HW % 8 == 0, "tattn_block: the pixels of a frame must be a multiple of 8 (N=%d HW=%d)", N, HW);
   MMD_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C && ((uintptr_t)X | (uintptr_t)Y | (uintptr_t)Wf) % 16 == 0,
               "tattn_block: 16-byte aligned rows");
@@ -570,7 +501,5 @@ extern "C" int mmd_tattn_block(const void* X, int64_t ldx, const void* A, int64_
   p.sc = 1.44269504088896f * (1.0f / sqrtf((float)(C / 4)));
   p.stats = stats; p.stats_ld = stats_ld;
   hipStream_t st = (hipStream_t)stream;
-  if (C == 256) return A ? launch_tattn<256, true>(p, st) : launch_tattn<256, false>(p, st);
-  if (C == 384) return A ? launch_tattn<384, true>(p, st) : launch_tattn<384, false>(p, st);
-  return A ? launch_tattn<512, true>(p, st) : launch_tattn<512, false>(p, st);
+  return A ? launch_tattn<256, true>(p, st) : launch_tattn<256, false>(p, st);
 }

@@ -106,7 +106,14 @@ class UNetEngine:
         self._tail_static = []        # affine tables written by producers: never pooled (they are live from the producer launch on)
         self._deferred = []           # video-stream buffers a launch of the AUDIO stream still reads (see _cross): released at the next sync
         H.reap()
-        self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
+        if os.environ.get("MMD_STREAM_PRIO") == "1":      # EXPERIMENT (round 5): audio chain on a low-priority stream, capture origin / video chain high
+            os.environ["MMD_NEXT_STREAM_PRIO"] = "low"
+            self._aux = H.Stream(self.device)
+            os.environ["MMD_NEXT_STREAM_PRIO"] = "high"
+            self._side = H.Stream(self.device)
+            os.environ.pop("MMD_NEXT_STREAM_PRIO")
+        else:
+            self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
         self.aux = self._aux.torch          # audio-chain launches
         self.side = self._side.torch        # capture stream (graphs of this engine and of the samplers driving it)
         self.keep = []          # packed weights etc. (kept alive)
@@ -187,7 +194,7 @@ class UNetEngine:
     def _resample_stats(self, out):
         """The record view a resample writing `out` fills (None: no record buffer, or a column slice its 16-byte record stores cannot
         address; MMD_RESAMPLE_STATS=0: the statistics pass - A/B)."""
-        if not _RESAMPLE_STATS:
+        if not _RESAMPLE_STATS or self.dtype != torch.bfloat16:       # (MMD_GN_EPILOGUE=2 gives fp32 plans record buffers: bf16 kernel only)
             return None
         ent, c0 = self._rec_slice(out)
         if ent is None or c0 % 8 or out.shape[1] % 8 or ent["C"] % 8:

@@ -62,6 +62,11 @@ def record_sync(src, dst):
     _recorder.append((None, (src, dst, ev), "sync", None, -1, ""))
 
 
+# EXPERIMENT switch (timing only, never set by the product or the tests): MMD_SKIP_SID=0 / 1 drops the launches of the video / audio
+# chain from a replayed plan - the step time without one chain bounds what that chain costs the other (interference + waits)
+_SKIP_SID = int(os.environ["MMD_SKIP_SID"]) if os.environ.get("MMD_SKIP_SID", "") in ("0", "1") else None
+
+
 def run_plan(plan, stream, aux_stream=None):
     """Replay a recorded plan.  With aux_stream the audio-stream ops run there (fork/join through events, also
     valid under stream capture); without it everything runs in recording order on `stream` (markers are no-ops)."""
@@ -73,6 +78,8 @@ def run_plan(plan, stream, aux_stream=None):
                 src, dst, ev = args
                 if lib.mmd_event_record(ev, streams[src]) or lib.mmd_stream_wait_event(streams[dst], ev):
                     raise H.MMDError(f"sync failed: {lib.mmd_last_error().decode()}")
+            continue
+        if _SKIP_SID is not None and sid == _SKIP_SID:
             continue
         rc = fn(*args, streams[sid])
         if rc != 0:
@@ -634,25 +641,21 @@ def tconv(x, wf, bias, Cout, N, F, HW, out=None, stats=None):
 
 
 # The temporal-attention block in one launch (include/mmd.h: mmd_tattn_block): GroupNorm over a pixel's frames, qkv, attention over the
-# frames, proj_out and the residual - instead of gn_small + qkv GEMM + attn_small + proj_out GEMM.  Built for 256 / 384 / 512 channels,
-# 4 heads, 16 frames; used where it pays (_TATTN_LEVELS); like every kernel choice it depends on the layer's geometry only.
-# MMD_TATTN_FUSED=0: the four-launch path (A/B).
+# frames, proj_out and the residual - instead of gn_small + qkv GEMM + attn_small + proj_out GEMM.  Built for 256 channels (the ds2
+# level), 4 heads, 16 frames; like every kernel choice it depends on the layer's geometry only.  (The 384 / 512-channel instances of
+# round 4 - ds4 neutral in the step, ds8 74 vs 44 us - were removed in round 5.)  MMD_TATTN_FUSED=0: the four-launch path (A/B).
 _TATTN_FUSED = os.environ.get("MMD_TATTN_FUSED", "1") != "0"
 # the spatial block's proj_out + residual as the front stage of the same launch (MMD_TATTN_PRE=0: its own strip GEMM; A/B)
 _TATTN_PRE = os.environ.get("MMD_TATTN_PRE", "1") != "0"
-# channel counts (levels) the engine uses the fused block at: 256 = ds2.  The kernel is also built and tested for 384 / 512 channels (ds4 /
-# ds8: head widths 96 / 128 need one wave per SIMD), measured round 4: ds4 50 vs 63 us alone, neutral in the step; ds8 74 vs 44 us, a
-# loss (MMD_TATTN_LEVELS=256,384,512: A/B)
-_TATTN_LEVELS = tuple(int(v) for v in os.environ.get("MMD_TATTN_LEVELS", "256").split(",") if v)
 
 
 def tattn_shape_ok(x, heads, N, F, HW):
-    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] in (256, 384, 512) and heads == 4 and F == 16 and HW % 8 == 0
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and heads == 4 and F == 16 and HW % 8 == 0
             and x.shape[0] == N * F * HW and x.stride(1) == 1 and x.stride(0) % 8 == 0)
 
 
 def tattn_fused_ok(x, heads, N, F, HW):
-    return _TATTN_FUSED and tattn_shape_ok(x, heads, N, F, HW) and x.shape[1] in _TATTN_LEVELS
+    return _TATTN_FUSED and tattn_shape_ok(x, heads, N, F, HW)
 
 
 def tattn_pack(wqkv, wproj, wpre=None):
@@ -662,15 +665,15 @@ def tattn_pack(wqkv, wproj, wpre=None):
     C = wproj.shape[0]
     mats = [(wqkv, (3 * C, C)), (wproj, (C, C))] + ([(wpre, (C, C))] if wpre is not None else [])
     for w, shape in mats:
-        if C not in (256, 384, 512) or w.dtype != torch.bfloat16 or tuple(w.shape) != shape or not w.is_contiguous():
-            raise H.MMDError(f"tattn_pack: expected contiguous bf16 {shape} with C in (256, 384, 512), got {tuple(w.shape)} {w.dtype}")
+        if C != 256 or w.dtype != torch.bfloat16 or tuple(w.shape) != shape or not w.is_contiguous():
+            raise H.MMDError(f"tattn_pack: expected contiguous bf16 {shape} with C = 256, got {tuple(w.shape)} {w.dtype}")
     out = torch.empty(H.lib().mmd_tattn_weight_bytes(C, 0 if wpre is None else 1) // 2, dtype=torch.bfloat16, device=wqkv.device)
     H.call("mmd_tattn_pack", H.ptr(wpre), wqkv.data_ptr(), wproj.data_ptr(), out.data_ptr(), C, H.stream_handle())
     return out
 
 
 def tattn_block(x, wf, bias_qkv, bias_proj, gamma, beta, heads, N, F, HW, out=None, stats=None, pre=None):
-    """x [N*F*HW, C] bf16 (C = 256 / 384 / 512) -> x + proj_out(temporal attention(qkv(GroupNorm32(x)))) (include/mmd.h:
+    """x [N*F*HW, C] bf16 (C = 256) -> x + proj_out(temporal attention(qkv(GroupNorm32(x)))) (include/mmd.h:
     mmd_tattn_block).  stats: the output's record view [M / 64, C / 4, 2] (records in the kernel's own row order inside a sample).  pre = (att, bias_pre, mid): the
     front stage - the block's input is x + att Wpre^T + bias_pre (wf packed with wpre), written to the scratch `mid`."""
     _chk2d(x)

@@ -12,7 +12,7 @@ from helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-C, HEADS, F = 256, 4, 16          # (C: the default of the helpers below; the kernel is built for 256 / 384 / 512)
+C, HEADS, F = 256, 4, 16          # (the kernel is built for 256 channels: the ds2 level; the 384 / 512 instances were removed in round 5)
 
 
 @pytest.fixture(scope="module")
@@ -62,8 +62,7 @@ def _four_launch(ops, x, wqkv, wproj, bqkv, bproj, gamma, beta, N, HW, C=C):
     return ops.conv_gemm(att, wproj, bproj, residual=x)
 
 
-@pytest.mark.parametrize("N,HW,C", [(1, 16, 256), (2, 64, 256), (1, 1024, 256), (3, 48, 256), (1, 8, 384), (2, 256, 384), (1, 8, 512), (4, 64, 512),
-                                    (3, 40, 384)])
+@pytest.mark.parametrize("N,HW,C", [(1, 16, 256), (2, 64, 256), (1, 1024, 256), (3, 48, 256), (1, 8, 256), (4, 40, 256)])
 def test_tattn_block_vs_torch_and_the_four_launch_path(ops, N, HW, C):
     x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(N, HW, 100 * N + HW + C, C)
     wf = ops.tattn_pack(wqkv, wproj)
@@ -83,7 +82,7 @@ def test_tattn_block_vs_torch_and_the_four_launch_path(ops, N, HW, C):
     assert e_fused < 1.2 * e_four + 1e-3, (e_fused, e_four)
 
 
-@pytest.mark.parametrize("N,HW,C", [(1, 16, 256), (2, 256, 256), (2, 64, 384), (2, 64, 512)])
+@pytest.mark.parametrize("N,HW,C", [(1, 16, 256), (2, 256, 256), (3, 40, 256)])
 def test_tattn_front_stage_is_the_spatial_proj_out(ops, N, HW, C):
     """pre = (att, bias, mid): the block's input is x + att Wpre^T + bias, i.e. the spatial block's proj_out 1x1 conv + residual in
     front (unet:485-490).  Same K order, same epilogue arithmetic and the same bf16 rounding as the row-strip GEMM, then the same
@@ -107,7 +106,7 @@ def test_tattn_front_stage_is_the_spatial_proj_out(ops, N, HW, C):
         assert torch.equal(rec0, rec1)
 
 
-@pytest.mark.parametrize("C", [256, 384, 512])
+@pytest.mark.parametrize("C", [256])
 def test_tattn_statistics_records(ops, C):
     N, HW = 2, 64
     x, wqkv, wproj, bqkv, bproj, gamma, beta = _case(N, HW, 7 + C, C)
@@ -166,6 +165,9 @@ def test_tattn_rejects_unsupported(ops):
         ops.tattn_block(x[:, :128], wf, bqkv, bproj, gamma, beta, HEADS, 1, F, 16)       # 128 channels
     with pytest.raises(H.MMDError):
         ops.tattn_pack(wqkv[:, :128].contiguous(), wproj)
+    with pytest.raises(H.MMDError):                                                       # 384 channels: the instance was removed in round 5
+        x3 = torch.zeros(F * 16, 384, device="cuda", dtype=BF)
+        ops.tattn_block(x3, wf, bqkv, bproj, gamma, beta, HEADS, 1, F, 16)
     with pytest.raises(H.MMDError):                                                       # HW % 8 (straight through the C-ABI)
         H.call("mmd_tattn_block", x.data_ptr(), 256, None, 0, None, 0, wf.data_ptr(), None, bqkv.data_ptr(), bproj.data_ptr(), gamma.data_ptr(),
                beta.data_ptr(), 1e-5, torch.empty_like(x).data_ptr(), 256, 1, 16, 20, 256, 4, None, 0, H.stream_handle())
@@ -176,30 +178,31 @@ def test_tattn_rejects_unsupported(ops):
 
 
 def test_engine_plan_uses_the_fused_temporal_attention(monkeypatch):
-    """The headline architecture (batch 1) with and without MMD_TATTN_FUSED: the default plan carries mmd_tattn_block at the ds2 level
-    and three launches fewer per block.  Two bf16 plans of this depth differ by ~1e-2 whatever the reason (synthetic weights amplify
-    rounding noise), so each is measured against the fp32 engine: the fused plan must not be further from it than the unfused one."""
-    from helpers import flags, inputs
+    """The headline architecture (batch 1) with and without MMD_TATTN_FUSED on the REFERENCE-generated full-size fixture
+    (tests/golden/full_forward.npz, round 5): the default plan carries mmd_tattn_block at the ds2 level and three launches fewer per block;
+    both plans sit inside the bf16 forward bound against the reference, and the fused plan is not further from it than the unfused one."""
+    from helpers import flags, gold, inputs, synth_sd
     from mm_diffusion import multimodal_script_util as msu, ops as o
-    from mm_diffusion.synth import synth_init_
-    import random
+    g = gold("full_forward")
     outs = []
-    for fp16, on in ((False, True), (True, True), (True, False)):
-        fl = flags("full", use_fp16=fp16)
+    for on in (True, False):
+        fl = flags("full", use_fp16=True)
         monkeypatch.setattr(o, "_TATTN_FUSED", on)
         model, _ = msu.create_model_and_diffusion(**fl)
-        synth_init_(model)
+        model.load_state_dict(synth_sd("full"))
         model.cuda().eval()
-        v, a = inputs(fl, 1, 3)
-        random.seed(5)
+        v, a = inputs(fl, int(g["B"]), int(g["seed"]))
+        it = iter(int(s) for s in g["shifts"])
+        model.shift_source = lambda lo, hi: next(it)
         with torch.no_grad():
-            ov, oa = model(v.cuda(), a.cuda(), torch.tensor([417]).cuda())
+            ov, oa = model(v.cuda(), a.cuda(), torch.from_numpy(g["t"]).cuda())
         names = [e[2] for e in next(iter(model._engines.values())).plan]
         outs.append((ov.float().cpu(), oa.float().cpu(), names.count("mmd_tattn_block"), names.count("mmd_attn_small_fwd"), len(names)))
         model.release_engines()
-    ref, fused, unfused = outs
-    assert ref[2] == 0 and fused[2] > 0 and unfused[2] == 0 and fused[3] == unfused[3] - fused[2], [o_[2:] for o_ in outs]
+    fused, unfused = outs
+    assert fused[2] > 0 and unfused[2] == 0 and fused[3] == unfused[3] - fused[2], [o_[2:] for o_ in outs]
     assert fused[4] <= unfused[4] - 3 * fused[2]          # (4 per block with the spatial proj_out riding along, MMD_TATTN_PRE)
-    for k in (0, 1):
-        e_f, e_u = rel_l2(fused[k], ref[k].numpy()), rel_l2(unfused[k], ref[k].numpy())
-        assert e_f < 1.3 * e_u + 2e-3 and e_f < 3e-2, (k, e_f, e_u)
+    for k, ref in ((0, g["video_out"]), (1, g["audio_out"])):
+        e_f, e_u = rel_l2(fused[k], ref), rel_l2(unfused[k], ref)
+        print(f"fused temporal attention vs the reference fixture: fused {e_f:.3e} unfused {e_u:.3e}")
+        assert e_f < 2.5e-2 and e_u < 2.5e-2 and e_f < 1.3 * e_u + 2e-3, (k, e_f, e_u)

@@ -32,7 +32,7 @@ def timed(fn, n=20):
 
 def main():
     heads, F = 4, 16
-    for N, HW, C in ((4, 1024, 256), (4, 256, 384), (4, 64, 512), (1, 1024, 256)):
+    for N, HW, C in ((4, 1024, 256), (1, 1024, 256), (4, 256, 256)):      # (the 384 / 512-channel instances were removed in round 5)
         M = N * F * HW
         g = torch.Generator(device="cuda").manual_seed(0)
         x = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
