@@ -1,6 +1,5 @@
 // Error plumbing, version and HIP-graph capture helpers of the C-ABI.
 #include "mmd_common.h"
-#include <cstdlib>
 #include <string.h>
 #include <execinfo.h>
 #include <signal.h>
@@ -36,9 +35,7 @@ extern "C" int mmd_graph_end(void* stream, void** exec_out) {
   hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
   if (e != hipSuccess || !g) return mmd_set_error(MMD_ERR_LAUNCH, "graph_end: %s", hipGetErrorString(e));
   hipGraphExec_t ex = nullptr;
-  const char* np = getenv("MMD_GRAPH_NODE_PRIO");      // EXPERIMENT (round 5): run the graph with the per-node priorities its nodes captured
-  if (np && np[0] == '1') e = hipGraphInstantiateWithFlags(&ex, g, hipGraphInstantiateFlagUseNodePriority);
-  else e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
   if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "graph_instantiate: %s", hipGetErrorString(e));
   *exec_out = (void*)ex;
@@ -58,15 +55,7 @@ extern "C" int mmd_graph_destroy(void* exec) {
 // library's fork/join never aliases a stream of the framework's pool
 extern "C" int mmd_stream_create(void** stream_out) {
   hipStream_t s = nullptr;
-  // EXPERIMENT (round 5, tools/round5_calls/r05_call2.sh): MMD_NEXT_STREAM_PRIO=high|low, set by the host mirror around the call
-  const char* pr = getenv("MMD_NEXT_STREAM_PRIO");
-  hipError_t e;
-  if (pr && (pr[0] == 'h' || pr[0] == 'l')) {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr[0] == 'h' ? greatest : least);
-  } else
-    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "stream_create: %s", hipGetErrorString(e));
   *stream_out = (void*)s;
   return MMD_OK;

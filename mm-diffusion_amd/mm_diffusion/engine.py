@@ -106,14 +106,7 @@ class UNetEngine:
         self._tail_static = []        # affine tables written by producers: never pooled (they are live from the producer launch on)
         self._deferred = []           # video-stream buffers a launch of the AUDIO stream still reads (see _cross): released at the next sync
         H.reap()
-        if os.environ.get("MMD_STREAM_PRIO") == "1":      # EXPERIMENT (round 5): audio chain on a low-priority stream, capture origin / video chain high
-            os.environ["MMD_NEXT_STREAM_PRIO"] = "low"
-            self._aux = H.Stream(self.device)
-            os.environ["MMD_NEXT_STREAM_PRIO"] = "high"
-            self._side = H.Stream(self.device)
-            os.environ.pop("MMD_NEXT_STREAM_PRIO")
-        else:
-            self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
+        self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
         self.aux = self._aux.torch          # audio-chain launches
         self.side = self._side.torch        # capture stream (graphs of this engine and of the samplers driving it)
         self.keep = []          # packed weights etc. (kept alive)
@@ -205,11 +198,7 @@ class UNetEngine:
         """Keyword arguments for the GEMM that writes `out`: {"tail": struct} (filled in when the consumer norm is recorded; left
         empty - a plain GEMM - when no norm claims it), {"stats": record view} on the record path, or {}."""
         ent, c0 = self._tail_slice(out)
-        if ent is not None and self._TAIL_PROBE == "none":
-            return {}
         if ent is not None and c0 % 4 == 0 and out.shape[1] % 4 == 0:
-            if self._TAIL_PROBE == "acc":
-                ent["active"] = True
             st = H.GnTail()
             ent["producers"].append((c0, c0 + out.shape[1], st))
             self._tail_structs.append((st, ent))
@@ -218,17 +207,7 @@ class UNetEngine:
         rec = self._stats_for(out)
         return {} if rec is None else {"stats": rec}
 
-    # EXPERIMENT (round 5, tools/round5_calls/r05_call3.sh; with MMD_GN_TAIL=auto): what the producers' accumulator atomics cost by
-    # themselves.  "acc": every tail buffer's producers add their quad sums to the integer accumulators, NOBODY finalises (no ticket, no
-    # last-block finalize) and the norms run their statistics pass; "none": the same plan with plain producers.  acc - none = the atomics.
-    _TAIL_PROBE = os.environ.get("MMD_TAIL_PROBE", "")
-
     def _tail_claim(self, x, geom, gamma, beta, film):
-        if self._TAIL_PROBE:
-            return None
-        return self._tail_claim_(x, geom, gamma, beta, film)
-
-    def _tail_claim_(self, x, geom, gamma, beta, film):
         """The fused affine of a GroupNorm over x from its producers' tails: x's columns must be exactly covered by recorded producer
         launches of a tail buffer with x's slice geometry.  The LAST of them (all producers of a buffer run on one stream, in plan
         order) finalises; the affine tables are static buffers - they are written at the producer's launch, long before this point

@@ -24,10 +24,6 @@ def unwrap_unet(model):
     return None
 
 
-# hipGraphExec instances per lane, launched round-robin (see GraphStepper._capture); MMD_GRAPH_EXECS=1: one exec re-launched (A/B)
-_GRAPH_EXECS = max(1, int(os.environ.get("MMD_GRAPH_EXECS", "2")))
-
-
 def default_lanes(batch):
     """Batch lanes of a sampling step (see GraphStepper): 1 unless MMD_LANES says otherwise.  Measured on MI355X at batch 4
     (BASELINE configs[1]): 1 lane 15.53 ms / step, 2 lanes 15.37, 4 lanes 20.5 - the per-level kernels already occupy every CU
@@ -137,21 +133,12 @@ class GraphStepper:
             e.side.wait_stream(cur)
             self._lane_launch(r, e.side.cuda_stream)        # warm-up: one-time function attributes, lazy module load
         th.cuda.synchronize(self.device)
-        # Round 5: _GRAPH_EXECS (default 2) executables of the same capture per lane, launched in turn.  A re-launch of ONE hipGraphExec
-        # does not start to enqueue before its previous replay has retired (an exec owns one set of kernel arguments), so with a single
-        # exec the GPU idles while the host writes the next replay's ~650 packets (measured: 10.96 ms replayed against 10.80 ms with eager
-        # launches, profiles/r05_chain_interference_and_launch_modes.txt); with two, replay t + 1 is queued while replay t runs.  The
-        # replays stay ordered by the launch stream; they read the same device buffers (timestep, shifts, noise: stream-ordered uploads).
         graphs = []
         for r, e in enumerate(self.engs):
-            lane = []
-            for _ in range(_GRAPH_EXECS):
-                with H.capture(e.side.cuda_stream) as cap:
-                    self._lane_launch(r, e.side.cuda_stream)
-                lane.append(cap.exec)
-            graphs.append(lane)
+            with H.capture(e.side.cuda_stream) as cap:
+                self._lane_launch(r, e.side.cuda_stream)
+            graphs.append(cap.exec)
         self.graphs = graphs
-        self._turn = 0
 
     def _fan(self, body):
         """Run body(r, stream) for every lane: lane streams fork from the current stream and join it again (plain events)."""
@@ -200,8 +187,7 @@ class GraphStepper:
                 for e, (xv, xa) in zip(self.engs, keep):
                     e.x_video.copy_(xv)
                     e.x_audio.copy_(xa)
-            k = self._turn = (self._turn + 1) % _GRAPH_EXECS
-            self._fan(lambda r, stream: H.call("mmd_graph_launch", self.graphs[r][k], stream))
+            self._fan(lambda r, stream: H.call("mmd_graph_launch", self.graphs[r], stream))
         else:
             if self.lanes == 1:
                 self.eng.aux.wait_stream(th.cuda.current_stream(self.device))
@@ -216,9 +202,8 @@ class GraphStepper:
         also runs as a finaliser from the cyclic GC)."""
         try:
             gs, self.graphs = getattr(self, "graphs", None) or [], None
-            for lane in gs:
-                for g in lane:
-                    H.retire("graph", g)
+            for g in gs:
+                H.retire("graph", g)
             for ev in H.plan_events(*(getattr(self, "update_plans", None) or [])) + list(getattr(self, "_lane_ev", [])):
                 H.retire("event", ev)
             self.update_plans, self.update_plan, self._lane_ev = [], [], []
