@@ -176,14 +176,6 @@ int mmd_zero(void* ptr, int64_t bytes, void* stream);
 int mmd_conv_gemm_stats(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                         void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
                         float* stats, int64_t stats_ld, void* stream);
-/* Split-K form of mmd_conv_gemm for layers whose output has fewer tiles than the chip has CUs (round 5: the 3x3 convs of the ds8 level,
- * unet:83-99: 128 tiles x 72 - 144 K steps): bf16, no residual, no statistics.  `ksplit` workgroups per output tile each take a share of
- * the K steps on the direct-to-LDS main loop (tile 129 / 132) and write fp32 partial tiles part[ksplit][M][Cout]
- * (mmd_conv_gemm_splitk_workspace_bytes); a second launch adds them in ascending order, the bias, and rounds once.  Deterministic and
- * independent of M; equal to mmd_conv_gemm up to the fp32 rounding of the split sum.  Cin % 64 == 0, 2 <= ksplit <= 8. */
-int64_t mmd_conv_gemm_splitk_workspace_bytes(int M, int Cout, int ksplit);
-int mmd_conv_gemm_splitk(const void* A, int64_t lda, const void* W, const float* bias, void* Y, int64_t ldy, int M, int Cout, int Cin,
-                         int ntaps, const int* taps, int D0, int D1, int D2, int tile, int ksplit, float* part, void* stream);
 int mmd_gn_conv1x1_stats(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
                          int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                          int M, int Cout, int Cin, int tile, float* stats, int64_t stats_ld, void* stream);

@@ -34,10 +34,6 @@ struct ConvGemmParams {
   float* stats; int64_t stats_ld;
   // or: in-launch statistics + affine of the consumer GroupNorm (include/mmd.h: mmd_gn_tail); gt.acc != nullptr switches it on
   mmd_gn_tail gt;
-  // split-K (round 5, direct-to-LDS tiles only): ksplit > 1 -> every output tile is computed by ksplit workgroups, each over its share of
-  // the K steps; they write fp32 partial tiles to part[kz][m][co] (no bias / residual / statistics) and splitk_reduce_kernel sums them
-  int ksplit;
-  float* part;
   int taps[27 * 3];
 };
 
@@ -436,17 +432,13 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
     const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int ksp = p.ksplit > 1 ? p.ksplit : 1;            // split-K: the ksp workgroups of a tile are neighbours (uniform)
-  const int kz = wgid % ksp, tileid = wgid / ksp;
-  const int nt = tileid % Nt, mt = tileid / Nt;
+  const int nt = wgid % Nt, mt = wgid / Nt;
   const int m0 = mt * BM, n0 = nt * BN;
 
   const int CinV = p.Cin / EPV;
   const int KV = CinV * p.ntaps;
   const int64_t K = (int64_t)p.Cin * p.ntaps;
-  const int nit_all = (KV + 7) >> 3;
-  const int it0 = (int)((int64_t)kz * nit_all / ksp);      // this workgroup's K steps [it0, it0 + nit) (FAST only when ksp > 1: launcher)
-  const int nit = (int)((int64_t)(kz + 1) * nit_all / ksp) - it0;
+  const int nit = (KV + 7) >> 3;
   const int D12 = p.D1 * p.D2;
 
   const int lrow = lane >> 3, pc = lane & 7;
@@ -480,8 +472,7 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
     w_ok[i] = co < p.Cout;
     w_ptr[i] = p.W + ((int64_t)(w_ok[i] ? co : 0) * K + (int64_t)c_par[i & 1] * EPV) * ES;
   }
-  int u_tap = (it0 * 8) / CinV, u_civ = (it0 * 8) % CinV;      // uniform: tap index and first 16-byte chunk of this K step inside the tap
-  bool tap_fresh = true;                     // DESC: the row offsets of the current tap are not computed yet (a split-K share may start mid-tap)
+  int u_tap = 0, u_civ = 0;                  // uniform: tap index and first 16-byte chunk of this K step inside the tap
   __syncthreads();   // s_taps visible
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -501,8 +492,7 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
   }
   auto issue = [&](int buf) {
     if constexpr (DESC) {
-      if (u_civ == 0 || tap_fresh) {                      // a new tap (uniform): row validity and row shift of this tap
-        tap_fresh = false;
+      if (u_civ == 0) {                                   // a new tap (uniform): row validity and row shift of this tap
         const int t3 = u_tap * 3;
         const int o0 = __builtin_amdgcn_readfirstlane(s_taps[t3]), o1 = __builtin_amdgcn_readfirstlane(s_taps[t3 + 1]),
                   o2 = __builtin_amdgcn_readfirstlane(s_taps[t3 + 2]);
@@ -696,20 +686,6 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
       }
     }
   __syncthreads();
-  if (ksp > 1) {                          // block-uniform: this share's fp32 partial tile, rows of 8 columns per thread (32-byte pieces)
-    if (e_co < p.Cout) {
-      float* dst = p.part + ((int64_t)kz * p.M + m0) * p.Cout + e_co;
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int ml = e_rr + ps * RP;
-        if (m0 + ml < p.M) {
-          *(f32x4*)(dst + (int64_t)ml * p.Cout) = *(const f32x4*)(sC + ml * LDC + e_cg * 8);
-          *(f32x4*)(dst + (int64_t)ml * p.Cout + 4) = *(const f32x4*)(sC + ml * LDC + e_cg * 8 + 4);
-        }
-      }
-    }
-    return;
-  }
   float ssum[2][8], ssq[2][8];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -1813,7 +1789,7 @@ static int launch_conv_gemm_glds(const ConvGemmParams& p, hipStream_t st) {
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_glds: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128) * (p.ksplit > 1 ? p.ksplit : 1);
+  const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128);
   if (p.Cin % (8 * Elt<T>::EPV) != 0) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, false, 2, false>), dim3(grid), dim3(256), lds, st, p);
   else if (glds_desc_ok<T>(p)) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 2, true>), dim3(grid), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 2, false>), dim3(grid), dim3(256), lds, st, p);
@@ -1834,7 +1810,7 @@ static int launch_conv_gemm_ring(const ConvGemmParams& p, hipStream_t st) {
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_gemm_ring: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128) * (p.ksplit > 1 ? p.ksplit : 1);
+  const int grid = cdiv(p.M, 128) * cdiv(p.Cout, 128);
   if (glds_desc_ok<T>(p)) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 4, true>), dim3(grid), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, true, 4, false>), dim3(grid), dim3(256), lds, st, p);
   return mmd_check_launch("conv_gemm_ring");
@@ -1905,7 +1881,6 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
               "conv_gemm: output statistics need M %% 64 == 0, Cout %% 4 == 0, stats_ld >= Cout / 4 (quads) and a row-tiled main loop (not tiles 130 / 133)");
   p.stats = stats; p.stats_ld = stats_ld;
   p.gt = mmd_gn_tail{};
-  p.ksplit = 0; p.part = nullptr;
   if (tail && tail->acc) {
     const mmd_gn_tail& g = *tail;
     MMD_REQUIRE(!stats, "conv_gemm: records and the in-launch tail are alternatives");
@@ -1937,68 +1912,6 @@ extern "C" int mmd_conv_gemm(int dtype, const void* A, int64_t lda, const void* 
                              int tile, void* stream) {
   return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 0,
                         0, nullptr, 0, stream);
-}
-
-// ---- split-K for the layers whose output has FEWER TILES THAN THE CHIP HAS CUs (round 5): the 3x3 convs of the ds8 level are 128 tiles of
-// 72 - 144 K steps, each step one dependent L2 -> LDS round trip, on 256 CUs.  ksplit workgroups per tile each take a contiguous share of
-// the K steps (same tap-major order inside a share) and leave an fp32 partial tile; splitk_reduce_kernel adds the shares in ascending order,
-// the bias, and rounds once - a fixed order (bitwise repeatable, independent of M: the layer is chosen by geometry, ops.splitk_pinned), but
-// not the single-pass summation order: equal to the unsplit launch to fp32 rounding of the sum, i.e. a last-bit difference of some bf16
-// outputs.  No in-kernel hand-off (round 3 measured a fence or a ticket at tens of microseconds on this multi-die part): two launches.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int64_t M, int Cout,
-                                                            const float* __restrict__ bias, char* __restrict__ Y, int64_t ldy) {
-  const int CV = Cout >> 3;
-  const int64_t total = M * CV;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t m = i / CV;
-    const int c = (int)(i - m * CV) * 8;
-    const float* src = part + m * Cout + c;
-    f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
-    for (int k = 1; k < ksplit; ++k) {
-      const float* sk = src + (int64_t)k * M * Cout;
-      const f32x4 b0 = *(const f32x4*)sk, b1 = *(const f32x4*)(sk + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a0[j] += b0[j]; a1[j] += b1[j]; }
-    }
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = a0[j] + (bias ? bias[c + j] : 0.f); v[4 + j] = a1[j] + (bias ? bias[c + 4 + j] : 0.f); }
-    *(u32x4*)(Y + (m * ldy + c) * 2) = Elt<__bf16>::pack(v);
-  }
-}
-
-extern "C" int64_t mmd_conv_gemm_splitk_workspace_bytes(int M, int Cout, int ksplit) { return (int64_t)ksplit * M * Cout * 4; }
-
-// Y = conv(A) + bias as mmd_conv_gemm (bf16, no residual, no statistics), with every output tile computed by `ksplit` workgroups over
-// shares of the K steps on the direct-to-LDS main loop (tile 129: two-slot ring, two workgroups per CU; 132: four-slot ring) and a
-// second launch that sums the fp32 partial tiles part[ksplit][M][Cout] (mmd_conv_gemm_splitk_workspace_bytes) in ascending order.
-// Cin must be a multiple of 64 (uniform-tap K steps), ksplit in 2 .. 8 and at most half the K steps.
-extern "C" int mmd_conv_gemm_splitk(const void* A, int64_t lda, const void* W, const float* bias, void* Y, int64_t ldy, int M, int Cout, int Cin,
-                                    int ntaps, const int* taps, int D0, int D1, int D2, int tile, int ksplit, float* part, void* stream) {
-  MMD_REQUIRE(A && W && Y && part && M > 0 && Cout > 0 && Cin > 0, "conv_gemm_splitk: null/empty argument");
-  MMD_REQUIRE(ntaps >= 1 && ntaps <= 27 && taps, "conv_gemm_splitk: ntaps %d out of [1,27]", ntaps);
-  MMD_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0 && lda % 8 == 0 && ldy % 8 == 0, "conv_gemm_splitk: Cin %% 64, Cout %% 8, 16-byte row strides");
-  MMD_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)part) % 16 == 0, "conv_gemm_splitk: pointers must be 16-byte aligned");
-  MMD_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "conv_gemm_splitk: bad position dims");
-  MMD_REQUIRE(tile == 129 || tile == 132, "conv_gemm_splitk: tile 129 or 132 (the direct-to-LDS main loops)");
-  const int nit = Cin * ntaps / 64;
-  MMD_REQUIRE(ksplit >= 2 && ksplit <= 8 && 2 * ksplit <= nit, "conv_gemm_splitk: ksplit %d (2 .. 8, at most half of the %d K steps)", ksplit, nit);
-  ConvGemmParams p;
-  p.A = (const char*)A; p.lda = lda; p.W = (const char*)W; p.bias = nullptr;
-  p.R = nullptr; p.ldr = 0; p.Y = (char*)Y; p.ldy = ldy;
-  p.M = M; p.Cout = Cout; p.Cin = Cin; p.ntaps = ntaps; p.D0 = D0; p.D1 = D1; p.D2 = D2;
-  p.gn_a = nullptr; p.gn_b = nullptr; p.gn_act = 0; p.gn_S = 0; p.gn_rows = 0;
-  p.stats = nullptr; p.stats_ld = 0;
-  p.gt = mmd_gn_tail{};
-  p.ksplit = ksplit; p.part = part;
-  for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
-  hipStream_t st = (hipStream_t)stream;
-  const int rc = tile == 129 ? launch_conv_gemm_glds<__bf16>(p, st) : launch_conv_gemm_ring<__bf16>(p, st);
-  if (rc) return rc;
-  const int64_t total = (int64_t)M * (Cout / 8);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((int64_t)2048, (total + 255) / 256)), dim3(256), 0, st, part, ksplit, (int64_t)M, Cout, bias,
-                     (char*)Y, ldy);
-  return mmd_check_launch("conv_gemm_splitk");
 }
 
 // As mmd_conv_gemm, and the epilogue also leaves the GroupNorm statistics of the output for its consumer: per (64-row record, QUAD

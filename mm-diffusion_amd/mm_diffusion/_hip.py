@@ -51,8 +51,6 @@ _PROTOS = {
     "mmd_conv_gemm": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_gn_conv1x1": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "mmd_conv_gemm_stats": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp, i64, vp]),
-    "mmd_conv_gemm_splitk_workspace_bytes": (i64, [i32, i32, i32]),
-    "mmd_conv_gemm_splitk": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, i32, vp, vp]),
     "mmd_gn_conv1x1_stats": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
     "mmd_gn_conv_gemm": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_tconv_weight_bytes": (i64, [i32, i32]),

@@ -29,7 +29,6 @@ _UP_LOWRES = os.environ.get("MMD_UP_LOWRES", "1") != "0"
 # round 5: a cross-attention block's audio-side attention runs behind its video-side attention and the video stream does not wait for it;
 # MMD_CROSS_SERIAL=0: both start together and each stream waits for the other's (A/B)
 _CROSS_SERIAL = os.environ.get("MMD_CROSS_SERIAL", "1") != "0"
-_CROSS_SERIAL_MODE = int(os.environ.get("MMD_CROSS_SERIAL", "1") or 1)
 # round 5: GroupNorm statistics of resampled tensors from the resample launch's epilogue (mmd_resample_stats); =0: statistics passes (A/B)
 _RESAMPLE_STATS = os.environ.get("MMD_RESAMPLE_STATS", "1") != "0"
 
@@ -471,13 +470,10 @@ class UNetEngine:
                 pass
             elif vid:
                 if t0 is not None:
-                    # (the small frames - ds8 - run split-K: fp32 partial tiles in a scratch of this stream's pool, ops.splitk_pinned)
-                    wsk = self._alloc(ops.splitk_workspace_elems(rows_in, cout), 1, torch.float32) \
-                        if ops.splitk_pinned(t0, ops.TAPS_SPATIAL, (N * F, Hh, Hh), cout) else None
                     t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
                                        self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,
-                                       dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout), ws=wsk)
-                    self._release(t0, wsk)
+                                       dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
+                    self._release(t0)
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
                 wtk = f"{p}.video_in_layers.2.video_conv_temporal.weight"
                 if self._tconv and ops.tconv_ok(t1, cout, N, F, Hh * Hh):
@@ -590,26 +586,12 @@ class UNetEngine:
             # attention starts BEHIND the video stream's (the audio chain has ~6 ms of slack per step), the video stream never waits for it
             # (its proj_out follows its own attention at once), and the video qkv buffer the audio attention reads is parked until the
             # next point where the video stream has waited for the audio stream anyway (the next block's first sync)
-            vproj_done = False
-            if _CROSS_SERIAL_MODE == 2:        # EXPERIMENT: the audio attention also waits for the video stream's proj_out
-                ops.cur_sid = 0
-                vo = out_v if out_v is not None else self._alloc(N * F * HW, C, stats=True, unit=F * HW)
-                self._pw(vatt, p + ".video_proj_out.video_conv.weight", p + ".video_proj_out.video_conv.bias", residual=v, out=vo)
-                self._release(vatt)
-                vproj_done = True
             ops.record_sync(0, 1)
             ops.cur_sid = 1
             aatt = self._alloc(N * L, C)
             ops.attn(aqkv, vqkv, aatt, heads, ch, N, F, L, apf, F * HW, HW, win, shift_dev=sh)
             self._release(aqkv)    # audio pool: its readers are audio-stream launches and the video attention this stream has waited for
             self._deferred.append(vqkv)
-            if vproj_done:
-                ops.cur_sid = 1
-                ao = out_a if out_a is not None else self._alloc(N * L, C, stats=True, unit=L)
-                self._pw(aatt, p + ".audio_proj_out.audio_conv.weight", p + ".audio_proj_out.audio_conv.bias", residual=a, out=ao)
-                self._release(aatt)
-                ops.cur_sid, ops.cur_tag = 0, ""
-                return vo, ao
         else:
             ops.cur_sid = 1
             aatt = self._alloc(N * L, C)

@@ -391,27 +391,7 @@ def ring_tile_candidate(x, Cout, ntaps):
             and ((M + 127) // 128) * ((Cout + 127) // 128) <= 384)
 
 
-# Split-K for the 3x3 convs whose output has fewer 128 x 128 tiles than the chip has CUs (include/mmd.h: mmd_conv_gemm_splitk): the frames
-# of at most _SPLITK_MAX_PIXELS pixels (default 64: the ds8 level of the base model - 4096 rows x 512 channels = 128 tiles at batch 4).
-# The split changes the fp32 summation order (last-bit differences of some bf16 outputs), so - like every such kernel choice - it is a
-# property of the LAYER (frame size, taps), never of the batch size or of a timing.  MMD_SPLITK=0: off (A/B); =2 / 4: shares per tile.
-_SPLITK = int(os.environ.get("MMD_SPLITK", "2"))
-_SPLITK_TILE = int(os.environ.get("MMD_SPLITK_TILE", "129"))
-_SPLITK_MAX_PIXELS = int(os.environ.get("MMD_SPLITK_MAX_PIXELS", "64"))
-
-
-def splitk_pinned(x, taps, dims, Cout):
-    """The layers that always run split-K: bf16 spatial 3x3 convs on frames of <= _SPLITK_MAX_PIXELS pixels, Cin a multiple of 64."""
-    return (_SPLITK >= 2 and x.dtype == torch.bfloat16 and len(taps) == 9 and tuple(tuple(t) for t in taps) == tuple(TAPS_SPATIAL)
-            and dims[1] * dims[2] <= _SPLITK_MAX_PIXELS and x.shape[1] % 64 == 0 and Cout % 8 == 0 and 2 * _SPLITK <= 9 * x.shape[1] // 64
-            and dims[0] * dims[1] * dims[2] == x.shape[0])
-
-
-def splitk_workspace_elems(M, Cout):
-    return _SPLITK * M * Cout
-
-
-def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None, tail=None, ws=None):
+def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None, tail=None):
     """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None.  stats (optional): record view that receives
     the GroupNorm statistics of the output (include/mmd.h: mmd_conv_gemm_stats).  tail (optional): an _hip.GnTail - the statistics
     go into the consumer norm's integer accumulators and the last block leaves its fused affine (mmd_conv_gemm_tail); the struct is
@@ -428,15 +408,6 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, nt, arr,
             int(dims[0]), int(dims[1]), int(dims[2]))
-    if tile == 0 and stats is None and tail is None and residual is None and ws is not None and splitk_pinned(x, taps, dims, Cout):
-        # ws: fp32 scratch of splitk_workspace_elems(M, Cout) elements (the caller's: a recorded plan replays raw pointers)
-        if ws.dtype != torch.float32 or ws.numel() < _SPLITK * M * Cout or not ws.is_contiguous():
-            raise H.MMDError("conv_gemm: the split-K workspace must be a contiguous fp32 buffer of ksplit * M * Cout elements")
-        _dispatch("mmd_conv_gemm_splitk", x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), out.data_ptr(), out.stride(0), M, Cout, Cin, nt,
-                  arr, int(dims[0]), int(dims[1]), int(dims[2]), _SPLITK_TILE, _SPLITK, ws.data_ptr(),
-                  meta=(f"conv_gemm<bf16,splitk{_SPLITK}>[M={M},K={Cin * nt},N={Cout}]", 2 * M * Cout * Cin * nt,
-                        es * (M * Cin + M * Cout + Cout * Cin * nt) + 4 * Cout))
-        return out
     if tile == 0 and stats is None and tail is None and halo_tile_pinned(x, taps, dims):
         tile = halo_tile_code(x, taps, dims)
     if tile == 0 and strip_tile_pinned(x, Cout, taps, stats if stats is not None else tail):

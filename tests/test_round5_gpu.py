@@ -244,63 +244,3 @@ def test_round5_plan_switches_against_reference_fixture(tmp_path, cfg, keyset, t
     if tag == "full":
         assert "mmd_head_gemm" in na and "mmd_head_gather" in na and "mmd_head_conv" in nb
         print("launches per forward:", int(a["nlaunch"]), "(was", int(b["nlaunch"]), ")")
-
-
-# --------------------------------------------------------------------------- split-K 3x3 conv (mmd_conv_gemm_splitk)
-@pytest.mark.parametrize("NF,Hh,Cin,Cout,ksplit,tile", [
-    (64, 8, 512, 512, 2, 129), (64, 8, 512, 512, 4, 129), (64, 8, 512, 512, 2, 132), (16, 8, 1024, 512, 3, 129),
-    (5, 8, 384, 320, 2, 129),          # ragged: 320 rows (2.5 row tiles), 320 columns (2.5 column tiles), 54 K steps
-    (2, 4, 256, 64, 8, 132),           # 32 rows, one partial tile, 36 K steps in 8 shares (a share starts in the middle of a tap)
-])
-def test_conv_gemm_splitk(ops, NF, Hh, Cin, Cout, ksplit, tile):
-    from mm_diffusion import _hip as H
-    M = NF * Hh * Hh
-    g = torch.Generator().manual_seed(7 + ksplit)
-    x = torch.randn(M, Cin, generator=g).to(torch.bfloat16).cuda()
-    w4 = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
-    wp = ops.pack_conv_weight(w4.unsqueeze(2), torch.bfloat16).cuda()          # [Cout, 9 Cin], K = tap * Cin + ci
-    bias = torch.randn(Cout, generator=g).cuda()
-    dims = (NF, Hh, Hh)
-    arr, nt = H.taps_array(ops.TAPS_SPATIAL)
-    part = torch.full((ksplit * M * Cout,), float("nan"), dtype=torch.float32, device="cuda")
-    assert part.numel() * 4 == H.lib().mmd_conv_gemm_splitk_workspace_bytes(M, Cout, ksplit)
-    y = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
-    H.call("mmd_conv_gemm_splitk", x.data_ptr(), x.stride(0), wp.data_ptr(), bias.data_ptr(), y.data_ptr(), y.stride(0), M, Cout, Cin, nt, arr,
-           *dims, tile, ksplit, part.data_ptr(), H.stream_handle())
-    assert torch.isfinite(y.float()).all() and torch.isfinite(part).all()
-    # the unsplit launch of the same main loop: same products, another fp32 summation order -> at most a last-bit difference per output
-    y0 = ops.conv_gemm(x, wp, bias, taps=ops.TAPS_SPATIAL, dims=dims, tile=129)
-    assert rel_l2(y.float().cpu(), y0.float().cpu()) < 2e-3
-    frac_equal = float((y == y0).float().mean())
-    assert frac_equal > 0.9, frac_equal
-    # fp32 torch restatement of the operator (unet:83-99: the per-frame 3x3 conv, zero padding) on the bf16-rounded operands
-    xr = x.float().cpu().view(NF, Hh, Hh, Cin).permute(0, 3, 1, 2)
-    ref = F_.conv2d(xr, w4.to(torch.bfloat16).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
-    assert rel_l2(y.float().cpu(), ref) < 5e-3
-    # the partial tiles really are shares of the sum: their fp32 total + bias, rounded, is the output
-    tot = part.view(ksplit, M, Cout).sum(0) + bias
-    assert rel_l2(y.float().cpu(), tot.cpu()) < 3e-3
-    # bitwise repeatable
-    y2 = torch.empty_like(y)
-    H.call("mmd_conv_gemm_splitk", x.data_ptr(), x.stride(0), wp.data_ptr(), bias.data_ptr(), y2.data_ptr(), y2.stride(0), M, Cout, Cin, nt, arr,
-           *dims, tile, ksplit, part.data_ptr(), H.stream_handle())
-    assert torch.equal(y, y2)
-
-
-def test_conv_gemm_splitk_through_ops_is_batch_invariant(ops):
-    """ops.conv_gemm picks the split by the LAYER's geometry (frames of <= 64 pixels), never by M: the rows of a batch-4 launch are the
-    batch-1 launches bitwise; without a workspace (or on larger frames) the unsplit tiles run."""
-    if ops._SPLITK < 2:
-        pytest.skip("MMD_SPLITK=0")
-    NF, Hh, C = 16, 8, 512
-    g = torch.Generator().manual_seed(3)
-    wp = ops.pack_conv_weight((torch.randn(C, C, 1, 3, 3, generator=g) * (9 * C) ** -0.5), torch.bfloat16).cuda()
-    bias = torch.randn(C, generator=g).cuda()
-    x4 = torch.randn(4 * NF * Hh * Hh, C, generator=g).to(torch.bfloat16).cuda()
-    assert ops.splitk_pinned(x4, ops.TAPS_SPATIAL, (4 * NF, Hh, Hh), C) and not ops.splitk_pinned(x4, ops.TAPS_SPATIAL, (NF, 16, 16), C)
-    ws = torch.empty(ops.splitk_workspace_elems(x4.shape[0], C), dtype=torch.float32, device="cuda")
-    y4 = ops.conv_gemm(x4, wp, bias, taps=ops.TAPS_SPATIAL, dims=(4 * NF, Hh, Hh), ws=ws)
-    M1 = NF * Hh * Hh
-    for n in range(4):
-        y1 = ops.conv_gemm(x4[n * M1:(n + 1) * M1], wp, bias, taps=ops.TAPS_SPATIAL, dims=(NF, Hh, Hh), ws=ws)
-        assert torch.equal(y1, y4[n * M1:(n + 1) * M1])
