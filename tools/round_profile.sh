@@ -10,7 +10,7 @@ O=gpurun_out/$TAG
 mkdir -p $O profiles
 export PYTHONFAULTHANDLER=1
 if [ -z "$RP_SKIP_TESTS" ]; then      # RP_SKIP_TESTS=1: profiling passes only (the suite was just run at this build)
-timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest_full.txt 2>&1
+timeout 2100 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest_full.txt 2>&1
 tail -3 $O/pytest_full.txt > $O/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 fi
@@ -18,6 +18,10 @@ B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-breakdown"
 # the kernel trace ranks the REPLAYED step: 60 steps (40 k launches) beside the ~1 k plan-time autotune launches of the warm-up
 BT="python bench.py --steps 60 --warmup 2 --no-cpu-baseline --no-breakdown"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $BT > $O/kt.log 2>&1
+# the same trace as csv, summarised per LAUNCH SHAPE (kernel, grid) and per HW queue (round 5: tools/kt_by_shape.py)
+BC="python bench.py --steps 24 --warmup 2 --no-cpu-baseline --no-breakdown"
+timeout 600 rocprofv3 --kernel-trace -f csv -d $O/ktc -o kt -- $BC > $O/ktc.log 2>&1
+python tools/kt_by_shape.py "$(find $O/ktc -name '*kernel_trace.csv' | head -1)" profiles/${TAG}_kernel_trace_by_shape.txt 20 > /dev/null
 timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p -f csv -- $B > $O/pmc_fetch.log 2>&1
 timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p -f csv -- $B > $O/pmc_write.log 2>&1
 timeout 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $O/pmc_sq1 -o p -f csv -- $B > $O/pmc_sq1.log 2>&1
@@ -35,5 +39,5 @@ timeout 400 python bench.py --mode dpm --batch 2 --steps 2 --warmup 1 > $O/bench
 timeout 400 python bench.py --mode sr --batch 1 --steps 1 --warmup 1 > $O/bench_sr.log 2>&1; tail -1 $O/bench_sr.log > profiles/${TAG}_bench_line_sr.json
 timeout 400 python bench.py --mode train --batch 8 --steps 5 --warmup 2 > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log > profiles/${TAG}_bench_line_train.json
 mkdir -p $O/profiles && cp profiles/${TAG}_* profiles/pmc_traffic.json profiles/kernel_stats.json profiles/kernel_stats_train.json $O/profiles/ 2>/dev/null
-rm -rf $O/kt $O/kt_train $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces stay on the box: only the summaries travel back
+rm -rf $O/kt $O/ktc $O/kt_train $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces stay on the box: only the summaries travel back
 tail -3 $O/pytest.txt 2>/dev/null; tail -1 $O/smoke.log 2>/dev/null; cat profiles/${TAG}_bench_line.json
