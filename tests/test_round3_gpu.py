@@ -274,7 +274,10 @@ def test_engine_tails_match_the_record_path(monkeypatch):
         names = [e[2] for e in next(iter(model._engines.values())).plan]
         assert ("mmd_gn_finalize_stats" in names) == (mode == "0")
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), f"mode {mode}: not repeatable"
-        assert torch.equal(res[0][0][:1], res[2][0]) and torch.equal(res[0][0][1:], res[3][0]) and torch.equal(res[0][1][1:], res[3][1])
+        rows_ok = [torch.equal(res[0][0][:1], res[2][0]), torch.equal(res[0][1][:1], res[2][1]), torch.equal(res[0][0][1:], res[3][0]),
+                   torch.equal(res[0][1][1:], res[3][1])]
+        assert all(rows_ok), (f"mode {mode}: rows of the batch-2 run differ from the batch-1 runs (video 0, audio 0, video 1, audio 1 equal: {rows_ok}; "
+                              f"rel-L2 video 1 {rel_l2(res[0][0][1:].cpu(), res[3][0].cpu().numpy()):.2e} audio 1 {rel_l2(res[0][1][1:].cpu(), res[3][1].cpu().numpy()):.2e})")
         outs[mode] = res[0]
         model.release_engines()
     assert rel_l2(outs["all"][0].cpu(), outs["0"][0].cpu().numpy()) < 3e-2 and rel_l2(outs["all"][1].cpu(), outs["0"][1].cpu().numpy()) < 3e-2
