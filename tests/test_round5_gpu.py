@@ -244,3 +244,17 @@ def test_round5_plan_switches_against_reference_fixture(tmp_path, cfg, keyset, t
     if tag == "full":
         assert "mmd_head_gemm" in na and "mmd_head_gather" in na and "mmd_head_conv" in nb
         print("launches per forward:", int(a["nlaunch"]), "(was", int(b["nlaunch"]), ")")
+
+
+# --------------------------------------------------------------------------- cross-stream ordering: alternating inputs on one engine
+@pytest.mark.parametrize("cfg,B,iters", [("mid", 1, 200), ("mid", 2, 100), ("full", 1, 40)])
+def test_alternating_inputs_replay_bitwise(cfg, B, iters):
+    """tools/alternating_inputs_stress.py: two different inputs fed alternately to ONE engine (graph replay of the two-stream plan); every
+    output must be bitwise its first occurrence.  Replaying the same input cannot see a launch that runs ahead of its producer on the other
+    stream (it reads the previous replay's identical data); with alternating inputs the stale data is the other input's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("alt_stress", os.path.join(ROOT, "tools", "alternating_inputs_stress.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    nbad, worst = m.run(cfg, B, iters, verbose=True)
+    assert nbad == 0, f"{nbad} of {iters} alternating replays differ (worst rel-L2 {worst:.2e})"
