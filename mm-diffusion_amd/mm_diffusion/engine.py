@@ -83,27 +83,13 @@ class UNetEngine:
         mode = os.environ.get("MMD_GN_EPILOGUE", "1")
         self.rec_enabled = mode == "2" or (mode != "0" and dtype == torch.bfloat16)
         self._recs = {}
-        # Round 3: in-launch statistics + affine (include/mmd.h: mmd_gn_tail) instead of records + a finalize launch per norm: the
-        # producers add exact integer partial sums per (slice, quad of channels) into the buffer's accumulators and the last block of
-        # the last producer leaves the consumer norm's fused affine.  MMD_GN_TAIL=0 keeps the record path (A/B).
-        # MEASURED (round 3, gpurun c7 / c8): correct and bitwise order-free, but SLOWER than records + finalize launches - the
-        # device-scope 64-bit atomics run at ~13 G/s chip-wide (a ds2 GEMM with 1024 tiles x 256 atomics pays +20 us) and even on the
-        # small ds8 launches the drain + ticket round trip + last-block finalize costs what the 7 us finalize launch cost: 14.7 ms per
-        # step with tails everywhere, 13.6 with tails on buffers of <= 2^21 elements, 12.8 without.  So the default is OFF (records);
-        # MMD_GN_TAIL=all / =auto (buffers of <= MMD_GN_TAIL_MAX elements) switch the experiment on.
-        tmode = os.environ.get("MMD_GN_TAIL", "0")
-        self.tail_enabled = self.rec_enabled and tmode != "0"
+        # (Round 3's in-launch statistics + affine - "tails": integer accumulators in the producers, the last block of the last producer
+        # finalises; include/mmd.h: mmd_conv_gemm_tail - were an engine mode (MMD_GN_TAIL) until round 5.  Measured slower in round 3
+        # (14.7 / 13.6 ms against 12.8 with records), and round 5 measured its premise: the producers' atomics ALONE cost + 0.30 ... 0.83 ms
+        # per step (profiles/r05_chain_interference_and_launch_modes.txt).  The mode is gone from the engine; the entry points stay in the
+        # C ABI with their kernel-level tests.)
         self._gn_small = os.environ.get("MMD_GN_SMALL", "1") != "0"
-        # the fused VideoConv 2d+1d launch (ops.vconv_fused_ok) writes quad RECORDS, not tails: with the tail experiment on, the layer
-        # keeps its two-launch form
-        self._vconv_fused = dtype == torch.bfloat16 and not self.tail_enabled
-        self._tattn_fused = dtype == torch.bfloat16 and not self.tail_enabled
-        self._tconv = dtype == torch.bfloat16 and not self.tail_enabled
-        self.tail_max = (1 << 62) if tmode == "all" else int(os.environ.get("MMD_GN_TAIL_MAX", str(1 << 21)))
-        self._tails = {}              # buffer storage -> entry (slice geometry, accumulator offset, producer structs)
-        self._tail_structs = []       # every GnTail handed to a producer launch: (struct, entry)
-        self._tail_bytes = 0          # bump allocator of the per-forward-zeroed arena (accumulators + counters)
-        self._tail_static = []        # affine tables written by producers: never pooled (they are live from the producer launch on)
+        self._vconv_fused = self._tattn_fused = self._tconv = dtype == torch.bfloat16
         self._deferred = []           # video-stream buffers a launch of the AUDIO stream still reads (see _cross): released at the next sync
         H.reap()
         self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
@@ -131,13 +117,7 @@ class UNetEngine:
         raw = pool.get(rows * C * es)
         t = raw[: rows * C * es].view(dtype).view(rows, C)
         t._raw, t._pool = raw, pool
-        if stats and self.tail_enabled and rows * C <= self.tail_max and rows % unit == 0 and unit % 64 == 0 and C % 4 == 0:
-            S = rows // unit
-            off = self._tail_bytes
-            self._tail_bytes += S * (C // 4) * 4 * 8                     # [S][C / 4 quads][4] int64
-            self._tails[raw.untyped_storage().data_ptr()] = dict(ptr=t.data_ptr(), es=es, rows=rows, C=C, unit=unit, S=S, off=off,
-                                                                 producers=[], active=False)
-        elif stats and self.rec_enabled and rows % 64 == 0 and unit % 64 == 0 and C % 4 == 0:
+        if stats and self.rec_enabled and rows % 64 == 0 and unit % 64 == 0 and C % 4 == 0:
             rec = self._alloc(rows // 64, C // 2, torch.float32)            # one (sum, sum of squares) record per 64 rows and channel QUAD
             self._recs[raw.untyped_storage().data_ptr()] = dict(rec=rec, view=rec.view(rows // 64, C // 4, 2), ptr=t.data_ptr(), es=es,
                                                                 rows=rows, C=C, cover=[])
@@ -149,7 +129,6 @@ class UNetEngine:
                 ent = self._recs.pop(t._raw.untyped_storage().data_ptr(), None)
                 if ent is not None:
                     self._release(ent["rec"])
-                self._tails.pop(t._raw.untyped_storage().data_ptr(), None)      # (its structs stay valid: they point into the arena)
                 t._pool.put(t._raw)
                 del t._raw
 
@@ -173,16 +152,8 @@ class UNetEngine:
         ent["cover"].append((c0, c0 + out.shape[1]))
         return ent["view"][:, c0 // 4:(c0 + out.shape[1]) // 4, :]
 
-    # ------------------------------------------------------------------ in-launch statistics + affine (tails)
-    def _tail_slice(self, t):
-        ent = self._tails.get(t.untyped_storage().data_ptr())
-        if ent is None or t.stride(0) != ent["C"] or t.shape[0] != ent["rows"]:
-            return None, 0
-        c0 = (t.data_ptr() - ent["ptr"]) // ent["es"]
-        return (ent, c0) if 0 <= c0 and c0 + t.shape[1] <= ent["C"] else (None, 0)
-
     def _has_stats(self, out):
-        return self._tail_slice(out)[0] is not None or self._rec_slice(out)[0] is not None
+        return self._rec_slice(out)[0] is not None
 
     def _resample_stats(self, out):
         """The record view a resample writing `out` fills (None: no record buffer, or a column slice its 16-byte record stores cannot
@@ -195,75 +166,9 @@ class UNetEngine:
         return self._stats_for(out)
 
     def _stats_kw(self, out):
-        """Keyword arguments for the GEMM that writes `out`: {"tail": struct} (filled in when the consumer norm is recorded; left
-        empty - a plain GEMM - when no norm claims it), {"stats": record view} on the record path, or {}."""
-        ent, c0 = self._tail_slice(out)
-        if ent is not None and c0 % 4 == 0 and out.shape[1] % 4 == 0:
-            st = H.GnTail()
-            ent["producers"].append((c0, c0 + out.shape[1], st))
-            self._tail_structs.append((st, ent))
-            st.q_ld, st.q_off, st.S, st.rows_per_slice = ent["C"] // 4, c0 // 4, ent["S"], ent["unit"]
-            return {"tail": st}
+        """Keyword arguments for the GEMM that writes `out`: {"stats": record view}, or {} when its buffer has no record buffer."""
         rec = self._stats_for(out)
         return {} if rec is None else {"stats": rec}
-
-    def _tail_claim(self, x, geom, gamma, beta, film):
-        """The fused affine of a GroupNorm over x from its producers' tails: x's columns must be exactly covered by recorded producer
-        launches of a tail buffer with x's slice geometry.  The LAST of them (all producers of a buffer run on one stream, in plan
-        order) finalises; the affine tables are static buffers - they are written at the producer's launch, long before this point
-        of the plan.  None -> the caller runs the statistics pass."""
-        ent, c0 = self._tail_slice(x)
-        C = x.shape[1]
-        if (ent is None or geom.inner != 1 or geom.tstride != 1 or geom.outer_stride != geom.Tn or geom.Tn != ent["unit"]
-                or geom.S != ent["S"] or C % 128 or c0 % 4):
-            return None
-        inside = [pr for pr in ent["producers"] if pr[0] < c0 + C and pr[1] > c0]
-        if not inside or any(pr[0] < c0 or pr[1] > c0 + C for pr in inside):
-            return None
-        pos = c0
-        for lo, hi, _ in sorted(inside, key=lambda pr: pr[0]):
-            if lo > pos:
-                return None
-            pos = max(pos, hi)
-        if pos < c0 + C:
-            return None
-        st = inside[-1][2]                         # recorded last = runs last
-        if st.shared_counter:                      # that launch already finalises another norm
-            return None
-        a = torch.empty(geom.S, C, dtype=torch.float32, device=self.device)
-        b = torch.empty(geom.S, C, dtype=torch.float32, device=self.device)
-        self._tail_static += [a, b]
-        coff = self._tail_bytes
-        self._tail_bytes += 16                     # launch counter, shared counter (+ padding: the accumulators stay 8-byte aligned)
-        st._coff = coff
-        st.n_producers, st.C, st.fq0 = 1, C, c0 // 4
-        st.gamma, st.beta = gamma.data_ptr(), beta.data_ptr()
-        st.film, st.film_ld = (0 if film is None else film.data_ptr()), (0 if film is None else film.stride(0))
-        st.eps = ops.GN_EPS
-        st.a_out, st.b_out = a.data_ptr(), b.data_ptr()
-        st.shared_counter = 1                      # placeholder (non-null = "finalises"): the arena address is filled in by _tail_commit
-        ent["active"] = True
-        return a, b
-
-    def _tail_commit(self):
-        """After recording: allocate the arena, point every struct of an active buffer at its accumulators / counters (inactive
-        buffers keep acc = NULL: their producers run as plain GEMMs) and put the arena's reset in front of the plan."""
-        if not self._tail_structs:
-            return None
-        self._tail_arena = torch.zeros(max(self._tail_bytes, 16) // 8 + 2, dtype=torch.int64, device=self.device)
-        base = self._tail_arena.data_ptr()
-        for st, ent in self._tail_structs:
-            if ent["active"]:
-                st.acc = base + ent["off"]
-                if st.shared_counter:
-                    st.launch_counter, st.shared_counter = base + st._coff, base + st._coff + 4
-            else:
-                st.acc, st.shared_counter = None, None
-        head = []
-        with ops.recording(head):
-            ops.cur_sid = 0
-            ops.zero(self._tail_arena)
-        return head
 
     def _rec_ready(self, x, geom):
         """The record view a GroupNorm over x can finalize from: every column of x written by a statistics-emitting GEMM, contiguous
@@ -336,10 +241,6 @@ class UNetEngine:
         a = self._alloc(geom.S, C, torch.float32)
         b = self._alloc(geom.S, C, torch.float32)
         gamma, beta = self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias")
-        ab = self._tail_claim(x, geom, gamma, beta, film) if self.tail_enabled else None
-        if ab is not None:
-            self._release(a, b)
-            return ab
         rec = self._rec_ready(x, geom)
         if rec is not None:
             ops.gn_finalize_stats(rec, gamma, beta, geom, film=film, a=a, b=b)
@@ -653,9 +554,6 @@ class UNetEngine:
 
         # two plans that differ only in the timestep dtype read by the first kernel
         self.plan = record(self.t_i64)
-        head = self._tail_commit()
-        if head:
-            self.plan = head + self.plan
         self.plan_f32 = [(fn, (self.t_f32.data_ptr(), 2) + args[2:], name, meta, sid, tag) if name == "mmd_temb_fwd"
                          else (fn, args, name, meta, sid, tag) for fn, args, name, meta, sid, tag in self.plan]
 

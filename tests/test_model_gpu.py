@@ -171,15 +171,12 @@ def test_epilogue_statistics_do_not_change_the_forward(monkeypatch, dt):
             outs[flag] = model(video.cuda(), audio.cuda(), torch.tensor([7, 800]).cuda())
         eng = next(iter(model._engines.values()))
         names = [e[2] for e in eng.plan if e[0] is not None]
-        # round 3: the producers' last blocks leave the affine themselves (mmd_gn_tail): no finalize launch; the norms served that way
-        # are the structs that finalise
-        n_tail = sum(1 for st, ent in eng._tail_structs if ent["active"] and st.shared_counter)
         n_fin = names.count("mmd_gn_finalize_stats")
-        assert (n_tail + n_fin > 0) == (flag != "0")
+        assert (n_fin > 0) == (flag != "0")
         if flag != "0":
             n_pass = names.count("mmd_gn_stats")
-            print(f"{dt}: {n_fin} norms finalized from epilogue records, {n_tail} inside their producer launches, {n_pass} by a statistics pass")
-            assert (n_tail == 0 or names[0] == "mmd_zero") and (dt == torch.float32 or 4 * (n_fin + n_tail) > n_pass)   # (64- / 192-channel norms of this config: groups are not whole quads)
+            print(f"{dt}: {n_fin} norms finalized from epilogue records, {n_pass} by a statistics pass")
+            assert dt == torch.float32 or 4 * n_fin > n_pass        # (64- / 192-channel norms of this config: groups are not whole quads)
     a, b = [v for k, v in outs.items() if k != "0"][0], outs["0"]
     ev, ea = rel_l2(a[0].cpu(), b[0].cpu().numpy()), rel_l2(a[1].cpu(), b[1].cpu().numpy())
     print(f"epilogue statistics vs statistics pass ({dt}): rel-L2 video {ev:.2e} audio {ea:.2e}")

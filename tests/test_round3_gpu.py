@@ -249,38 +249,9 @@ def test_tail_two_producers_of_a_concat_and_two_consumers(ops):
     assert torch.equal(sP1._a[0], stP._a[0]) and torch.equal(sQ1._a[0], stQ._a[0]) and torch.equal(sQ1._b[0], stQ._b[0])
 
 
-def test_engine_tails_match_the_record_path(monkeypatch):
-    """The mid-size model with in-launch tails (default) and with records + finalize launches (MMD_GN_TAIL=0): same statistics up to
-    fp32 rounding of the sums -> outputs within the bf16 noise floor of each other; no finalize launch in the tail plan; bitwise
-    repeatable; rows of a batch-2 run equal the batch-1 runs."""
-    from helpers import flags, inputs
-    from mm_diffusion import multimodal_script_util as msu
-    from mm_diffusion.synth import synth_init_
-    import random
-    fl = flags("mid", use_fp16=True)
-    outs = {}
-    for mode in ("all", "0"):
-        monkeypatch.setenv("MMD_GN_TAIL", mode)
-        model, _ = msu.create_model_and_diffusion(**fl)
-        synth_init_(model)
-        model.cuda().eval()
-        v, a = inputs(fl, 2, 3)
-        res = []
-        for rows in (slice(0, 2), slice(0, 2), slice(0, 1), slice(1, 2)):
-            random.seed(5)
-            with torch.no_grad():
-                ov, oa = model(v[rows].cuda(), a[rows].cuda(), torch.tensor([17, 400])[rows].cuda())
-            res.append((ov.clone(), oa.clone()))
-        names = [e[2] for e in next(iter(model._engines.values())).plan]
-        assert ("mmd_gn_finalize_stats" in names) == (mode == "0")
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), f"mode {mode}: not repeatable"
-        rows_ok = [torch.equal(res[0][0][:1], res[2][0]), torch.equal(res[0][1][:1], res[2][1]), torch.equal(res[0][0][1:], res[3][0]),
-                   torch.equal(res[0][1][1:], res[3][1])]
-        assert all(rows_ok), (f"mode {mode}: rows of the batch-2 run differ from the batch-1 runs (video 0, audio 0, video 1, audio 1 equal: {rows_ok}; "
-                              f"rel-L2 video 1 {rel_l2(res[0][0][1:].cpu(), res[3][0].cpu().numpy()):.2e} audio 1 {rel_l2(res[0][1][1:].cpu(), res[3][1].cpu().numpy()):.2e})")
-        outs[mode] = res[0]
-        model.release_engines()
-    assert rel_l2(outs["all"][0].cpu(), outs["0"][0].cpu().numpy()) < 3e-2 and rel_l2(outs["all"][1].cpu(), outs["0"][1].cpu().numpy()) < 3e-2
+# (test_engine_tails_match_the_record_path - the ENGINE mode that used the tails, MMD_GN_TAIL - went with that mode in round 5: measured slower in
+# round 3, its premise measured false in round 5 (profiles/r05_chain_interference_and_launch_modes.txt), and its batch-row check was the one test
+# of the suite that ever failed without a reproduction: once in 23 runs, inside a 380-test process.  The entry points above stay, with their tests.)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, BF])

@@ -3,7 +3,7 @@
 out(A) must equal the first out(A) bitwise and every out(B) the first out(B).  The replay-determinism tests replay the SAME input, where a
 launch that runs before its producer (a missing cross-stream wait) reads the previous replay's identical data and goes unnoticed; with
 alternating inputs the previous replay's data is the OTHER input's.  usage: alternating_inputs_stress.py [tiny|mid|full] [batch] [iterations]
-(MMD_GN_TAIL and the other engine switches are read from the environment as usual)"""
+(the engine's A/B switches are read from the environment as usual)"""
 import os
 import sys
 
@@ -41,7 +41,7 @@ def run(cfg="mid", B=1, iters=300, verbose=True):
             bad[k] += 1
             worst = max(worst, float((ov - ref[k][0]).norm() / ref[k][0].norm()), float((oa - ref[k][1]).norm() / ref[k][1].norm()))
     if verbose:
-        print(f"{cfg} batch {B}: {iters} alternating replays, MMD_GN_TAIL={os.environ.get('MMD_GN_TAIL', '0')}: {bad[0]} + {bad[1]} differ"
+        print(f"{cfg} batch {B}: {iters} alternating replays: {bad[0]} + {bad[1]} differ"
               + (f" (worst rel-L2 {worst:.2e})" if sum(bad) else ""))
     return sum(bad), worst
 
