@@ -127,6 +127,31 @@ class NoiseScheduleVP:
             raise ValueError(f"Unsupported noise schedule {schedule}. The schedule needs to be 'discrete' or 'linear' or 'cosine'")
         self.schedule, self.total_N, self.T = schedule, self._family.total_N, self._family.T
 
+    # read-only counterparts of the attributes the reference's class exposes (dpm:113-118): nothing here uses them
+    @property
+    def t_array(self):
+        if self.schedule != "discrete":
+            raise AttributeError("t_array exists for the 'discrete' schedule only")
+        return self._family.curve.x.reshape((1, -1))
+
+    @property
+    def log_alpha_array(self):
+        if self.schedule != "discrete":
+            raise AttributeError("log_alpha_array exists for the 'discrete' schedule only")
+        return self._family.curve.y.reshape((1, -1))
+
+    @property
+    def beta_0(self):
+        if self.schedule != "linear":
+            raise AttributeError("beta_0 exists for the 'linear' schedule only")
+        return self._family.b0
+
+    @property
+    def beta_1(self):
+        if self.schedule != "linear":
+            raise AttributeError("beta_1 exists for the 'linear' schedule only")
+        return self._family.b0 + self._family.db
+
     def marginal_log_mean_coeff(self, t):
         shape = t.shape
         return self._family.log_alpha(t).reshape(shape) if self.schedule != "discrete" else self._family.log_alpha(t).reshape((-1))

@@ -385,6 +385,15 @@ def test_noise_schedule_vp_matches_reference_fixture():
         np.testing.assert_allclose(inv.numpy(), g[f"{tag}_inv"], rtol=2e-7, atol=1e-9, err_msg=f"{tag} inverse_lambda")
     with pytest.raises(ValueError):
         NoiseScheduleVP("quadratic")
+    # the read-only counterparts of the reference class's public attributes (dpm:113-118)
+    ns = NoiseScheduleVP(schedule="discrete", betas=torch.tensor(betas))
+    assert tuple(ns.t_array.shape) == (1, 1000) and tuple(ns.log_alpha_array.shape) == (1, 1000)
+    assert float(ns.t_array[0, 0]) == pytest.approx(1e-3) and float(ns.t_array[0, -1]) == 1.0
+    np.testing.assert_allclose(ns.log_alpha_array[0].numpy(), 0.5 * np.log(1 - betas).cumsum(), rtol=1e-6)
+    lin = NoiseScheduleVP("linear", continuous_beta_0=0.2, continuous_beta_1=15.)
+    assert lin.beta_0 == 0.2 and lin.beta_1 == pytest.approx(15.)
+    with pytest.raises(AttributeError):
+        lin.t_array
 
 
 def test_tattn_register_model():
