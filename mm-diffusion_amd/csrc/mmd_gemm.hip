@@ -1656,12 +1656,16 @@ template <int KS, int RF, int CC, int GNM, int STM>
 static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
   constexpr int BR = 128 * RF, STAGE_B = KS * CC * 128;
   const int rowblocks = cdiv(p.M, BR), nch = p.Cout / CC;
-  // column split: the smallest divisor of the chunk count that gives the chip >= ~1.75 blocks per CU (the strip's rows are then
-  // loaded nsplit times, from L2 after the first); results do not depend on it
-  static const int want_blocks = [] {                     // tuning switch (read once): MMD_STRIP_BLOCKS, default 448
+  // column split: the smallest divisor of the chunk count that gives the chip ONE block per CU (the strip's rows are then loaded nsplit
+  // times, from L2 after the first); results do not depend on it.  256 since round 5 (448 = ~1.75 blocks per CU before): a launch of the
+  // small levels that fills BOTH block slots of every CU leaves no room for the other launch chain's blocks, and the two chains' small,
+  // latency-bound launches then queue behind each other instead of running side by side - same-call A/B, two boxes, two passes each:
+  // 11.14 -> 10.80 ms and 11.18 -> 10.94 ms per step; 224: the same, 192: 10.96, 128: 11.40, 288 / 320 (1.5 blocks per CU at ds4): 11.3 / 11.0
+  // (profiles/r05_launch_width_ab.txt)
+  static const int want_blocks = [] {                     // tuning switch (read once): MMD_STRIP_BLOCKS, default 256
     const char* e = getenv("MMD_STRIP_BLOCKS");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 448;
+    return v > 0 ? v : 256;
   }();
   int nsplit = 1;
   for (int d = 1; d <= nch && d <= 16; ++d)

@@ -18,6 +18,7 @@
 // Workgroup = 4 waves = 8 pixels x 16 frames = 128 rows x a range of column blocks (the column split fills the chip at the small
 // levels: 4096 rows are 32 row blocks); <= 64 KB of LDS + tables, <= 256 VGPRs: two workgroups per CU.
 #include "mmd_common.h"
+#include <cstdlib>
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -217,14 +218,19 @@ static int launch_tconv(const TConvParams& p, hipStream_t st) {
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "tconv: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  // column split (results do not depend on it): the smallest divisor of the column-block count that gives the chip >= 2 workgroups
-  // per CU - at ds8 (32 row blocks of 128 rows) every workgroup computes ONE 32-channel column block
+  // column split (results do not depend on it): the smallest divisor of the column-block count that gives the chip ONE workgroup per CU
+  // (two until round 5: see the row-strip GEMM's split, mmd_gemm.hip - the second slot of a CU is the other launch chain's)
   const int rowblocks = p.N * (p.HW / 8), ncb = p.Cout / CC;
+  static const int want_blocks = [] {                     // tuning switch (read once): MMD_TCONV_BLOCKS
+    const char* e = getenv("MMD_TCONV_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 256;
+  }();
   int nsplit = 1;
   for (int d = 1; d <= ncb; ++d)
     if (ncb % d == 0) {
       nsplit = d;
-      if ((int64_t)rowblocks * d >= 512) break;
+      if ((int64_t)rowblocks * d >= want_blocks) break;
     }
   TConvParams q = p;
   q.nsplit = nsplit;

@@ -371,10 +371,10 @@ class UNetEngine:
                 pass
             elif vid:
                 if t0 is not None:
-                    t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
+                        t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
                                        self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,
                                        dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
-                    self._release(t0)
+                        self._release(t0)
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
                 wtk = f"{p}.video_in_layers.2.video_conv_temporal.weight"
                 if self._tconv and ops.tconv_ok(t1, cout, N, F, Hh * Hh):

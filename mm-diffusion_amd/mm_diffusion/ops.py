@@ -65,6 +65,9 @@ def record_sync(src, dst):
 # EXPERIMENT switch (timing only, never set by the product or the tests): MMD_SKIP_SID=0 / 1 drops the launches of the video / audio
 # chain from a replayed plan - the step time without one chain bounds what that chain costs the other (interference + waits)
 _SKIP_SID = int(os.environ["MMD_SKIP_SID"]) if os.environ.get("MMD_SKIP_SID", "") in ("0", "1") else None
+# likewise timing only: MMD_SKIP_WAIT=10 drops every "video stream waits for the audio stream" marker, =01 the opposite direction - how long
+# does a chain actually stand waiting for the other one (the numbers of such a run mean nothing)
+_SKIP_WAIT = os.environ.get("MMD_SKIP_WAIT", "")
 
 
 def run_plan(plan, stream, aux_stream=None):
@@ -76,6 +79,8 @@ def run_plan(plan, stream, aux_stream=None):
         if fn is None:
             if aux_stream is not None:
                 src, dst, ev = args
+                if _SKIP_WAIT and _SKIP_WAIT == f"{src}{dst}":
+                    continue
                 if lib.mmd_event_record(ev, streams[src]) or lib.mmd_stream_wait_event(streams[dst], ev):
                     raise H.MMDError(f"sync failed: {lib.mmd_last_error().decode()}")
             continue
@@ -435,15 +440,21 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     return out
 
 
+# the threshold of the fuse / unfuse rule below.  It was the strip kernel's own split target until round 5; the kernel now splits for ONE block per
+# CU (256, mmd_gemm.hip: MMD_STRIP_BLOCKS) and the rule kept its 448 (following the kernel - MMD_STRIP_BLOCKS_RULE=256, more norms fused -
+# measured 10.98 against 10.94 ms: no gain)
+_STRIP_BLOCKS_RULE = int(os.environ.get("MMD_STRIP_BLOCKS_RULE", "448"))
+
+
 def strip_column_split(M, K, Cout):
-    """The column split conv_gemm tile 131 launches with (mmd_gemm.hip: launch_conv1x1_strip_mode): the smallest divisor of the chunk
-    count that gives the chip >= 448 blocks, at most 16."""
+    """The column split the fuse / unfuse rule of gn_fusable reasons with: the smallest divisor of the chunk count that gives the chip
+    >= _STRIP_BLOCKS_RULE blocks, at most 16 (the kernel's own split - mmd_gemm.hip: launch_conv1x1_strip_mode - aims for 256 since round 5)."""
     rf, cc = (2, 64) if K <= 256 else (1, 32)
     rowblocks, nch, n = -(-M // (128 * rf)), Cout // cc, 1
     for d in range(1, min(nch, 16) + 1):
         if nch % d == 0:
             n = d
-            if rowblocks * d >= 448:
+            if rowblocks * d >= _STRIP_BLOCKS_RULE:
                 break
     return n
 
