@@ -416,3 +416,48 @@ def test_tconv_register_model():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(seed=2) < 1e-12
+
+
+def test_profile_summarisers_on_a_synthetic_trace(tmp_path):
+    """tools/kt_by_shape.py (kernel trace per launch shape and HW queue over the last replayed steps) and tools/clock_summary.py (GRBM_GUI_ACTIVE /
+    dispatch wall time per kernel) on a hand-made rocprofv3 csv: three replayed steps of two kernels on two queues."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = ('"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp",'
+           '"End_Timestamp","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y",'
+           '"Workgroup_Size_Z","Grid_Size_X","Grid_Size_Y","Grid_Size_Z"')
+    rows, disp, t, did = [hdr], [], 1_000_000, 0
+    for step in range(4):                                   # 4 x ddpm_update marks = 3 complete steps behind the first mark
+        for q, name, grid, dur in ((4, "void conv1x1_strip_kernel<8, 1, 32, 0, 0>(ConvGemmParams, int)", 131072, 12_000),
+                                   (4, "void conv1x1_strip_kernel<8, 1, 32, 0, 0>(ConvGemmParams, int)", 65536, 8_000),
+                                   (1, "gn_finalize_rec_kernel(float const*, long)", 8192, 4_000),
+                                   (4, "ddpm_update_kernel(DdpmParams)", 4096, 2_000)):
+            did += 1
+            rows.append(f'"KERNEL_DISPATCH","Agent 2",{q},0,1,{did},7,"{name}",{did},{t},{t + dur},0,0,64,0,32,256,1,1,{grid},1,1')
+            disp.append((did, name, t, t + dur))
+            t += dur + 1_000
+        t += 3_000_000                                      # the gap between replayed steps
+    trace = tmp_path / "kt_kernel_trace.csv"
+    trace.write_text("\n".join(rows) + "\n")
+    out = tmp_path / "by_shape.txt"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kt_by_shape.py"), str(trace), str(out), "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = out.read_text()
+    assert "last 3 replayed steps" in txt and "queue 4" in txt and "queue 1" in txt
+    line = [ln for ln in txt.splitlines() if "conv1x1_strip_kernel<8, 1, 32, 0, 0> | 131072x1x1" in ln][0].split()
+    assert float(line[0]) == 1.0 and float(line[2]) == 12.0 and float(line[3]) == 12.0          # one launch per step, 12 us average and minimum
+    assert any("conv1x1_strip_kernel<8, 1, 32, 0, 0> | 65536x1x1" in ln for ln in txt.splitlines())   # the same kernel, another shape: its own row
+    # clock summary: 1.7 GHz x 8 XCCs x the dispatch's wall time in the counter
+    pmc = tmp_path / "pmc"
+    pmc.mkdir()
+    (pmc / "p_kernel_trace.csv").write_text("\n".join(rows) + "\n")
+    cc = ['"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"']
+    for d, name, s, e in disp:
+        cc.append(f'{d},{d},"Agent 2",4,1,1,4096,7,"{name}",256,0,0,64,0,32,"GRBM_GUI_ACTIVE",{8 * 1.7 * (e - s)},{s},{e}')
+    (pmc / "p_counter_collection.csv").write_text("\n".join(cc) + "\n")
+    out2 = tmp_path / "clocks.txt"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "clock_summary.py"), str(pmc), str(out2), "strip"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    row = [ln for ln in out2.read_text().splitlines() if "conv1x1_strip_kernel" in ln][0].split()
+    assert abs(float(row[4]) - 1.7) < 1e-3                  # GHz(sum / 8)
