@@ -164,6 +164,27 @@ def require_cuda(*tensors):
             raise MMDError("the MI355X HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")
 
 
+class preserve_rng:
+    """Keep torch's default generator of `device` out of plan building.  The per-shape tile autotuner (ops._pick_tile) fills its scratch
+    inputs with N(0,1) from that generator the FIRST time a shape is seen in a process, so without this a seeded sampling loop
+    (`th.manual_seed(s)` ... `p_sample_loop`, reference gd:547-550 / 453-454) would draw a different noise stream depending on whether
+    the engine was already built - the reference's stream has no such consumer (measured: profiles/r05_rccl_world1_and_rng.txt)."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        self.state = None
+
+    def __enter__(self):
+        if self.dev.type == "cuda":
+            self.state = torch.cuda.get_rng_state(self.dev)
+        return self
+
+    def __exit__(self, *exc):
+        if self.state is not None:
+            torch.cuda.set_rng_state(self.state, self.dev)
+        return False
+
+
 # ----------------------------------------------------------------------------- lifetime of HIP handles
 # Graph execs, events and streams are owned by Python objects (engines, steppers) that sit in reference cycles, so their
 # finalisers run from the cyclic GC at arbitrary points - e.g. in the middle of ANOTHER engine's stream capture, where

@@ -373,7 +373,7 @@ class ImageUnet(nn.Module):
             H.reap()
             g = dict(ins=[torch.zeros(t.shape, dtype=torch.float32, device=dev) for t in inputs],
                      t=torch.zeros(timesteps.shape, dtype=timesteps.dtype, device=dev), plan=[], keep=[], stream=H.Stream(dev))
-            with ops.recording(g["plan"], keep=g["keep"]):
+            with H.preserve_rng(dev), ops.recording(g["plan"], keep=g["keep"]):
                 g["out"] = body(tuple(g["ins"]), g["t"])
             side = g["stream"].torch
             side.wait_stream(torch.cuda.current_stream(dev))

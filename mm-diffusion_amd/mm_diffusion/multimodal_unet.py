@@ -302,7 +302,9 @@ class MultimodalUNet(nn.Module):
         key = (int(batch), self.dtype, str(device)) + ((int(replica),) if replica else ())
         eng = self._engines.get(key)
         if eng is None or eng.stale():
-            eng = UNetEngine(self, int(batch), self.dtype, device)
+            from . import _hip as H
+            with H.preserve_rng(device):                  # the plan builder's autotuner must not consume the caller's noise stream
+                eng = UNetEngine(self, int(batch), self.dtype, device)
             self._engines[key] = eng
         return eng
 

@@ -461,3 +461,29 @@ def test_profile_summarisers_on_a_synthetic_trace(tmp_path):
     assert r.returncode == 0, r.stderr
     row = [ln for ln in out2.read_text().splitlines() if "conv1x1_strip_kernel" in ln][0].split()
     assert abs(float(row[4]) - 1.7) < 1e-3                  # GHz(sum / 8)
+
+
+def test_preserve_rng_restores_the_device_generator(monkeypatch):
+    """_hip.preserve_rng (around plan building: the tile autotuner draws N(0,1) scratch data from torch's default device generator, which a
+    seeded sampling loop must not see - profiles/r05_rccl_world1_and_rng.txt): a no-op for CPU devices, and for a device generator the state
+    saved on entry is put back on exit, also when the body raises.  The GPU half (seeded trajectories bitwise equal whether or not the plan
+    was built after seeding) is tools/rccl_world1_check.py."""
+    from mm_diffusion import _hip as H
+    calls = []
+    monkeypatch.setattr(torch.cuda, "get_rng_state", lambda dev: calls.append(("get", str(dev))) or "STATE")
+    monkeypatch.setattr(torch.cuda, "set_rng_state", lambda st, dev: calls.append(("set", st, str(dev))))
+    with H.preserve_rng("cpu"):
+        pass
+    assert calls == []
+    with H.preserve_rng(torch.device("cuda", 0)):
+        calls.append("body")
+    assert calls == [("get", "cuda:0"), "body", ("set", "STATE", "cuda:0")]
+    calls.clear()
+    with pytest.raises(RuntimeError):
+        with H.preserve_rng("cuda:0"):
+            raise RuntimeError("plan building failed")
+    assert calls == [("get", "cuda:0"), ("set", "STATE", "cuda:0")]
+    import inspect
+    from mm_diffusion import image_unet, multimodal_unet
+    assert "preserve_rng" in inspect.getsource(multimodal_unet.MultimodalUNet.engine)
+    assert "preserve_rng" in inspect.getsource(image_unet)
