@@ -487,3 +487,15 @@ def test_preserve_rng_restores_the_device_generator(monkeypatch):
     from mm_diffusion import image_unet, multimodal_unet
     assert "preserve_rng" in inspect.getsource(multimodal_unet.MultimodalUNet.engine)
     assert "preserve_rng" in inspect.getsource(image_unet)
+
+
+def test_head_gemm_register_model():
+    """tools/head_gemm_model.py: lane-level model of head_gemm_kernel and of the (hi, lo) weight image of ops.head_gemm_pack - fragment
+    addresses in LDS, the activation fragment with the GroupNorm slice table, accumulator register -> (output, row) -> P[o][m], every
+    element written exactly once - against (hi + lo) . act(x a + b) in float64 (exact: bf16 products)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "head_gemm_model.py")
+    spec = importlib.util.spec_from_file_location("head_gemm_model", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check(seed=3) < 1e-12
