@@ -245,7 +245,8 @@ int mmd_tconv(const void* X, int64_t ldx, const void* Wf, const float* bias, voi
  * k_rows_per_batch, j < win*k_per_group.  shift_dev: device int (nullable = 0) so a captured graph can be
  * replayed with a new shift.  Head h uses columns {q,k,v}_off + h*ch.  impl: 0 auto, 1 force the VALU kernel, 2 the per-128-query
  * MFMA kernel (register-staged K / V), 3 the staged-window kernel, 4 the DMA-staged kernel (head width 64: K / V tiles by
- * buffer_load ... lds, V^T fragments by transposing LDS reads; bitwise equal to 2). */
+ * buffer_load ... lds, V^T fragments by transposing LDS reads; bitwise equal to 2), 5 the software-pipelined kernel whose loop
+ * iteration is one hand-written instruction stream (head width 64; bitwise equal to 2). */
 int mmd_attn_fwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off, int v_off, void* O,
                  int64_t ldo, int heads, int ch, int nb, int G, int64_t q_rows_per_batch, int q_per_group,
                  int64_t k_rows_per_batch, int k_per_group, int win, const int* shift_dev, int impl, void* stream);

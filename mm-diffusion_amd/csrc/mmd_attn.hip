@@ -532,6 +532,287 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const AttnParams p) {
   }
 }
 
+// ============================================================================= hand-placed pipelined attention (bf16, head width 64; round 6)
+// attn_dma_kernel above leaves the ORDER of a tile's ~300 instructions to hipcc, which emits them as three blocks: 8 S^T MFMAs, ~190 VALU
+// instructions of softmax, 8 P V MFMAs (ISA of round 5).  A wave issues in order: during an MFMA block it stalls 32 cycles per MFMA with
+// nothing else to issue, during the VALU block the matrix pipe has nothing from this wave - SQ counters: MFMA pipe busy 32.6 %, and five
+// compiler-scheduled restructurings (rounds 3 - 4) measured nothing.  Here the order is fixed by hand:
+//   * software pipeline over key tiles: iteration t runs the softmax of tile t (VALU) and, BETWEEN its instructions, the S^T MFMAs of tile
+//     t + 1 and the P V MFMAs of tile t - one MFMA per ~10 VALU slots, so each MFMA's 32-cycle shadow is filled by the wave's own VALU
+//     work instead of a stall;
+//   * the whole iteration is ONE asm statement with literal registers (tools/gen_attn_pipe.py writes it: a list scheduler over the
+//     iteration's dependency graph under the machine's hazard rules, counted `s_waitcnt lgkmcnt(N)` computed from the order of the LDS
+//     reads, a linear-scan allocation of the temporaries); the compiler only sees the interface registers;
+//   * the O rescale is unconditional (alpha == 1.0 exactly where the running max did not move): no branch in the stream;
+//   * key tiles by descriptor DMA as above, but K runs TWO tiles ahead and V one (S^T of tile t + 1 needs K(t + 1) while P V still reads
+//     V(t)); a full tile with no wrap of the circular window inside takes a lane-constant offset + a scalar tile offset (no per-tile
+//     address VALU at all), the ragged / wrapping tile the per-lane form;
+//   * waves whose 32 queries lie beyond the group (the 16-query tail block of the 400-query audio groups) only stage and synchronise.
+// Same arithmetic, same order of every sum as attn_mfma_kernel: bitwise the same output (tests/test_round6_gpu.py).
+#include "mmd_attn_pipe_body.inc"
+// One pipelined iteration = one asm statement (generated, literal registers): softmax of the tile whose scores are in `sa` and its P V
+// into o, S^T of the next tile into `sb`.  VAR = A: sa = v[0:31], sb = v[32:63], K stage 1, V stage 0;  B: the two sets and stages swapped.
+#define ATTN_PIPE_ITER(VAR)                                                                                                            \
+  asm volatile(ATTN_PIPE_ASM_##VAR                                                                                                     \
+               : "+{v[0:15]}"(s0[0]), "+{v[16:31]}"(s0[1]), "+{v[32:47]}"(s1[0]), "+{v[48:63]}"(s1[1]), "+{v[64:79]}"(o[0]),           \
+                 "+{v[80:95]}"(o[1]), "+{v119}"(m_run), "+{v120}"(l_run)                                                               \
+               : "{v[96:99]}"(qf[0]), "{v[100:103]}"(qf[1]), "{v[104:107]}"(qf[2]), "{v[108:111]}"(qf[3]), "{v112}"(ka[0]),            \
+                 "{v113}"(ka[1]), "{v114}"(ka[2]), "{v115}"(ka[3]), "{v116}"(va[0]), "{v117}"(va[1]), "{v118}"(sc)                     \
+               : ATTN_PIPE_CLOBBERS, "memory")
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
+  static_assert(D == 64, "pipelined attention: head width 64 (one 128-byte LDS row per key)");
+  constexpr int KST = D / 16, DT = D / 32, TILE_B = 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                     // [2 stages][64 keys][128 B]
+  char* sV = smem + 2 * TILE_B;        // [2 stages][64 keys][128 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int qt, h, bg;
+  attn_block_coords(qt, h, bg);
+  const GroupInfo gi = group_info(p, bg);
+  const int q0 = qt * 128;
+  if (q0 >= gi.q_count) return;        // uniform per block
+  const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 domain
+  const bool active = q0 + wave * 32 < gi.q_count;  // (wave-uniform) a wave without queries stages its share of K / V and keeps the barriers
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l31, half) holds d = 16 s + 8 half + [0, 8)
+  const int qi = q0 + wave * 32 + l31;
+  const bool qok = qi < gi.q_count;
+  u32x4 qf[KST];
+  {
+    const char* qp = p.Q + ((gi.q_row0 + qi) * p.ldq + p.q_off + h * D) * 2;
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qok) v = *(const u32x4*)(qp + (s * 16 + half * 8) * 2);
+      qf[s] = v;
+    }
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // ---- DMA: wave w stages row groups {w, w + 4} of K and of V; lane L of a group covers row 8 g + L / 8, physical chunk L % 8
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.KV, 0, (int)((int64_t)p.nb * p.k_rows_per_batch * p.ldkv * 2), 0x00020000);
+  const int lrow = lane >> 3, pc = lane & 7;
+  const uint32_t ldb = (uint32_t)(p.ldkv * 2);
+  const uint32_t kcol_s = (uint32_t)((p.k_off + h * D) * 2), vcol_s = (uint32_t)((p.v_off + h * D) * 2);   // (scalar) column of this head
+  int row_in_tile[2];
+  uint32_t kswz[2], vswz[2], kfast[2], vfast[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + 4 * i) + lrow;
+    row_in_tile[i] = row;
+    kswz[i] = (uint32_t)((pc ^ ((row >> 1) & 7)) * 16);
+    vswz[i] = (uint32_t)((pc ^ (((row >> 1) & 1) << 2)) * 16);
+    kfast[i] = (uint32_t)row * ldb + kswz[i];
+    vfast[i] = (uint32_t)row * ldb + vswz[i];
+  }
+  // tile T of the window into `stage`: K rows (which == 0) or V rows (which == 1)
+  auto issue = [&](int which, int stage, int T) {
+    const int kt0 = T * 64;
+    int r0 = gi.k_start + kt0;
+    r0 = r0 >= gi.k_mod ? r0 - gi.k_mod : r0;
+    char* dst = (which ? sV : sK) + stage * TILE_B;
+    if (kt0 + 64 <= gi.k_count && r0 + 64 <= gi.k_mod) {      // (uniform) all 64 rows inside the window, no wrap inside the tile
+      const uint32_t so = (uint32_t)(gi.k_row0 + r0) * ldb + (which ? vcol_s : kcol_s);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + (wave + 4 * i) * 1024), 16, which ? vfast[i] : kfast[i], so, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = kt0 + row_in_tile[i];
+        int r = gi.k_start + kk;
+        r = r >= gi.k_mod ? r - gi.k_mod : r;
+        const uint32_t off = (uint32_t)(gi.k_row0 + r) * ldb + (which ? vcol_s + vswz[i] : kcol_s + kswz[i]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + (wave + 4 * i) * 1024), 16, kk < gi.k_count ? off : 0xfffffff0u, 0, 0, 0);
+      }
+    }
+  };
+  // fragment addresses (LDS byte addresses for the asm reads).  K: row 32 kt + l31, logical chunk 2 st + half.  V^T by transposing reads:
+  // group (kt, st, u) of 4 keys, key0 = 32 kt + 16 st + 8 u + 4 half; this lane supplies row key0 + (lane & 15) / 4, columns
+  // dt * 32 + 16 ((lane >> 4) & 1) + 4 (lane & 3); the chunk swizzle of a V row depends on bit 1 of the row = bit 1 of vrow0
+  const int kx = (l31 >> 1) & 7;
+  const char* kbase = sK + l31 * 128;
+  const int vrow0 = 4 * half + ((lane & 15) >> 2);
+  const int vcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  uint32_t ka[KST], va[DT];
+#pragma unroll
+  for (int st = 0; st < KST; ++st) ka[st] = lds0 + (uint32_t)(l31 * 128 + (((2 * st + half) ^ kx) * 16));
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+    va[dt] = lds0 + (uint32_t)(vrow0 * 128 + ((((vcolb >> 4) + 4 * dt) ^ ((vrow0 & 2) << 1)) * 16) + (vcolb & 15));
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4* lp4;
+
+  const int ntiles = (gi.k_count + 63) >> 6;
+  issue(0, 0, 0);
+  issue(1, 0, 0);
+  if (ntiles > 1) issue(0, 1, 1);
+  // ---- prologue: S^T of tile 0 (compiler-scheduled, as in attn_dma_kernel)
+  f32x16 s0[2], s1[2];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (active) {
+    u32x4 kf[KST][2];
+#pragma unroll
+    for (int st = 0; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) kf[st][kt] = *(const u32x4*)(kbase + kt * 32 * 128 + (((2 * st + half) ^ kx) * 16));
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      s0[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0][kt]), __builtin_bit_cast(bf16x8, qf[0]), z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int st = 1; st < KST; ++st)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        s0[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[st][kt]), __builtin_bit_cast(bf16x8, qf[st]), s0[kt], 0, 0, 0);
+    // the loop's first statements read these accumulators from asm, where hipcc does not pad the MFMA -> VALU distance
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(s0[0]), "+v"(s0[1]));
+  }
+  // ---- pipelined iterations t = 0 .. ntiles - 2 (unrolled by two: the stage offsets are literals)
+  auto top = [&](int t) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // K(t + 1), V(t) landed for everyone; everyone is past K(t), V(t - 1)
+    if (t + 2 < ntiles) issue(0, t & 1, t + 2);
+    if (t + 1 < ntiles) issue(1, (t + 1) & 1, t + 1);
+    asm volatile("" ::: "memory");
+  };
+  int t = 0;
+  for (; t + 2 < ntiles; t += 2) {
+    top(t);
+    if (active) ATTN_PIPE_ITER(A);
+    top(t + 1);
+    if (active) ATTN_PIPE_ITER(B);
+  }
+  if (t + 1 < ntiles) {
+    top(t);
+    if (active) {
+      ATTN_PIPE_ITER(A);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(s1[0]), "+v"(s1[1]));
+      s0[0] = s1[0];
+      s0[1] = s1[1];
+    }
+    ++t;
+  }
+  // ---- drain: softmax and P V of the last tile (t == ntiles - 1; the only one that can be ragged), compiler-scheduled
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (active) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(s0[0]), "+v"(s0[1]));
+    const char* vb = sV + (t & 1) * TILE_B;
+    bf16x8 vf[2][2][DT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          s16x4 lo, hi;
+          {
+            const int row = 32 * kt + 16 * st + vrow0;
+            const int ch = ((vcolb >> 4) + 4 * dt) ^ (((row >> 1) & 1) << 2);
+            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(vb + row * 128 + ch * 16 + (vcolb & 15)));
+          }
+          {
+            const int row = 32 * kt + 16 * st + 8 + vrow0;
+            const int ch = ((vcolb >> 4) + 4 * dt) ^ (((row >> 1) & 1) << 2);
+            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(vb + row * 128 + ch * 16 + (vcolb & 15)));
+          }
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          vf[kt][st][dt] = __builtin_bit_cast(bf16x8, both);
+        }
+    if (gi.k_count & 63) {                                           // (uniform) ragged last tile: keys beyond the window never win
+      const int kbase2 = t * 64 + 4 * half;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = kbase2 + 32 * kt + (r & 3) + 8 * (r >> 2);
+          s0[kt][r] = kk < gi.k_count ? s0[kt][r] : -3e38f;
+        }
+    }
+    float ps = 0.f;
+    float mx = -3e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s0[kt][r]);
+    mx = half_pair_max(mx);
+    const float m_new = fmaxf(m_run, mx * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[kt][r], sc, -m_new));
+        s0[kt][r] = e;
+        ps += e;
+      }
+    ps = half_pair_sum(ps);
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    m_run = m_new;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s0[kt][8 * st + j];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][st][dt], pf, o[dt], 0, 0, 0);
+      }
+  }
+  // ---- normalise, transpose through LDS (stage 0 of K / V: free after the last tile) and store whole 128-byte head rows
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (active) {
+    constexpr int SO = D * 2 + 16;           // padded row of the transposed tile
+    const float inv = 1.f / l_run;
+    if (p.lse2 && half == 0 && qok) p.lse2[(gi.q_row0 + qi) * p.heads + h] = m_run + __builtin_amdgcn_logf(l_run);
+    char* so = smem + (wave * 32) * SO;      // this wave's 32 rows; written and read by this wave only (4 x 4.6 KB < 32 KB)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * half;
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[dt][4 * q4 + e] * inv);
+        *(bf16x4*)(so + l31 * SO + d * 2) = w;
+      }
+    const int tq = q0 + wave * 32;
+#pragma unroll
+    for (int ps2 = 0; ps2 < 32 * (D / 8) / 64; ++ps2) {
+      const int idx = ps2 * 64 + lane;
+      const int row = idx / (D / 8), v = idx % (D / 8);
+      if (tq + row < gi.q_count) {
+        const u32x4 x = *(const u32x4*)(so + row * SO + v * 16);
+        *(u32x4*)(p.O + ((gi.q_row0 + tq + row) * p.ldo + h * D + v * 8) * 2) = x;
+      }
+    }
+  }
+}
+
 // Round 4 also built a 64-queries-per-wave form of the kernel above (8 waves, two 32-query sub-tiles per wave sharing every K / V fragment
 // read; key tiles streamed, or - video <- audio - the whole key window resident in LDS with no barrier in the loop), bitwise equal and
 // tested, and measured it: 109.0 vs 108.9 us (spatial ds2), 50.7 vs 51.2 us (v <- a ds2, resident), 48.9 vs 50.8 us (a <- v ds2), 1.5 -
@@ -1154,6 +1435,14 @@ static int launch_dma(const AttnParams& p, int qmax, hipStream_t st) {
 }
 
 template <int D>
+static int launch_pipe(const AttnParams& p, int qmax, hipStream_t st) {
+  const size_t lds = 4 * 64 * 128;
+  dim3 grid(cdiv(qmax, 128), p.heads, p.nb * p.G);
+  hipLaunchKernelGGL(attn_pipe_kernel<D>, grid, dim3(256), lds, st, p);
+  return mmd_check_launch("attn_pipe");
+}
+
+template <int D>
 static int launch_stage(const AttnParams& p, int qmax, hipStream_t st) {
   const size_t lds = (size_t)ATS_KEYS * (D * 2 + 16) + (size_t)D * ATS_VT_STRIDE;
   static bool attr_done[MMD_MAX_DEVICES] = {};
@@ -1218,8 +1507,12 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
   // the same kernel (the kernel family of a layer - and with it the last bits of its output - must not depend on the batch size)
   const int64_t kv_batch_bytes = k_rows_per_batch * ldkv * 2;
   const bool dma_ok = stage_ok && kv_batch_bytes < 0x7fffffffLL;
+  // hand-placed pipelined kernel (impl 5; round 6): same staging, same arithmetic, bitwise the same output
+  static const bool pipe_on = [] { const char* e = getenv("MMD_ATTN_PIPE"); return e && e[0] == '1'; }();
+  const bool use_pipe = impl == 5 || (impl == 0 && pipe_on);
+  if (impl == 5 && !dma_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 5 (pipelined): needs bf16, head width 64, aligned rows, one batch of K/V below 2 GB");
   if (impl == 4 && !dma_ok) return mmd_set_error(MMD_ERR_UNSUPPORTED, "attn_fwd impl 4 (DMA-staged): needs bf16, head width 64, aligned rows, one batch of K/V below 2 GB");
-  if (dma_ok && (impl == 4 || (impl == 0 && dma_on))) {
+  if (dma_ok && (impl == 4 || impl == 5 || (impl == 0 && dma_on))) {
     const int per = (int)(0x7fffffffLL / kv_batch_bytes) < nb ? (int)(0x7fffffffLL / kv_batch_bytes) : nb;
     for (int n0 = 0; n0 < nb; n0 += per) {
       AttnParams c = p;
@@ -1228,7 +1521,7 @@ static int attn_fwd_impl(int dtype, const void* Q, int64_t ldq, int q_off, const
       c.KV = p.KV + (int64_t)n0 * kv_batch_bytes;
       c.O = p.O + (int64_t)n0 * q_rows_per_batch * ldo * 2;
       if (p.lse2) c.lse2 = p.lse2 + (int64_t)n0 * q_rows_per_batch * heads;
-      const int rc = launch_dma<64>(c, qmax, st);
+      const int rc = use_pipe ? launch_pipe<64>(c, qmax, st) : launch_dma<64>(c, qmax, st);
       if (rc != MMD_OK) return rc;
     }
     return MMD_OK;

@@ -499,3 +499,23 @@ def test_head_gemm_register_model():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(seed=3) < 1e-12
+
+
+def test_attn_pipe_stream_generator():
+    """tools/gen_attn_pipe.py: the committed instruction stream of attn_pipe_kernel<64> is what the generator writes today, and the
+    generator's own replay holds - every register read still holds the temporary it names (linear-scan allocation), the hazard
+    distances (v_exp -> use, v_cvt_pk / rescale -> MFMA operand) hold on the final order, no MFMA reads an LDS destination in front
+    of its counted wait, 16 MFMAs / 24 LDS reads per iteration."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_attn_pipe", os.path.join(root, "tools", "gen_attn_pipe.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text, order, nops, mf, top = mod.generate()
+    assert open(mod.OUT).read() == text, "mmd_attn_pipe_body.inc is stale: run python tools/gen_attn_pipe.py"
+    assert len(mf) == 16 and top <= 255 and nops <= 4
+    assert min(b - a for a, b in zip(mf, mf[1:])) >= mod.MFMA_GAP
+    # the two variants differ only in the score-set registers and the stage offsets
+    a = text[text.index("#define ATTN_PIPE_ASM_A"):text.index("#define ATTN_PIPE_ASM_B")].count("v_mfma")
+    b = text[text.index("#define ATTN_PIPE_ASM_B"):text.index("#define ATTN_PIPE_CLOBBERS")].count("v_mfma")
+    assert a == b == 16

@@ -27,7 +27,7 @@ def main():
         H.call("mmd_event_create", ctypes.byref(e))
     st = H.stream_handle()
     only = os.environ.get("ATTN_BENCH_SHAPES")
-    impls = tuple(int(v) for v in os.environ.get("ATTN_BENCH_IMPLS", "2,3,4").split(","))
+    impls = tuple(int(v) for v in os.environ.get("ATTN_BENCH_IMPLS", "2,4,5").split(","))
     for si, (name, qr, qg, kr, kg, win, heads, ch) in enumerate(SHAPES):
         if only and str(si) not in only.split(","):
             continue
@@ -39,8 +39,8 @@ def main():
         flops = 4.0 * N * qr * win * kg * C
         line = f"{name:22s} ({flops/1e9:5.1f} GF)"
         ref = None
-        for impl in impls:             # 2 = per-128-query MFMA kernel, 3 = staged-window kernel, 4 = DMA-staged kernel (head width 64 only)
-            if impl in (3, 4) and ch != 64:
+        for impl in impls:             # 2 = per-128-query MFMA kernel, 3 = staged-window kernel, 4 = DMA-staged kernel, 5 = hand-written pipelined kernel (head width 64 only)
+            if impl in (3, 4, 5) and ch != 64:
                 continue
             out = torch.zeros(N * qr, C, device="cuda", dtype=dt)
             for _ in range(2):
