@@ -1436,7 +1436,18 @@ static int launch_dma(const AttnParams& p, int qmax, hipStream_t st) {
 
 template <int D>
 static int launch_pipe(const AttnParams& p, int qmax, hipStream_t st) {
-  const size_t lds = 4 * 64 * 128;
+  // tuning switch (read once; tools only): MMD_ATTN_PIPE_LDSPAD = extra bytes of LDS per block, e.g. 65536 = one block per CU
+  static const int pad = [] { const char* e = getenv("MMD_ATTN_PIPE_LDSPAD"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 120 * 1024 ? v : 0; }();
+  const size_t lds = 4 * 64 * 128 + (size_t)pad;
+  if (pad) {
+    static bool attr_done[MMD_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[mmd_device_slot()];
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)attn_pipe_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return mmd_set_error(MMD_ERR_LAUNCH, "attn_pipe: set LDS attr");
+      attr_set = true;
+    }
+  }
   dim3 grid(cdiv(qmax, 128), p.heads, p.nb * p.G);
   hipLaunchKernelGGL(attn_pipe_kernel<D>, grid, dim3(256), lds, st, p);
   return mmd_check_launch("attn_pipe");

@@ -40,6 +40,11 @@ OUT = os.path.join(ROOT, "mm-diffusion_amd", "csrc", "mmd_attn_pipe_body.inc")
 MFMA_GAP = 9        # instructions between consecutive MFMAs (minimum)
 LDS_AHEAD = 10      # instructions between an LDS read and the wait of its consumer (minimum)
 REUSE_GAP = 4       # instructions before a register read by an MFMA may be redefined
+VALU_DIST = 2       # instructions between a VALU result and its first use: a dependent VALU instruction issued right behind its
+                    # producer waits for it; measured (profiles/r06_attn_pipe_variants.txt): distances 1 .. 4 run the same 99 - 101 us - the
+                    # stream is not bound by it; 2 keeps the temporaries at 25 registers
+K_UPFRONT = 4       # K fragment reads issued at the top of the iteration (the rest follow the S^T MFMAs one by one)
+ALIGN_PAD = 0       # s_nop 0 instructions behind the `.p2align 3` that opens the stream (4-byte phase of the instruction stream)
 SCALE_BONUS = (30, 12)   # priority of the O rescale (d tile 0, 1) over the exp stream: the first P V MFMA waits for both
 TEMP0 = 121
 
@@ -64,9 +69,11 @@ class Sched:
         self.last_def = {}
         self.width = {}        # temp name -> registers
 
-    def add(self, name, text, kind, defs=(), uses=(), extra=(), dist=1):
+    def add(self, name, text, kind, defs=(), uses=(), extra=(), dist=None):
         op = Op(name, text, kind)
-        op.res_dist = dist     # distance this op's results need before a use
+        if dist is None:
+            dist = VALU_DIST if kind in ("valu", "trans") else 1
+        op.res_dist = max(dist, VALU_DIST) if kind in ("valu", "trans") else dist     # distance this op's results need before a use
         for u in uses:
             if u in self.last_def:
                 p = self.last_def[u]
@@ -142,10 +149,10 @@ def build():
         lds_prev[0] = op
         return op
 
-    def kread(n):
+    def kread(n, after=None):
         st, kt = divmod(n, 2)
         S.width[f"kf{n}"] = 4
-        return lds(f"k{n}", f"ds_read_b128 {{kf{n}:4}}, {{ka{st}}} offset:@K+{kt * 4096}", [f"kf{n}_raw"])
+        return lds(f"k{n}", f"ds_read_b128 {{kf{n}:4}}, {{ka{st}}} offset:@K+{kt * 4096}", [f"kf{n}_raw"], after)
 
     def vread(g, dt, u, after=None):
         kt, st = divmod(g, 2)
@@ -154,9 +161,9 @@ def build():
         return lds(f"v{g}{dt}{u}", f"ds_read_b64_tr_b16 {{vf{g}{dt}.{2 * u}:2}}, {{va{dt}}} offset:@V+{off}", [f"vf{g}{dt}_raw{u}"], after)
 
     reads = {}
-    for n in range(8):
+    for n in range(K_UPFRONT):
         reads[f"k{n}"] = kread(n)
-        reads[f"k{n}"].bonus = 2000                      # the K fragments go out before anything else (32 registers)
+        reads[f"k{n}"].bonus = 2000                      # the first K fragments go out before anything else
     mf_prev = None
     vq = [(g, dt) for g in range(4) for dt in range(2)]
     for n in range(8):                                   # S^T MFMAs of tile t + 1: (st, kt) = divmod(n, 2)
@@ -168,6 +175,8 @@ def build():
         m = add(f"S{n}", f"v_mfma_f32_32x32x16_bf16 {{sb{kt}:16}}, {{kf{n}:4}}, {{qf{st}:4}}, {c}", "mfma", [f"sb{kt}"],
                 [f"kf{n}"] + ([f"sb{kt}"] if st else []), extra)
         mf_prev = m
+        if n + K_UPFRONT < 8:                            # the other K fragments one by one behind the first S^T MFMAs (registers)
+            reads[f"k{n + K_UPFRONT}"] = kread(n + K_UPFRONT, after=m)
         if n >= 2:                                       # V^T fragment pairs 0 .. 5 go out behind S2 .. S7
             g, dt = vq[n - 2]
             reads[f"v{g}{dt}0"] = vread(g, dt, 0, after=m)
@@ -269,7 +278,8 @@ def verify(S, order, base):
             continue
         if op.kind == "wait":
             names = [n for n, _ in pending]
-            pending = pending[names.index(op.text.split()[1]) + 1:]
+            if op.text.split()[1] in names:          # (else: an earlier wait for a later read has covered it - LDS returns in order)
+                pending = pending[names.index(op.text.split()[1]) + 1:]
             continue
         toks = [(m.group(1), int(m.group(2) or 0), int(m.group(3) or 1)) for m in TOK.finditer(op.text)]
         swap = "permlane" in op.text
@@ -328,7 +338,22 @@ def render(S, order, base, variant):
     return lines
 
 
-def generate():
+def ablate(lines, kind):
+    """TIMING-ONLY variants of the stream (tools/attn_pipe_ablate.sh): the results are wrong, the durations say which resource binds."""
+    if kind == "nomfma":
+        return [ln for ln in lines if not ln.startswith("v_mfma")]
+    if kind == "novalu":
+        return [ln for ln in lines if ln.startswith(("v_mfma", "ds_read", "s_waitcnt"))]
+    if kind == "nolds":
+        return [ln for ln in lines if not ln.startswith(("ds_read", "s_waitcnt"))]
+    if kind == "noexp":
+        return [ln.replace("v_exp_f32", "v_mov_b32") for ln in lines]
+    if kind == "mfmaonly":
+        return [ln for ln in lines if ln.startswith("v_mfma")]
+    raise SystemExit("unknown ablation " + kind)
+
+
+def generate(abl=None):
     S = build()
     order, nops = schedule(S)
     assert sum(1 for o in order if o.kind == "mfma") == 16 and sum(1 for o in order if o.kind == "lds") == 24
@@ -344,6 +369,9 @@ def generate():
     ]
     for variant in "AB":
         lines = render(S, order, base, variant)
+        if abl:
+            lines = ablate(lines, abl)
+        lines = [".p2align 3"] + ["s_nop 0"] * ALIGN_PAD + lines
         out.append(f"#define ATTN_PIPE_ASM_{variant} \\")
         out += [f'  "{ln}\\n\\t" \\' for ln in lines[:-1]] + [f'  "{lines[-1]}"']
     out.append("#define ATTN_PIPE_CLOBBERS " + ", ".join(f'"v{r}"' for r in range(TEMP0, top + 1)))
@@ -351,7 +379,16 @@ def generate():
 
 
 def main():
-    text, order, nops, mf, top = generate()
+    abl = sys.argv[sys.argv.index("--ablate") + 1] if "--ablate" in sys.argv else None
+    for kv in sys.argv[1:]:                      # schedule parameters for experiments: MFMA_GAP=12 LDS_AHEAD=20 ...
+        if "=" in kv and kv.split("=")[0] in ("MFMA_GAP", "LDS_AHEAD", "REUSE_GAP", "VALU_DIST", "ALIGN_PAD", "K_UPFRONT"):
+            globals()[kv.split("=")[0]] = int(kv.split("=")[1])
+    text, order, nops, mf, top = generate(abl)
+    if "--out" in sys.argv:
+        with open(sys.argv[sys.argv.index("--out") + 1], "w") as f:
+            f.write(text)
+        print("wrote variant", abl, [b - a for a, b in zip(mf, mf[1:])])
+        return
     if "--stats" in sys.argv:
         print(f"{len(order)} instructions, {nops} pads, top v{top}, MFMAs at {mf}, gaps {[b - a for a, b in zip(mf, mf[1:])]}")
         for i, op in enumerate(order):
