@@ -238,6 +238,15 @@ int mmd_tconv_pack(const void* W, void* out, int Cin, int Cout, void* stream);
 int mmd_tconv(const void* X, int64_t ldx, const void* Wf, const float* bias, void* Y, int64_t ldy, int N, int F, int HW, int Cin,
               int Cout, float* stats, int64_t stats_ld, void* stream);
 
+/* The audio half of a ResBlock's in_layers in one launch (round 6): GroupNorm32(+FiLM) + SiLU + AudioConv (Conv1d, kernel 3, dilation,
+ * zero "same" padding) on channels-last rows of S = M / L samples (unet:339-346, 108-131; nn.py:16-33) - instead of mmd_gn_apply followed
+ * by mmd_conv_gemm with the taps (-d, 0, +d).  bf16.  X [M, ldx] (Cin columns), W [Cout][3 Cin] (mmd_conv_gemm's weight layout),
+ * ga / gb [S, Cin] = the fused affine written by mmd_gn_finalize_stats / mmd_gn_stats, act != 0: SiLU; a tap that leaves its sample
+ * contributes zero (the padding is zero AFTER the norm).  stats (nullable): quad records of Y as mmd_conv_gemm_stats writes them
+ * (M % 64 == 0).  Bitwise equal to the two launches it replaces (same K order, same rounding points). */
+int mmd_aconv(const void* X, int64_t ldx, const void* W, const float* bias, const float* ga, const float* gb, int act, void* Y, int64_t ldy,
+              int M, int L, int Cin, int Cout, int dil, float* stats, int64_t stats_ld, void* stream);
+
 /* softmax(q k^T / sqrt(ch)) v over query groups with circular key windows - SingleModalQKVAttention
  * (unet:221-240) and the random-shift cross-modal QKVAttention (unet:507-564; window addressing unet:614-647).
  * For batch n, group g (< G): queries = Q rows n*q_rows_per_batch + g*q_per_group + [0, q_per_group) (the last

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libmmd.so")
-SOURCES = ["mmd_core.hip", "mmd_gemm.hip", "mmd_vconv.hip", "mmd_tattn.hip", "mmd_tconv.hip", "mmd_norm.hip", "mmd_attn.hip", "mmd_misc.hip", "mmd_bwd.hip", "mmd_attn_bwd.hip", "mmd_attn_bwd_mfma.hip"]
+SOURCES = ["mmd_core.hip", "mmd_gemm.hip", "mmd_vconv.hip", "mmd_tattn.hip", "mmd_tconv.hip", "mmd_aconv.hip", "mmd_norm.hip", "mmd_attn.hip", "mmd_misc.hip", "mmd_bwd.hip", "mmd_attn_bwd.hip", "mmd_attn_bwd_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 FLAGS += os.environ.get("MMD_EXTRA_CXXFLAGS", "").split()      # ablation builds (tools/*_bench.py), never set for the product
 # The library is built WITHOUT the packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32).  Measured on MI355X

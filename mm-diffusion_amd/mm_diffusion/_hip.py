@@ -56,6 +56,7 @@ _PROTOS = {
     "mmd_tconv_weight_bytes": (i64, [i32, i32]),
     "mmd_tconv_pack": (i32, [vp, vp, i32, i32, vp]),
     "mmd_tconv": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp]),
+    "mmd_aconv": (i32, [vp, i64, vp, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp]),
     "mmd_tattn_weight_bytes": (i64, [i32, i32]),
     "mmd_tattn_pack": (i32, [vp, vp, vp, vp, i32, vp]),
     "mmd_tattn_block": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp]),

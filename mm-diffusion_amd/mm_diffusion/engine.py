@@ -89,7 +89,7 @@ class UNetEngine:
         # per step (profiles/r05_chain_interference_and_launch_modes.txt).  The mode is gone from the engine; the entry points stay in the
         # C ABI with their kernel-level tests.)
         self._gn_small = os.environ.get("MMD_GN_SMALL", "1") != "0"
-        self._vconv_fused = self._tattn_fused = self._tconv = dtype == torch.bfloat16
+        self._vconv_fused = self._tattn_fused = self._tconv = self._aconv = dtype == torch.bfloat16
         self._deferred = []           # video-stream buffers a launch of the AUDIO stream still reads (see _cross): released at the next sync
         H.reap()
         self._aux, self._side = H.Stream(self.device), H.Stream(self.device)
@@ -365,6 +365,13 @@ class UNetEngine:
                                       out=self._alloc(rows_in, cout))
                 self._release(ga, gb)
                 t0 = None
+            elif not vid and self._aconv and ops.aconv_ok(x, cout, N, L):
+                # in_layers norm + SiLU + dilated k = 3 conv in ONE launch (round 6): no normalised tensor, no gn_apply launch
+                ga, gb = self._gn_affine(x, f"{p}.{mod}_in_layers.0", gin, None)
+                h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
+                ops.aconv(x, ga, gb, self._gemm_w(f"{p}.audio_in_layers.2.audio_conv.weight"), self._f32(f"{p}.audio_in_layers.2.audio_conv.bias"),
+                          N, L, layer["dilation"], act=True, out=h, stats=self._stats_for(h))
+                self._release(ga, gb)
             else:
                 t0 = self._gn(x, f"{p}.{mod}_in_layers.0", gin, act=True)
             if h is not None:

@@ -651,6 +651,44 @@ def tconv(x, wf, bias, Cout, N, F, HW, out=None, stats=None):
     return out
 
 
+# The audio in_layers of a ResBlock in one launch (include/mmd.h: mmd_aconv): GroupNorm + SiLU + dilated k = 3 conv, rows stationary, K
+# streamed.  Bitwise equal to gn_apply + conv_gemm with taps_audio(dilation), so the switch (MMD_ACONV=0: the two launches) is a pure
+# speed choice - which is why it may depend on an environment variable at all.
+_ACONV = os.environ.get("MMD_ACONV", "1") != "0"
+# Where the engine uses it: the kernel redoes the normalisation (~8 VALU instructions per element with SiLU) for each of the three taps
+# and each column range of a row block, so it only pays where the column split is shallow - measured (profiles/r06_aconv_bench.txt, batch
+# 4): 25600 x 128 -> 128 36.8 vs 41.6 us, 6400 x 256 -> 256 35.1 vs 36.6 us, but 6400 x 640 -> 256 75 vs 50, 1600 x 896 -> 384 84 vs 59,
+# 400 x 1024 -> 512 63 vs 41 us (the same lesson as the row-strip kernel's fused norm in round 2).  Input widths up to MMD_ACONV_MAXCIN.
+_ACONV_MAXCIN = int(os.environ.get("MMD_ACONV_MAXCIN", "256"))
+
+
+def aconv_shape_ok(x, Cout, N, L):
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] == N * L and L >= 128 and x.shape[1] % 64 == 0 and 64 <= x.shape[1] <= 2048
+            and Cout % 64 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def aconv_ok(x, Cout, N, L):
+    return _ACONV and x.shape[1] <= _ACONV_MAXCIN and aconv_shape_ok(x, Cout, N, L)
+
+
+def aconv(x, a, b, w, bias, N, L, dilation, act=True, out=None, stats=None):
+    """x [N*L, Cin] bf16, a / b [N, Cin] fused GroupNorm affine, w [Cout, 3 Cin] packed conv weight -> [N*L, Cout] (mmd_aconv)."""
+    _chk2d(x)
+    M, Cin = x.shape
+    Cout = w.shape[0]
+    if not aconv_shape_ok(x, Cout, N, L) or w.shape[1] != 3 * Cin or w.dtype != torch.bfloat16 or not w.is_contiguous():
+        raise H.MMDError(f"aconv: unsupported launch (x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)} {w.dtype}, N={N} L={L})")
+    if tuple(a.shape) != (N, Cin) or tuple(b.shape) != (N, Cin) or a.dtype != torch.float32 or b.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()):
+        raise H.MMDError(f"aconv: the fused affine must be two contiguous fp32 [N, Cin] tensors (got {tuple(a.shape)}, {tuple(b.shape)})")
+    out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
+    _chk2d(out)
+    sp, sld = (None, 0) if stats is None else _stats_args(stats, M, Cout)
+    _dispatch("mmd_aconv", x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), a.data_ptr(), b.data_ptr(), 1 if act else 0, out.data_ptr(),
+              out.stride(0), M, L, Cin, Cout, int(dilation), sp, sld,
+              meta=(f"aconv<bf16>[M={M},K={3 * Cin},N={Cout}]", 2 * M * Cout * 3 * Cin, 2 * (M * Cin + M * Cout + Cout * 3 * Cin) + 4 * Cout))
+    return out
+
+
 # The temporal-attention block in one launch (include/mmd.h: mmd_tattn_block): GroupNorm over a pixel's frames, qkv, attention over the
 # frames, proj_out and the residual - instead of gn_small + qkv GEMM + attn_small + proj_out GEMM.  Built for 256 channels (the ds2
 # level), 4 heads, 16 frames; like every kernel choice it depends on the layer's geometry only.  (The 384 / 512-channel instances of

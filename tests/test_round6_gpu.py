@@ -113,3 +113,71 @@ def test_attn_pipe_kernel_repeatable_under_load(ops):
         torch.cuda.synchronize()
         bad += sum(0 if torch.equal(o, ref) else 1 for o in outs)
     assert bad == 0, f"{bad} of 200 launches differ"
+
+
+# --------------------------------------------------------------------------- audio in_layers in one launch (mmd_aconv)
+ACONV_CASES = [   # N, L, Cin, Cout, dilation
+    (2, 400, 512, 512, 2), (4, 400, 1024, 512, 1), (2, 400, 512, 512, 512), (2, 1600, 384, 384, 256), (2, 1600, 896, 384, 512),
+    (1, 6400, 256, 256, 32), (2, 6400, 128, 256, 16), (1, 25600, 128, 128, 4), (1, 256, 128, 128, 8), (3, 448, 640, 256, 64)]
+
+
+@pytest.mark.parametrize("N,L,Cin,Cout,dil", ACONV_CASES)
+def test_aconv_is_bitwise_gn_apply_plus_conv_gemm(ops, N, L, Cin, Cout, dil):
+    """mmd_aconv (GroupNorm + SiLU + dilated k = 3 AudioConv in one launch; unet:339-346, 108-131, nn.py:16-33) against the two launches
+    it replaces (mmd_gn_apply, mmd_conv_gemm with the taps (-d, 0, d)): same K order and rounding points -> bitwise equal; against fp32
+    torch (group_norm -> silu -> conv1d, padding = dilation) to bf16 accuracy; the quad records against the stored output.  Dilations
+    beyond the sample (every side tap padded), samples that are not multiples of the 128-row blocks (two samples in one workgroup),
+    64- and 128-column workgroups."""
+    import torch.nn.functional as F_
+    g = torch.Generator().manual_seed(N * L + Cin + dil)
+    x = (torch.randn(N * L, Cin, generator=g) * 1.5 + 0.3).to(BF).cuda()
+    w = torch.randn(Cout, Cin, 3, generator=g) * (1.0 / (3 * Cin) ** 0.5)
+    bias = torch.randn(Cout, generator=g).cuda()
+    gamma, beta = (1 + 0.2 * torch.randn(Cin, generator=g)).cuda(), (0.2 * torch.randn(Cin, generator=g)).cuda()
+    wp = ops.pack_conv_weight(w, BF).cuda()
+    geom = ops.Geom.per_sample(N, L)
+    a, b = ops.gn_stats(x, gamma, beta, geom)
+    xn = ops.gn_apply(x, a, b, geom, act=True)
+    want_stats = (N * L) % 64 == 0
+    rec_ref = torch.zeros(N * L // 64, Cout // 4, 2, device="cuda") if want_stats else None
+    y_ref = ops.conv_gemm(xn, wp, bias, taps=ops.taps_audio(dil), dims=(L, 1, 1), stats=rec_ref)
+    rec = torch.full_like(rec_ref, 7.0) if want_stats else None
+    y = torch.full((N * L, Cout), 3.0, dtype=BF, device="cuda")
+    ops.aconv(x, a, b, wp, bias, N, L, dil, act=True, out=y, stats=rec)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref), f"rel-L2 {rel_l2(y.float().cpu(), y_ref.float().cpu().numpy()):.3e}"
+    # fp32 torch restatement of the reference operators on the same bf16-rounded input and weights
+    xt = x.float().cpu().reshape(N, L, Cin).permute(0, 2, 1)
+    ref = F_.conv1d(F_.silu(F_.group_norm(xt, 32, gamma.cpu(), beta.cpu(), eps=1e-5)), w.to(BF).float(), bias.cpu(), padding=dil, dilation=dil)
+    ref = ref.permute(0, 2, 1).reshape(N * L, Cout)
+    assert rel_l2(y.float().cpu(), ref.numpy()) < 1e-2
+    if want_stats:
+        yq = y.float().reshape(N * L // 64, 64, Cout // 4, 4)
+        s1, s2 = yq.sum(dim=(1, 3)), (yq * yq).sum(dim=(1, 3))
+        assert torch.allclose(rec[..., 0], s1, rtol=1e-4, atol=1e-2) and torch.allclose(rec[..., 1], s2, rtol=1e-4, atol=1e-2)
+        # and the records are usable where the GEMM's are: same sums up to the order of the fp32 additions
+        assert torch.allclose(rec, rec_ref, rtol=1e-4, atol=1e-2)
+
+
+def test_aconv_column_slice_output_and_rejects(ops):
+    """Output into the right-hand column slice of a wider buffer (the engine's concat views), input a column slice too; overlapping
+    X / Y and unsupported shapes are refused by the C side."""
+    from mm_diffusion import _hip as H
+    N, L, Cin, Cout, dil = 2, 400, 128, 128, 4
+    g = torch.Generator().manual_seed(11)
+    wide_x = torch.randn(N * L, 2 * Cin, generator=g).to(BF).cuda()
+    x = wide_x[:, Cin:]
+    w = torch.randn(Cout, Cin, 3, generator=g) * 0.05
+    wp = ops.pack_conv_weight(w, BF).cuda()
+    gamma, beta = torch.ones(Cin).cuda(), torch.zeros(Cin).cuda()
+    geom = ops.Geom.per_sample(N, L)
+    a, b = ops.gn_stats(x, gamma, beta, geom)
+    y_ref = ops.conv_gemm(ops.gn_apply(x, a, b, geom, act=True), wp, None, taps=ops.taps_audio(dil), dims=(L, 1, 1))
+    wide_y = torch.zeros(N * L, 3 * Cout, dtype=BF, device="cuda")
+    ops.aconv(x, a, b, wp, None, N, L, dil, out=wide_y[:, Cout:2 * Cout])
+    torch.cuda.synchronize()
+    assert torch.equal(wide_y[:, Cout:2 * Cout], y_ref) and float(wide_y[:, :Cout].abs().max()) == 0 and float(wide_y[:, 2 * Cout:].abs().max()) == 0
+    with pytest.raises(H.MMDError):
+        ops.aconv(x, a, b, wp, None, N, L, dil, out=wide_x[:, :Cin])      # overlapping ranges of one buffer
+    with pytest.raises(H.MMDError):
+        ops.aconv(x[:N * 100], a, b, wp, None, N, 100, dil)                # samples shorter than a row block
