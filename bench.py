@@ -614,7 +614,7 @@ def main():
             pass
         # the same kernel family's average launch INSIDE the profiled step (profiles/kernel_stats.json: rocprofv3 --kernel-trace of this
         # command, tools/round_profile.sh; both launch streams busy, caches as the step leaves them) - the isolated HIP-event replay
-        # above flatters a launch by up to 15 %.  `frac` is computed from the in-step figure when it exists for THIS build.
+        # above flatters a launch by up to 15 %.  Reported beside `frac` (`frac_in_step`) when the profile is of THIS build.
         in_step_ms = in_step_note = None
         try:
             import re
@@ -640,11 +640,11 @@ def main():
         iso_ms = a["ms"] / max(a["calls"], 1)
         ach_iso = ach                          # from the isolated HIP-event replay of this run
         ach_step = ach * iso_ms / in_step_ms if in_step_ms else None      # per-launch algorithmic work / the in-step launch time
-        ach = ach_step if ach_step is not None else ach_iso
+        ach = ach_iso      # round 6: `frac` / `achieved` are THIS run's measurement; the in-step figure from the committed profile is a labelled side figure
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         res["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                            "frac_isolated": ach_iso / peak, "frac_in_step": (ach_step / peak) if ach_step is not None else None,
-                           "frac_note": "frac = frac_in_step when profiles/kernel_stats.json matches this build (rocprofv3 kernel trace of this command), else frac_isolated (HIP events of this run)",
+                           "frac_note": "frac = frac_isolated = this run's HIP-event replay of the family's launches on the launch stream; frac_in_step = the same work over the family's average launch inside the profiled step (profiles/kernel_stats.json: rocprofv3 kernel trace of this command, used only when its build id matches)",
                            "mfma_frac_of_peak_in_step": (a["flops"] / max(a["calls"], 1) / (in_step_ms * 1e-3) / 1e12 / mfma_peak) if in_step_ms else None,
                            "avg_launch_ms_in_step": in_step_ms, "avg_launch_ms_in_step_note": in_step_note or ("rocprofv3 kernel trace of this command, profiles/kernel_stats.json" if in_step_ms else "no profile of this build: frac is from the isolated replay"),
                            "arithmetic_intensity_flop_per_B": ai, "ridge_flop_per_B": ridge,

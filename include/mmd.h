@@ -118,49 +118,7 @@ int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, con
 int mmd_gn_small(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int S, int Tn, int inner, int64_t outer_stride,
                  int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, float eps, int act, void* stream);
 
-/* In-launch GroupNorm statistics + affine ("tail", round 3) - what mmd_conv_gemm_tail / mmd_gn_conv1x1_tail add to a GEMM launch
- * whose output Y (a column range of a buffer that GroupNorm32s normalise next; nn.py:16-33) then needs neither a statistics pass
- * nor a finalize launch:
- *   1. every block adds the (sum, sum of squares) of the values it STORED, per (slice, QUAD of 4 consecutive channels), into the
- *      buffer's 64-bit integer accumulators acc[S][q_ld][4] (fixed point, split {hi, lo} so that no fp32 partial loses a bit: sums
- *      in units of 2^-32, sums of squares 2^-28).  Integer additions commute: the totals - and everything computed from them - are
- *      bitwise independent of the grid, the tile family, the arrival order and the batch size.  Quads (not the consumer's groups)
- *      because ONE producer can feed two norms with different groupings: an input block's output is normalised by the next input
- *      block AND, as the right half of a skip concat, by an output block; every group size of the model is a multiple of 4;
- *   2. the LAST block to arrive (a per-launch counter, then a counter over the `n_producers` launches that have to be complete) turns
- *      the quad totals of the consumer's C channels (quads fq0 .. fq0 + C / 4 of the buffer - they may include quads accumulated by
- *      EARLIER launches, e.g. the skip half of a concat) into the fused affine a[s,c] = rstd gamma (1 + scale),
- *      b[s,c] = (beta - mean rstd gamma)(1 + scale) + shift, exactly what mmd_gn_stats leaves for its consumers.
- * The caller zeroes accumulators and counters once per forward (mmd_zero).  Slices: S contiguous slices of rows_per_slice rows (a
- * multiple of 64).  acc == NULL: no statistics; shared_counter == NULL: accumulate only. */
-typedef struct mmd_gn_tail {
-  long long* acc;                 /* [S][q_ld][4]: sum hi, sum lo, sumsq hi, sumsq lo per (slice, quad of the buffer) */
-  int q_ld;                       /* quads per slice = buffer channels / 4 */
-  int q_off;                      /* first quad of THIS launch's output columns */
-  unsigned* launch_counter;       /* this launch's block arrivals */
-  unsigned* shared_counter;       /* launches completed, of n_producers */
-  int n_producers;
-  int S;
-  long long rows_per_slice;
-  int C, fq0;                     /* the consumer norm: channels, first quad in the buffer */
-  const float* gamma;
-  const float* beta;
-  const float* film;              /* [S, 2C] (scale | shift) or NULL */
-  long long film_ld;
-  float eps;
-  float* a_out;
-  float* b_out;
-} mmd_gn_tail;
-
-int mmd_conv_gemm_tail(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
-                       void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2, int tile,
-                       const mmd_gn_tail* tail, void* stream);
-int mmd_gn_conv1x1_tail(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
-                        int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
-                        int M, int Cout, int Cin, int tile, const mmd_gn_tail* tail, void* stream);
-/* The finalize step of a tail on its own (one small launch): accumulators filled by accumulate-only launches -> a_out / b_out. */
-int mmd_gn_tail_finalize(const mmd_gn_tail* tail, void* stream);
-/* hipMemsetAsync(ptr, 0, bytes) on the stream: the once-per-forward reset of every tail's accumulators and counters. */
+/* hipMemsetAsync(ptr, 0, bytes) on the stream (a memset node of a captured plan). */
 int mmd_zero(void* ptr, int64_t bytes, void* stream);
 
 /* The two GEMMs above with the GroupNorm statistics of their OUTPUT produced in the epilogue, for the norm that consumes Y next

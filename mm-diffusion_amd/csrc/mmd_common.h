@@ -120,84 +120,6 @@ __device__ __forceinline__ float halfwave_total(float v) {
 }
 
 
-// ----------------------------------------------------------------------------- in-launch GroupNorm statistics ("tail", include/mmd.h)
-// A partial sum p (fp32) enters a 64-bit integer accumulator pair exactly: hi = rint(p 2^H), lo = rint((p - hi 2^-H) 2^(H+24)) - both
-// exact in fp32 arithmetic for |p| < 2^(31-H) - so the accumulated total hi 2^-H + lo 2^-(H+24) is the EXACT sum of the partials,
-// whatever the order of the atomic additions.  H = 8 for sums, 4 for sums of squares (|p| < 8.3e6 / 1.3e8 per 64-row x group partial).
-#define GN_TAIL_HS 8
-#define GN_TAIL_HQ 4
-__device__ __forceinline__ void gn_tail_split(float p, int H, int& hi, int& lo) {
-  const float hf = rintf(p * (float)(1 << H));
-  hi = (int)hf;
-  lo = (int)rintf((p - hf * (1.0f / (float)(1 << H))) * (float)(1 << H) * 16777216.0f);
-}
-typedef unsigned long long gn_u64;
-__device__ __forceinline__ void gn_tail_add(long long* acc4, float sum, float sq) {
-  int h, l;
-  gn_tail_split(sum, GN_TAIL_HS, h, l);
-  atomicAdd((gn_u64*)acc4, (gn_u64)(long long)h);
-  atomicAdd((gn_u64*)acc4 + 1, (gn_u64)(long long)l);
-  gn_tail_split(sq, GN_TAIL_HQ, h, l);
-  atomicAdd((gn_u64*)acc4 + 2, (gn_u64)(long long)h);
-  atomicAdd((gn_u64*)acc4 + 3, (gn_u64)(long long)l);
-}
-__device__ __forceinline__ void gn_tail_totals(const long long* acc4, double& sum, double& sq) {
-  const long long sh = __hip_atomic_load(acc4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sl = __hip_atomic_load(acc4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const long long qh = __hip_atomic_load(acc4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ql = __hip_atomic_load(acc4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  sum = (double)sh * (1.0 / (double)(1 << GN_TAIL_HS)) + (double)sl * (1.0 / ((double)(1 << GN_TAIL_HS) * 16777216.0));
-  sq = (double)qh * (1.0 / (double)(1 << GN_TAIL_HQ)) + (double)ql * (1.0 / ((double)(1 << GN_TAIL_HQ) * 16777216.0));
-}
-// The fused affine of the consumer's (slice, channel)s from the quad totals: called by ALL threads of the last-arriving block (or of a
-// one-block finalize launch).  One (slice, group) per thread and turn: its C / 128 quads summed in double, then the group's channels.
-// The other blocks' atomics are complete (each block waits for its own before it takes its ticket) and are read with agent-scope
-// atomic loads: no stale lines.
-__device__ __forceinline__ void gn_tail_finalize(const mmd_gn_tail& g, int tid, int nthreads) {
-  const int cpg = g.C / 32, qpg = cpg / 4;
-  const double cnt = (double)g.rows_per_slice * (double)cpg;
-  for (int i = tid; i < g.S * 32; i += nthreads) {
-    const int s = i >> 5, gi = i & 31;
-    double sm = 0.0, sq = 0.0;
-    const long long* q = g.acc + ((int64_t)s * g.q_ld + g.fq0 + gi * qpg) * 4;
-    for (int k = 0; k < qpg; ++k) {
-      double a, b;
-      gn_tail_totals(q + k * 4, a, b);
-      sm += a;
-      sq += b;
-    }
-    const double mean = sm / cnt;
-    double var = sq / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)g.eps)), fmean = (float)mean;
-    for (int k = 0; k < cpg; ++k) {
-      const int c = gi * cpg + k;
-      float av = rstd * g.gamma[c];
-      float bv = g.beta[c] - fmean * av;
-      if (g.film) {
-        const float sc = 1.f + g.film[(int64_t)s * g.film_ld + c];
-        const float sh = g.film[(int64_t)s * g.film_ld + g.C + c];
-        av *= sc;
-        bv = bv * sc + sh;
-      }
-      g.a_out[(int64_t)s * g.C + c] = av;
-      g.b_out[(int64_t)s * g.C + c] = bv;
-    }
-  }
-}
-// End of a statistics-emitting block: every thread has issued its accumulator atomics.  Returns (block-uniform) after the finalize
-// when this block turned out to be the last of the last launch.  `flag` = one LDS word.
-__device__ __forceinline__ void gn_tail_arrive(const mmd_gn_tail& g, unsigned* flag, int tid, int nthreads, unsigned nblocks) {
-  if (!g.shared_counter) return;                                    // accumulate only (uniform)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's atomics (and stores) are performed
-  __syncthreads();
-  if (tid == 0) {
-    unsigned last = 0;
-    if (atomicAdd(g.launch_counter, 1u) == nblocks - 1) last = atomicAdd(g.shared_counter, 1u) == (unsigned)g.n_producers - 1 ? 1u : 0u;
-    *flag = last;
-  }
-  __syncthreads();
-  if (*flag) gn_tail_finalize(g, tid, nthreads);
-}
-
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: the launchers remember it per device slot

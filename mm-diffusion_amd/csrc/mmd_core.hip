@@ -134,7 +134,7 @@ extern "C" int mmd_debug_install_crash_handler(void) {
   return MMD_OK;
 }
 
-// Zero a device buffer on the stream (a memset node under capture): the per-forward reset of the GroupNorm tail accumulators / counters.
+// Zero a device buffer on the stream (a memset node under capture).
 extern "C" int mmd_zero(void* ptr, int64_t bytes, void* stream) {
   MMD_REQUIRE(ptr && bytes > 0, "mmd_zero: null pointer / empty");
   hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream);

@@ -32,8 +32,6 @@ struct ConvGemmParams {
   // optional GroupNorm statistics of the OUTPUT for its consumer (mmd_gn_finalize_stats): per (64-row record, column) the sum and
   // sum of squares of the stored values, stats[(m / 64) * stats_ld + column] = float2; M % 64 == 0
   float* stats; int64_t stats_ld;
-  // or: in-launch statistics + affine of the consumer GroupNorm (include/mmd.h: mmd_gn_tail); gt.acc != nullptr switches it on
-  mmd_gn_tail gt;
   int taps[27 * 3];
 };
 
@@ -86,14 +84,9 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
     if (m0 + r * 64 < p.M) {
       const float* v = sQ + (r * BN + 4 * q) * 2;
       const float a = (v[0] + v[2]) + (v[4] + v[6]), b = (v[1] + v[3]) + (v[5] + v[7]);
-      if (p.gt.acc) {                                   // into the buffer's integer accumulators (tail mode)
-        const int sl = (int)((m0 + r * 64) / p.gt.rows_per_slice);
-        gn_tail_add(p.gt.acc + ((int64_t)sl * p.gt.q_ld + p.gt.q_off + (n0 >> 2) + q) * 4, a, b);
-      } else {                                          // quad record of this 64-row record
-        float* d = p.stats + ((int64_t)(m0 / 64 + r) * p.stats_ld + (n0 >> 2) + q) * 2;
-        d[0] = a;
-        d[1] = b;
-      }
+      float* d = p.stats + ((int64_t)(m0 / 64 + r) * p.stats_ld + (n0 >> 2) + q) * 2;      // quad record of this 64-row record
+      d[0] = a;
+      d[1] = b;
     }
   }
 }
@@ -187,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
         for (int h = 0; h < 8 / EPV; ++h) {
           const u32x4 pk = Elt<T>::pack(v + h * EPV);
           *(u32x4*)(p.Y + ((int64_t)m * p.ldy + co + h * EPV) * ES) = pk;
-          if (p.stats || p.gt.acc) {     // statistics of the values as STORED (what the consumer GroupNorm reads back)
+          if (p.stats) {     // statistics of the values as STORED (what the consumer GroupNorm reads back)
             float rf[EPV];
             Elt<T>::unpack(pk, rf);
 #pragma unroll
@@ -197,10 +190,9 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
       }
     }
   }
-  if (p.stats || p.gt.acc) {             // block-uniform
+  if (p.stats) {             // block-uniform
     __syncthreads();                     // every thread is past its last sC read: the wave partials alias the staging tile
     epilogue_stats<BM, BN>(p, ssum, ssq, sC, m0, n0, tid);
-    if (p.gt.acc) gn_tail_arrive(p.gt, (unsigned*)sC, tid, 256, gridDim.x);
   }
 }
 
@@ -715,7 +707,7 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
         for (int h = 0; h < 8 / EPV; ++h) {
           const u32x4 pk = Elt<T>::pack(v + h * EPV);
           *(u32x4*)(p.Y + ((int64_t)m * p.ldy + e_co + h * EPV) * ES) = pk;
-          if (p.stats || p.gt.acc) {     // statistics of the values as STORED (what the consumer GroupNorm reads back)
+          if (p.stats) {     // statistics of the values as STORED (what the consumer GroupNorm reads back)
             float rf[EPV];
             Elt<T>::unpack(pk, rf);
 #pragma unroll
@@ -725,10 +717,9 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
       }
     }
   }
-  if (p.stats || p.gt.acc) {             // block-uniform
+  if (p.stats) {             // block-uniform
     __syncthreads();                     // every thread is past its last sC read: the wave partials alias the staging tile
     epilogue_stats<128, 128>(p, ssum, ssq, sC, m0, n0, tid);
-    if (p.gt.acc) gn_tail_arrive(p.gt, (unsigned*)sC, tid, 256, gridDim.x);
   }
 }
 
@@ -1335,7 +1326,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 // never by timing (ops.strip_tile_pinned).
 // Grid = row strips x nsplit column ranges (nsplit fills the chip when M is small; results do not depend on it).
 // (halfwave_total - the DPP fold of the quad statistics - lives in mmd_common.h: the fused VideoConv kernel shares it.)
-template <int KS, int RF, int CC, int GNM, int STM>   // STM: output statistics 0 none / 1 per-column records / 2 in-launch tail (compile
+template <int KS, int RF, int CC, int GNM, int STM>   // STM: output statistics 0 none / 1 quad records (compile
                                              // time: the runtime branches cost the K = 128 instance 30 spilled registers).  GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
                                              // normalisation in one kernel spill ~100 registers around the branch)
 __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
@@ -1368,8 +1359,6 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
   float* sBias = (float*)(smem + 2 * STAGE_B);          // [Cs] bias of this block's column range
   float* sGN = sBias + ((Cs + 3) & ~3);                 // [2 slices][a | b][K] fused GroupNorm affine
   float* sRec = sGN + (GNM != 0 ? 4 * K : 0);           // RF = 1: [2 chunk parities][4 waves][NA * 2][32] half-record statistics
-  // tail mode (p.gt.acc): the block's exact integer accumulators [4 local slices][32 groups][4], flushed to global memory at the end
-  long long* sAccT = (long long*)(sRec + (RF == 1 ? 2 * 4 * (CC / 32) * 2 * 32 : 0) + 2);   // (+2 floats: 16-byte carve -> 8-byte aligned)
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -1452,10 +1441,6 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     if (tid + 256 * i < Cs) sBias[tid + 256 * i] = bias_v[i];
-  if (STM == 2) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sAccT[tid + 256 * e] = 0;           // 16 KB (launcher: TAIL_B)
-  }
   if (gn) {
 #pragma unroll
     for (int e = 0; e < KS; ++e) sGN[tid + 256 * e] = tv[e];
@@ -1491,16 +1476,6 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
   const int xsw = (l31 >> 1) & 7;
   const bool wave_ok = (int64_t)m0 + wave * (32 * RF) < p.M;      // wave-uniform: statistics records are whole waves (RF = 2)
   const int64_t rec = ((int64_t)m0 + wave * (32 * RF)) / 64;
-  // tail mode: the local slice of this wave's rows (a wave's 32 * RF rows lie inside one 64-row record, a record inside one slice);
-  // the block's quad accumulators live in LDS when [t_nsl local slices][Cs / 4 quads][4] fits 16 KB, else the waves add to global memory
-  int t_sl = 0, t_s0 = 0, t_nsl = 1;
-  bool t_lds = false;
-  if (STM == 2) {
-    t_s0 = (int)(m0 / p.gt.rows_per_slice);
-    t_sl = (int)(((int64_t)m0 + wave * (32 * RF)) / p.gt.rows_per_slice) - t_s0;    // 0 .. 3 (rows_per_slice >= 64, block of <= 256 rows)
-    t_nsl = (int)(((int64_t)m0 + BR - 1) / p.gt.rows_per_slice) - t_s0 + 1;
-    t_lds = t_nsl * (Cs >> 2) * 4 <= 2048;
-  }
   for (int ci = 0; ci < nchunk; ++ci) {
     const int st = ci & 1;
     if (ci + 1 < nchunk) issue(st ^ 1, ci + 1);         // next chunk's weights land under this chunk's MFMAs
@@ -1573,29 +1548,6 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
             }
           }
         }
-        if (STM == 2) {                                  // block-uniform.  Four values over the 32 rows of the half-wave: recursive halving
-          const bool h16 = (l31 & 16) != 0, h8 = (l31 & 8) != 0;
-          const float k0 = h16 ? u[2] : u[0], s0 = h16 ? u[0] : u[2], k1 = h16 ? u[3] : u[1], s1 = h16 ? u[1] : u[3];
-          const float a0 = k0 + __shfl_xor(s0, 16, 64), a1 = k1 + __shfl_xor(s1, 16, 64);     // lane: (sum q0, sum q1) or (sq q0, sq q1)
-          float tt = (h8 ? a1 : a0) + __shfl_xor(h8 ? a0 : a1, 8, 64);                          // quad h8, quantity h16
-          tt += __shfl_xor(tt, 4, 64);
-          tt += __shfl_xor(tt, 2, 64);
-          tt += __shfl_xor(tt, 1, 64);
-          if (wave_ok && (l31 & 7) == 0) {
-            int hi, lw;
-            gn_tail_split(tt, h16 ? GN_TAIL_HQ : GN_TAIL_HS, hi, lw);
-            const int ql = ((col - cbase) >> 2) + (h8 ? 1 : 0);                                  // quad inside this block's column range
-            if (t_lds) {
-              gn_u64* d = (gn_u64*)(sAccT + ((t_sl * (Cs >> 2) + ql) * 4 + (h16 ? 2 : 0)));
-              atomicAdd(d, (gn_u64)(long long)hi);
-              atomicAdd(d + 1, (gn_u64)(long long)lw);
-            } else {
-              gn_u64* d = (gn_u64*)(p.gt.acc + ((int64_t)(t_s0 + t_sl) * p.gt.q_ld + p.gt.q_off + (cbase >> 2) + ql) * 4 + (h16 ? 2 : 0));
-              atomicAdd(d, (gn_u64)(long long)hi);
-              atomicAdd(d + 1, (gn_u64)(long long)lw);
-            }
-          }
-        }
         if (STM == 1) {                                   // block-uniform: quad records (sum, sum of squares) per 64 rows
           // lanes 16 / 17 of each half end up with the (sum, sum of squares) of quad 0 / 1 of the lane group's 8 channels
           const float t0 = halfwave_total(u[0]), t1 = halfwave_total(u[1]), t2 = halfwave_total(u[2]), t3 = halfwave_total(u[3]);
@@ -1637,19 +1589,6 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(c
       }
     }
   }
-  if (STM == 2) {                                        // block-uniform: flush the block's integer accumulators, then the ticket protocol
-    __syncthreads();
-    if (t_lds) {
-      const int nq4 = (Cs >> 2) * 4, tot = t_nsl * nq4;  // [local slice][quad][4]
-      for (int i = tid; i < tot; i += 256) {
-        const long long v = sAccT[i];
-        const int sl = i / nq4, r = i - sl * nq4;
-        if (v != 0 && t_s0 + sl < p.gt.S)
-          atomicAdd((gn_u64*)(p.gt.acc + ((int64_t)(t_s0 + sl) * p.gt.q_ld + p.gt.q_off + (cbase >> 2)) * 4 + r), (gn_u64)v);
-      }
-    }
-    gn_tail_arrive(p.gt, (unsigned*)sAccT, tid, 256, gridDim.x);
-  }
 }
 
 template <int KS, int RF, int CC, int GNM, int STM>
@@ -1675,9 +1614,8 @@ static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
     }
   const int Cs = p.Cout / nsplit;
   constexpr size_t REC_B = RF == 1 ? 2 * 4 * (CC / 32) * 2 * 32 * sizeof(float) : 0;
-  constexpr size_t TAIL_B = 8 + 2048 * sizeof(long long);
-  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0) + REC_B + (p.gt.acc ? TAIL_B : 0);
-  const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4 + REC_B + TAIL_B;
+  const size_t lds = 2 * (size_t)STAGE_B + (size_t)((Cs + 3) & ~3) * 4 + (p.gn_a ? 4 * (size_t)(64 * KS) * 4 : 0) + REC_B;
+  const size_t lds_max = 2 * (size_t)STAGE_B + 2048 * 4 + 4 * (size_t)(64 * KS) * 4 + REC_B;
   if (lds > lds_max) return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): %d output channels per block", Cs);
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
@@ -1698,7 +1636,6 @@ static int launch_conv1x1_strip_st(const ConvGemmParams& p, hipStream_t st) {
 
 template <int KS, int RF, int CC>
 static int launch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
-  if (p.gt.acc) return launch_conv1x1_strip_st<KS, RF, CC, 2>(p, st);
   return p.stats ? launch_conv1x1_strip_st<KS, RF, CC, 1>(p, st) : launch_conv1x1_strip_st<KS, RF, CC, 0>(p, st);
 }
 
@@ -1862,7 +1799,7 @@ static int dispatch_conv_gemm(const ConvGemmParams& p, int tile, hipStream_t st)
 static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
                           void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
                           int tile, const float* gn_a, const float* gn_b, int gn_act, int gn_S, int64_t gn_rows, float* stats,
-                          int64_t stats_ld, void* stream, const mmd_gn_tail* tail = nullptr) {
+                          int64_t stats_ld, void* stream) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "conv_gemm: bad dtype %d", dtype);
   MMD_REQUIRE(A && W && Y && M > 0 && Cout > 0 && Cin > 0, "conv_gemm: null/empty argument");
@@ -1884,22 +1821,6 @@ static int conv_gemm_impl(int dtype, const void* A, int64_t lda, const void* W, 
   MMD_REQUIRE(!stats || (M % 64 == 0 && Cout % 4 == 0 && stats_ld >= Cout / 4 && tile != 130 && tile != 133 && (uintptr_t)stats % 8 == 0),
               "conv_gemm: output statistics need M %% 64 == 0, Cout %% 4 == 0, stats_ld >= Cout / 4 (quads) and a row-tiled main loop (not tiles 130 / 133)");
   p.stats = stats; p.stats_ld = stats_ld;
-  p.gt = mmd_gn_tail{};
-  if (tail && tail->acc) {
-    const mmd_gn_tail& g = *tail;
-    MMD_REQUIRE(!stats, "conv_gemm: records and the in-launch tail are alternatives");
-    MMD_REQUIRE(tile != 130 && tile != 133 && M % 64 == 0, "conv_gemm tail: needs M %% 64 == 0 and a row-tiled main loop (not tiles 130 / 133)");
-    MMD_REQUIRE(g.S > 0 && g.rows_per_slice > 0 && g.rows_per_slice % 64 == 0 && (int64_t)g.S * g.rows_per_slice == M,
-                "conv_gemm tail: S slices of rows_per_slice rows (a multiple of 64) must cover M (S=%d rows=%lld M=%d)", g.S, g.rows_per_slice, M);
-    MMD_REQUIRE(g.q_ld > 0 && g.q_off >= 0 && g.q_off + Cout / 4 <= g.q_ld && Cout % 4 == 0,
-                "conv_gemm tail: quads %d .. %d of %d per slice", g.q_off, g.q_off + Cout / 4, g.q_ld);
-    MMD_REQUIRE(!g.shared_counter || (g.C > 0 && g.C % 128 == 0 && g.C <= 2048 && g.fq0 >= 0 && g.fq0 + g.C / 4 <= g.q_ld),
-                "conv_gemm tail: consumer norm over %d channels (a multiple of 128: groups of whole quads) from quad %d", g.C, g.fq0);
-    MMD_REQUIRE(((uintptr_t)g.acc) % 8 == 0, "conv_gemm tail: accumulators must be 8-byte aligned");
-    MMD_REQUIRE(!g.shared_counter || (g.launch_counter && g.n_producers >= 1 && g.gamma && g.beta && g.a_out && g.b_out && g.eps > 0.f),
-                "conv_gemm tail: the finalising form needs both counters, n_producers, gamma / beta and the affine outputs");
-    p.gt = g;
-  }
   for (int i = 0; i < ntaps * 3; ++i) p.taps[i] = taps[i];
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = (int64_t)cdiv(M, 128) * cdiv(Cout, 128) >= 320 ? 128 : 64;
@@ -1963,34 +1884,3 @@ extern "C" int mmd_gn_conv_gemm(int dtype, const void* A, int64_t lda, const flo
                         rows_per_slice, nullptr, 0, stream);
 }
 
-// mmd_conv_gemm / mmd_gn_conv1x1 whose epilogue also leaves the statistics of Y in the consumer GroupNorm's integer accumulators and,
-// in the last block of the last producer launch, turns them into that norm's fused affine (include/mmd.h: mmd_gn_tail): neither a
-// statistics pass nor a finalize launch.  `tail` is a HOST pointer, read at call time.
-extern "C" int mmd_conv_gemm_tail(int dtype, const void* A, int64_t lda, const void* W, const float* bias, const void* R, int64_t ldr,
-                                  void* Y, int64_t ldy, int M, int Cout, int Cin, int ntaps, const int* taps, int D0, int D1, int D2,
-                                  int tile, const mmd_gn_tail* tail, void* stream) {
-  MMD_REQUIRE(tail, "conv_gemm_tail: null tail");
-  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, ntaps, taps, D0, D1, D2, tile, nullptr, nullptr, 0, 0,
-                        0, nullptr, 0, stream, tail);
-}
-
-extern "C" int mmd_gn_conv1x1_tail(int dtype, const void* A, int64_t lda, const float* gn_a, const float* gn_b, int act, int S,
-                                   int64_t rows_per_slice, const void* W, const float* bias, const void* R, int64_t ldr, void* Y,
-                                   int64_t ldy, int M, int Cout, int Cin, int tile, const mmd_gn_tail* tail, void* stream) {
-  static const int tap0[3] = {0, 0, 0};
-  MMD_REQUIRE(gn_a && gn_b && tail, "gn_conv1x1_tail: null GroupNorm affine / tail");
-  return conv_gemm_impl(dtype, A, lda, W, bias, R, ldr, Y, ldy, M, Cout, Cin, 1, tap0, 1, 1, 1, tile, gn_a, gn_b, act, S,
-                        rows_per_slice, nullptr, 0, stream, tail);
-}
-
-// The finalize step on its own (one block): the fused affine from accumulators that some launches filled without finalising
-// (tail.shared_counter == NULL there) - tests, and producers that cannot know they are the last.
-__global__ __launch_bounds__(256) void gn_tail_finalize_kernel(const mmd_gn_tail g) { gn_tail_finalize(g, threadIdx.x, 256); }
-
-extern "C" int mmd_gn_tail_finalize(const mmd_gn_tail* tail, void* stream) {
-  MMD_REQUIRE(tail && tail->acc && tail->gamma && tail->beta && tail->a_out && tail->b_out, "gn_tail_finalize: null pointer");
-  MMD_REQUIRE(tail->S > 0 && tail->C > 0 && tail->C % 128 == 0 && tail->rows_per_slice > 0 && tail->eps > 0.f && tail->fq0 >= 0 &&
-                  tail->fq0 + tail->C / 4 <= tail->q_ld, "gn_tail_finalize: bad geometry");
-  hipLaunchKernelGGL(gn_tail_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *tail);
-  return mmd_check_launch("gn_tail_finalize");
-}

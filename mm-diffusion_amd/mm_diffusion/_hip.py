@@ -16,14 +16,6 @@ _lib = None
 i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
 
 
-class GnTail(C.Structure):
-    """include/mmd.h: mmd_gn_tail.  A plan holds a POINTER to one of these per producer launch and reads it at launch time: the
-    engine records the producer before it knows the consumer norm and fills the fields in when the consumer is recorded."""
-    _fields_ = [("acc", vp), ("q_ld", i32), ("q_off", i32), ("launch_counter", vp), ("shared_counter", vp), ("n_producers", i32),
-                ("S", i32), ("rows_per_slice", C.c_longlong), ("C", i32), ("fq0", i32), ("gamma", vp), ("beta", vp), ("film", vp),
-                ("film_ld", C.c_longlong), ("eps", f32), ("a_out", vp), ("b_out", vp)]
-
-
 _PROTOS = {
     "mmd_version": (C.c_int, []),
     "mmd_last_error": (C.c_char_p, []),
@@ -63,9 +55,6 @@ _PROTOS = {
     "mmd_vconv2d1d_weight_bytes": (i64, [i32]),
     "mmd_vconv2d1d_pack": (i32, [vp, vp, vp, i32, i32, vp]),
     "mmd_vconv2d1d": (i32, [vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
-    "mmd_conv_gemm_tail": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, C.POINTER(GnTail), vp]),
-    "mmd_gn_conv1x1_tail": (i32, [i32, vp, i64, vp, vp, i32, i32, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, C.POINTER(GnTail), vp]),
-    "mmd_gn_tail_finalize": (i32, [C.POINTER(GnTail), vp]),
     "mmd_zero": (i32, [vp, i64, vp]),
     "mmd_gn_finalize_stats": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp, vp, vp]),
     "mmd_attn_fwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, i64, i32, i64, i32, i32, vp, i32, vp]),

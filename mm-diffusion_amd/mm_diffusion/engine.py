@@ -84,10 +84,7 @@ class UNetEngine:
         self.rec_enabled = mode == "2" or (mode != "0" and dtype == torch.bfloat16)
         self._recs = {}
         # (Round 3's in-launch statistics + affine - "tails": integer accumulators in the producers, the last block of the last producer
-        # finalises; include/mmd.h: mmd_conv_gemm_tail - were an engine mode (MMD_GN_TAIL) until round 5.  Measured slower in round 3
-        # (14.7 / 13.6 ms against 12.8 with records), and round 5 measured its premise: the producers' atomics ALONE cost + 0.30 ... 0.83 ms
-        # per step (profiles/r05_chain_interference_and_launch_modes.txt).  The mode is gone from the engine; the entry points stay in the
-        # C ABI with their kernel-level tests.)
+        # finalises - measured slower in rounds 3 and 5 and were removed from the library in round 6; DESIGN.md section 5 has the numbers.)
         self._gn_small = os.environ.get("MMD_GN_SMALL", "1") != "0"
         self._vconv_fused = self._tattn_fused = self._tconv = self._aconv = dtype == torch.bfloat16
         self._deferred = []           # video-stream buffers a launch of the AUDIO stream still reads (see _cross): released at the next sync

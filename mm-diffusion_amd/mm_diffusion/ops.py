@@ -170,17 +170,10 @@ def gn_apply(x, a, b, geom: Geom, act=True, out=None):
 
 
 def zero(t):
-    """hipMemsetAsync(0) of a device tensor on the launch stream (a memset node in a captured plan): the once-per-forward reset of the
-    GroupNorm tail accumulators and counters."""
+    """hipMemsetAsync(0) of a device tensor on the launch stream (a memset node in a captured plan)."""
     H.require_cuda(t)
     _dispatch("mmd_zero", t.data_ptr(), t.numel() * t.element_size(), meta=("zero", 0, t.numel() * t.element_size()))
     return t
-
-
-def gn_tail_finalize(tail):
-    """The finalize step of a tail as its own (one-block) launch: accumulators -> fused affine (include/mmd.h: mmd_gn_tail_finalize)."""
-    import ctypes
-    _dispatch("mmd_gn_tail_finalize", ctypes.pointer(tail), meta=("gn_tail_finalize", 0, tail.S * tail.C * 8))
 
 
 def gn_small_ok(x, geom: Geom):
@@ -396,11 +389,9 @@ def ring_tile_candidate(x, Cout, ntaps):
             and ((M + 127) // 128) * ((Cout + 127) // 128) <= 384)
 
 
-def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None, tail=None):
+def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, tile=0, stats=None):
     """x [M, Cin]; w packed [Cout, ntaps*Cin] in x.dtype; bias fp32 [Cout] or None.  stats (optional): record view that receives
-    the GroupNorm statistics of the output (include/mmd.h: mmd_conv_gemm_stats).  tail (optional): an _hip.GnTail - the statistics
-    go into the consumer norm's integer accumulators and the last block leaves its fused affine (mmd_conv_gemm_tail); the struct is
-    read at LAUNCH time, so a recorded plan sees what the engine fills in later."""
+    the GroupNorm statistics of the output (include/mmd.h: mmd_conv_gemm_stats)."""
     _chk2d(x)
     M, Cin = x.shape
     Cout = w.shape[0]
@@ -413,16 +404,15 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin, nt, arr,
             int(dims[0]), int(dims[1]), int(dims[2]))
-    if tile == 0 and stats is None and tail is None and halo_tile_pinned(x, taps, dims):
+    if tile == 0 and stats is None and halo_tile_pinned(x, taps, dims):
         tile = halo_tile_code(x, taps, dims)
-    if tile == 0 and strip_tile_pinned(x, Cout, taps, stats if stats is not None else tail):
+    if tile == 0 and strip_tile_pinned(x, Cout, taps, stats):
         tile = 131
     if tile == 0:
         # statistics-emitting launches stay inside the 128-row tile family: the per-record sums are folded in an order that depends on
         # the tile's thread layout (128 / 129 share it, 64 does not), and the choice must not move the last bit of the statistics
         # when the batch size changes the autotuner's verdict
-        # (with a tail the statistics are exact integer sums - order-free - so every row-tiled loop is admissible)
-        cands = (128, 129) if stats is not None else (64, 128, 129) + ((130,) if HALO_CANDIDATE and tail is None and halo_tile_ok(x, taps, dims) else ())
+        cands = (128, 129) if stats is not None else (64, 128, 129) + ((130,) if HALO_CANDIDATE and halo_tile_ok(x, taps, dims) else ())
         if ring_tile_candidate(x, Cout, nt):
             cands = cands + (132,)
         tile = _pick_tile((es, M, Cin, nt, Cout, residual is not None, False, tuple(dims) if 130 in cands else None),
@@ -430,10 +420,7 @@ def conv_gemm(x, w, bias, taps=TAPS_1, dims=(1, 1, 1), residual=None, out=None, 
     flops = 2 * M * Cout * Cin * nt
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin * nt) + 4 * Cout
     label = f"conv_gemm<{'bf16' if es == 2 else 'f32'},{_tile_name(tile)}>[M={M},K={Cin * nt},N={Cout}]"
-    if tail is not None:
-        import ctypes
-        _dispatch("mmd_conv_gemm_tail", *base, tile, ctypes.pointer(tail), meta=(label, flops, nbytes))
-    elif stats is not None:
+    if stats is not None:
         _dispatch("mmd_conv_gemm_stats", *base, tile, *_stats_args(stats, M, Cout), meta=(label, flops, nbytes))
     else:
         _dispatch("mmd_conv_gemm", *base, tile, meta=(label, flops, nbytes))
@@ -476,7 +463,7 @@ def gn_fusable(geom: Geom, Cin, Cout, x=None, stats=None, act=False):
             and (Cout + 127) // 128 <= 2)
 
 
-def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=0, stats=None, tail=None):
+def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=0, stats=None):
     """1x1 conv of GroupNorm'd rows with the normalisation fused into the GEMM loader (include/mmd.h: mmd_gn_conv1x1)."""
     _chk2d(x)
     M, Cin = x.shape
@@ -489,26 +476,23 @@ def gn_conv1x1(x, a, b, geom: Geom, act, w, bias, residual=None, out=None, tile=
     # capability, not preference: an explicit tile is checked against what THAT main loop can do (gn_fusable is the caller's cost rule)
     tiled_ok = (geom.inner == 1 and geom.tstride == 1 and geom.outer_stride == geom.Tn and geom.Tn >= 128 and Cin <= 256
                 and (Cout + 127) // 128 <= 2)
-    strip_ok = strip_tile_ok(x, Cout, stats=stats if stats is not None else tail, geom=geom)
+    strip_ok = strip_tile_ok(x, Cout, stats=stats, geom=geom)
     if not ((tile == 131 and strip_ok) or (tile in (64, 128) and tiled_ok) or (tile == 0 and (tiled_ok or strip_ok))):
         raise H.MMDError("gn_conv1x1: needs contiguous slices of >= 128 rows, Cin <= 256 (use gn_apply + conv_gemm otherwise)")
     base = (H.dt_of(x), x.data_ptr(), x.stride(0), a.data_ptr(), b.data_ptr(), 1 if act else 0, geom.S, geom.Tn,
             w.data_ptr(), H.ptr(bias), H.ptr(residual),
             0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, Cout, Cin)
-    if tile == 0 and strip_tile_pinned(x, Cout, stats=stats if stats is not None else tail, geom=geom):
+    if tile == 0 and strip_tile_pinned(x, Cout, stats=stats, geom=geom):
         tile = 131                                         # (callers that follow gn_fusable only get here when the fusion pays)
     if tile == 0 and not tiled_ok:
         raise H.MMDError("gn_conv1x1: the row-strip kernel is switched off (MMD_GEMM_STRIP) and the tiled loader cannot take this launch")
     if tile == 0:
         tile = _pick_tile((es, M, Cin, 1, Cout, residual is not None, True),
                           lambda t: H.call("mmd_gn_conv1x1", *base, t, H.stream_handle()), M, Cout,
-                          candidates=(128,) if (stats is not None or tail is not None) else (64, 128), out=out, scratch=(x, residual, a, b))
+                          candidates=(128,) if stats is not None else (64, 128), out=out, scratch=(x, residual, a, b))
     nbytes = es * (M * Cin + M * Cout * (2 if residual is not None else 1) + Cout * Cin) + 4 * Cout
     meta = (f"gn_conv1x1<{'bf16' if es == 2 else 'f32'},{_tile_name(tile)}>[M={M},K={Cin},N={Cout}]", 2 * M * Cout * Cin, nbytes)
-    if tail is not None:
-        import ctypes
-        _dispatch("mmd_gn_conv1x1_tail", *base, tile, ctypes.pointer(tail), meta=meta)
-    elif stats is not None:
+    if stats is not None:
         _dispatch("mmd_gn_conv1x1_stats", *base, tile, *_stats_args(stats, M, Cout), meta=meta)
     else:
         _dispatch("mmd_gn_conv1x1", *base, tile, meta=meta)
