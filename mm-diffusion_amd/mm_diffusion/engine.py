@@ -341,6 +341,10 @@ class UNetEngine:
             # the out layers run at the INPUT resolution (a quarter of the rows, h's producer statistics instead of a statistics pass) and ONE
             # upsample writes the block's output (unet:441-448, 457-476; equal up to the rounding of the statistics sums)
             low_out = layer["up"] and ss and _UP_LOWRES
+            if low_out and (layer["vattn"] or layer["aattn"]):
+                # the low-resolution form returns before the attention branch below: an up block WITH attention (no shipped architecture
+                # builds one) must fail loudly, not be computed without its attention
+                raise H.MMDError(f"{p}: an upsampling ResBlock with self-attention is not supported by the low-resolution out layers")
             hstats = (fh == 1 or low_out) and ss
             t0 = t1 = h = None
             if vid and self._vconv_fused and ops.vconv_fused_ok(x, cout, N, F, Hh, Hh):
@@ -375,10 +379,10 @@ class UNetEngine:
                 pass
             elif vid:
                 if t0 is not None:
-                        t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
+                    t1 = ops.conv_gemm(t0, self._gemm_w(f"{p}.video_in_layers.2.video_conv_spatial.weight"),
                                        self._f32(f"{p}.video_in_layers.2.video_conv_spatial.bias"), taps=ops.TAPS_SPATIAL,
                                        dims=(N * F, Hh, Hh), out=self._alloc(rows_in, cout))
-                        self._release(t0)
+                    self._release(t0)
                 h = self._alloc(rows_in, cout, stats=hstats, unit=rows_in // N)
                 wtk = f"{p}.video_in_layers.2.video_conv_temporal.weight"
                 if self._tconv and ops.tconv_ok(t1, cout, N, F, Hh * Hh):
@@ -477,8 +481,8 @@ class UNetEngine:
         aqkv = self._gn_pw(a, p + ".a_norm", Geom.per_sample(N, L), False, p + ".a_qkv.weight", p + ".a_qkv.bias")
         ops.record_sync(1, 0)      # video queries need the audio k/v ...
         ops.record_sync(0, 1)      # ... and vice versa
-        # the video stream has now waited for everything recorded on the audio stream: the video qkv buffers that earlier blocks' AUDIO
-        # attentions were still reading go back to the video pool
+        # the video stream has now waited for everything recorded on the audio stream (the record_sync(1, 0) two lines up - the releases
+        # below depend on it): the video qkv buffers that earlier blocks' AUDIO attentions were still reading go back to the video pool
         self._release(*self._deferred)
         self._deferred = []
         sh = self.shift_dev[layer["shift_idx"]: layer["shift_idx"] + 1] if layer["shift"] else None
@@ -518,6 +522,7 @@ class UNetEngine:
     # ------------------------------------------------------------------ plan
     def _build(self):
         m, N, F, dt = self.model, self.N, self.F, self.dtype
+        self._deferred = []
         arch_in, arch_mid, arch_out = m._arch
         if self.H0 != self.W0:
             raise H.MMDError("square frames only (the reference's avg-pool/upsample path is exercised on H == W)")
@@ -690,6 +695,12 @@ class UNetEngine:
                       self.out_audio, N, 1, 1, L, [(0, 0, -1), (0, 0, 0), (0, 0, 1)])
         ops.cur_sid = 0
         self._release(hv, ha, v, a)
+        if self._deferred:
+            # the last cross block's video qkv buffer (parked while the AUDIO stream's attention read it, see _cross): back to the video
+            # pool behind an explicit audio -> video sync, so that no release depends on the caller's join
+            ops.record_sync(1, 0)
+            self._release(*self._deferred)
+            self._deferred = []
         # NOTE: no join here - the caller appends per-stream work (DDPM update) and then joins (join_plan)
 
     # ------------------------------------------------------------------ execution

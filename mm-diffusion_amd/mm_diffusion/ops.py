@@ -68,12 +68,20 @@ _SKIP_SID = int(os.environ["MMD_SKIP_SID"]) if os.environ.get("MMD_SKIP_SID", ""
 # likewise timing only: MMD_SKIP_WAIT=10 drops every "video stream waits for the audio stream" marker, =01 the opposite direction - how long
 # does a chain actually stand waiting for the other one (the numbers of such a run mean nothing)
 _SKIP_WAIT = os.environ.get("MMD_SKIP_WAIT", "")
+if _SKIP_SID is not None or _SKIP_WAIT:
+    import warnings
+    warnings.warn("MMD_SKIP_SID / MMD_SKIP_WAIT are set: replayed plans DROP a launch chain or cross-stream waits - timing experiments only, "
+                  "every output of this process is wrong", RuntimeWarning)
+_TIMING_ONLY_OK = os.environ.get("MMD_TIMING_ONLY", "") == "1"      # the bench / tools opt in explicitly; anything else refuses the switches
 
 
 def run_plan(plan, stream, aux_stream=None):
     """Replay a recorded plan.  With aux_stream the audio-stream ops run there (fork/join through events, also
     valid under stream capture); without it everything runs in recording order on `stream` (markers are no-ops)."""
     lib = H.lib()
+    if (_SKIP_SID is not None or _SKIP_WAIT) and not _TIMING_ONLY_OK:
+        raise H.MMDError("MMD_SKIP_SID / MMD_SKIP_WAIT (timing experiments: they drop launches / waits from every replayed plan) need "
+                         "MMD_TIMING_ONLY=1 as well - refusing to replay a plan whose outputs would be silently wrong")
     streams = (stream, aux_stream if aux_stream is not None else stream)
     for fn, args, name, _, sid, _tag in plan:
         if fn is None:
@@ -434,8 +442,10 @@ _STRIP_BLOCKS_RULE = int(os.environ.get("MMD_STRIP_BLOCKS_RULE", "448"))
 
 
 def strip_column_split(M, K, Cout):
-    """The column split the fuse / unfuse rule of gn_fusable reasons with: the smallest divisor of the chunk count that gives the chip
-    >= _STRIP_BLOCKS_RULE blocks, at most 16 (the kernel's own split - mmd_gemm.hip: launch_conv1x1_strip_mode - aims for 256 since round 5)."""
+    """A COST RULE, not the split the kernel launches: the column split the fuse / unfuse rule of gn_fusable reasons with - the smallest
+    divisor of the chunk count that gives the chip >= _STRIP_BLOCKS_RULE (448) blocks, at most 16.  The kernel's own split
+    (mmd_gemm.hip: launch_conv1x1_strip_mode) aims for 256 blocks since round 5; the rule kept its constant so that the fuse / unfuse
+    decisions - and with them the plan the fixtures pin - did not move with a launch-width tuning."""
     rf, cc = (2, 64) if K <= 256 else (1, 32)
     rowblocks, nch, n = -(-M // (128 * rf)), Cout // cc, 1
     for d in range(1, min(nch, 16) + 1):
@@ -548,9 +558,19 @@ def vconv_shape_ok(x, Cout, N, F, Hh, Ww):
             and x.shape[0] == N * F * Hh * Ww and (16 * Hh * Ww * x.stride(0) + x.shape[1]) * 2 < 2 ** 31)
 
 
-def vconv_fused_ok(x, Cout, N, F, Hh, Ww):
-    """The layers that always run on the fused kernel (a property of the layer, independent of the batch size)."""
-    return _VCONV_FUSED and vconv_shape_ok(x, Cout, N, F, Hh, Ww)
+def _ranges_overlap(x, y):
+    """The C side's X / Y check of mmd_vconv2d1d: whole address ranges [first byte, last byte] of the two row-strided views."""
+    x0, y0 = x.data_ptr(), y.data_ptr()
+    x1 = x0 + ((x.shape[0] - 1) * x.stride(0) + x.shape[1]) * x.element_size()
+    y1 = y0 + ((y.shape[0] - 1) * y.stride(0) + y.shape[1]) * y.element_size()
+    return not (x1 <= y0 or y1 <= x0)
+
+
+def vconv_fused_ok(x, Cout, N, F, Hh, Ww, out=None):
+    """The layers that always run on the fused kernel (a property of the layer, independent of the batch size).  out: the tensor the
+    engine would write - a column slice of the buffer x lives in is refused here (the caller falls back to the two-launch path)
+    instead of at launch time."""
+    return _VCONV_FUSED and vconv_shape_ok(x, Cout, N, F, Hh, Ww) and (out is None or not _ranges_overlap(x, out))
 
 
 def vconv_pack(ws, wt):
@@ -577,8 +597,9 @@ def vconv2d1d(x, wf, bias_s, bias_t, N, F, Hh, Ww, a=None, b=None, geom=None, ac
         raise H.MMDError("vconv2d1d: the fused input norm needs contiguous slices of whole samples")
     out = alloc(M, Cout, dtype=x.dtype, device=x.device) if out is None else out
     _chk2d(out)
-    if out.data_ptr() == x.data_ptr() or tuple(out.shape) != (M, Cout) or out.dtype != x.dtype:
-        raise H.MMDError("vconv2d1d: the output must be a distinct bf16 [M, 128] tensor (in-place is not supported)")
+    if _ranges_overlap(x, out) or tuple(out.shape) != (M, Cout) or out.dtype != x.dtype:
+        raise H.MMDError("vconv2d1d: the output must be a bf16 [M, 128] tensor whose address range does not overlap the input's (the C side "
+                         "compares whole ranges: column slices of one buffer count as overlapping)")
     if wf.numel() * wf.element_size() != H.lib().mmd_vconv2d1d_weight_bytes(Cin):
         raise H.MMDError("vconv2d1d: the weight image does not match Cin (pack it with vconv_pack)")
     sp, sld = (None, 0) if stats is None else _stats_args(stats, M, Cout)
