@@ -221,6 +221,37 @@ def test_config3_full_size_gradients_match_the_reference_fixture(dt):
     assert torch.isfinite(sub).all() and e_sub < tol_sub and e_norm < tol_norm
 
 
+def test_config4_dpm_solver_pp_full_size_matches_the_reference():
+    """configs[4], base-model half, against the REFERENCE at full size (round 6; until then the 50-evaluation test below graded bf16 against
+    this repository's own fp32 mode): tests/golden/full_dpmpp_multistep2.npz = the reference's DPM_Solver.sample on the shipped base model -
+    DPM-Solver++ (predict_x0 + dynamic thresholding), multistep order 2, 10 network evaluations, batch 2 (tools/gen_golden.py:
+    full_dpmpp_multistep2).  Same x_T (torch.manual_seed CPU draws), same replayed window shifts.  fp32 mode <= 1e-4 (the tiny fixtures of
+    tests/test_dpm_solver_gpu.py measure 3e-7 .. 1.2e-6), bf16 <= 3e-2."""
+    from helpers import gold
+    from mm_diffusion.multimodal_dpm_solver_plus import DPM_Solver
+    g = gold("full_dpmpp_multistep2")
+    B = int(g["B"])
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 3e-2)):
+        fl, model, diff = _full(dt)
+        it = iter(int(s) for s in g["shifts"])
+        used = []
+
+        def src(lo, hi):
+            v = next(it)
+            used.append(v)
+            return v
+        model.shift_source = src
+        torch.manual_seed(int(g["seed"]))
+        x_T = {"video": torch.randn(B, *fl["video_size"]).cuda(), "audio": torch.randn(B, *fl["audio_size"]).cuda()}
+        solver = DPM_Solver(model=model, alphas_cumprod=torch.tensor(diff.alphas_cumprod, dtype=torch.float32), predict_x0=True, thresholding=True)
+        out = solver.sample(x_T, steps=10, order=2, skip_type="logSNR", method="multistep")
+        ev, ea = rel_l2(out["video"].cpu(), g["video"]), rel_l2(out["audio"].cpu(), g["audio"])
+        print(f"configs[4] DPM-Solver++ multistep-2, 10 NFE, batch 2, full size vs the reference ({dt}): rel-L2 video {ev:.3e} audio {ea:.3e}")
+        assert solver.nfe == int(g["nfe"]) == 10 and len(used) == len(g["shifts"])
+        assert ev < tol and ea < tol
+        del model, diff, solver
+
+
 def test_config4_dpm_solver_pp_50_evaluations_then_sr_frame_batch():
     """configs[4]: DPM-Solver++ (predict_x0, dynamic thresholding), multistep order 2, 50 network evaluations at full size, batch 2, bf16 vs
     fp32 mode on the same x_T / shifts; then ONE evaluation of the shipped 64 -> 256 SR U-Net on the 16 frames of a clip (16 x 3 x 256 x 256),

@@ -333,10 +333,11 @@ def gen_cond(name, B, seed, respacing, which, class_scale):
          shifts=np.asarray(rec.draws), cond=cond, video=sample["video"].detach(), audio=sample["audio"].detach())
 
 
-def gen_dpm(tag, seed, predict_x0, thresholding, **sample_kw):
-    """Multimodal DPM-Solver(++) sample() on the tiny config, B = 2 (B = 1 fails inside the reference, dpm:344-345)."""
+def gen_dpm(tag, seed, predict_x0, thresholding, config="tiny", **sample_kw):
+    """Multimodal DPM-Solver(++) sample() on the tiny config (or, round 6, the shipped base model: BASELINE configs[4] at full size),
+    B = 2 (B = 1 fails inside the reference, dpm:344-345)."""
     from ref_mm import multimodal_dpm_solver_plus as rdpm
-    f = flags("tiny")
+    f = flags(config)
     model, diff = msu.create_model_and_diffusion(**f)
     synth_init(model).eval()
     B = 2
@@ -348,7 +349,8 @@ def gen_dpm(tag, seed, predict_x0, thresholding, **sample_kw):
     import contextlib, io
     with ShiftRecorder() as rec, contextlib.redirect_stdout(io.StringIO()):
         out = solver.sample({k: v.clone() for k, v in x_T.items()}, **sample_kw)
-    save(tag, seed=seed, B=B, shifts=np.asarray(rec.draws), nfe=len(rec.draws) // 9, video=out["video"], audio=out["audio"])      # 9 shift draws per tiny forward
+    per_fwd = 9 if config == "tiny" else 15          # shift draws per forward: one per shifted CrossAttentionBlock
+    save(tag, seed=seed, B=B, shifts=np.asarray(rec.draws), nfe=len(rec.draws) // per_fwd, video=out["video"], audio=out["audio"])
 
 
 def gen_noise_schedule():
@@ -467,6 +469,10 @@ ALL = {
                                         denoise=True),
     "dpmpp_adaptive2": lambda: gen_dpm("tiny_dpmpp_adaptive2", 65, True, True, steps=20, order=2, skip_type="logSNR", method="adaptive"),
     "dpm_adaptive3": lambda: gen_dpm("tiny_dpm_adaptive3", 66, False, False, order=3, method="adaptive", atol=0.05, rtol=0.1),
+    # BASELINE configs[4], base-model half, at FULL size against the reference itself (round 6): DPM-Solver++ (predict_x0 + dynamic
+    # thresholding) multistep order 2, 10 network evaluations, batch 2
+    "full_dpmpp_multistep2": lambda: gen_dpm("full_dpmpp_multistep2", 67, True, True, config="full", steps=10, order=2, skip_type="logSNR",
+                                             method="multistep"),
     "full_train_grads": gen_train_grads_full,
     "tiny_train_loss": lambda: gen_train_loss("tiny", 2, 31),
     "tiny_ls_train_loss": lambda: gen_train_loss("tiny", 2, 32, learn_sigma=True),
