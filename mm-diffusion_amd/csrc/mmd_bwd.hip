@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void wgrad128_bf16_kernel(const WgradParams
 // (no VGPR staging, no ds_write; a padding row or a row past the split is an out-of-range offset and lands as zeros), in the tile format
 // of the attention kernel's V ([plane of 64 channels][64 rows][128 B], 16-byte chunk ^ (((row >> 1) & 1) << 2)), double buffered with one
 // barrier per chunk; a fragment is two transposing reads.  wgrad128_bf16_kernel above spent 64 ds_write_b16 + 12 integer divisions per
-// thread and chunk on what the DMA and two float reciprocals do here.  The column sums (bias gradient) take the colsum launch.
+// thread and chunk on what the DMA and two float reciprocals do here.  The column sums (bias gradient) ride in the (tap 0, ci tile 0) blocks (round 6).
 __device__ __forceinline__ int wg_fdiv(int n, int d, float rd) {       // n / d for 0 <= n < 2^24 (the launcher checks M)
   int q = (int)((float)n * rd);
   const int r = n - q * d;
@@ -340,6 +340,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(const WgradParams
     return __builtin_bit_cast(bf16x8, both);
   };
 
+  // bias gradient (round 6: db != NULL): the (tap 0, ci tile 0) blocks sum the columns of the dY stage they have in LDS anyway - thread =
+  // (channel tid & 127, row half tid >> 7): a wave reads 128 contiguous bytes of a row per step (the chunk swizzle permutes 16-byte pieces
+  // inside them), rows past the split are zero-filled by the DMA.  No colsum launch: the 1x1 / k = 3 convs can use this kernel too.
+  const bool do_db = p.db != nullptr && kt_blk == 0;
+  float dbacc = 0.f;
+  const int dbc = tid & 127, dbh = tid >> 7;
   int stage = 0;
   if (m_begin < m_end) issue(0, m_begin);
   for (int mc = m_begin; mc < m_end; mc += 64) {
@@ -349,6 +355,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(const WgradParams
     if (mc + 64 < m_end) issue(stage ^ 1, mc + 64);         // in flight under this chunk's MFMAs
     const char* pa = smem_w + stage * STAGE_B + wi * PLANE_B;
     const char* pb = smem_w + stage * STAGE_B + OP_B + wj * PLANE_B;
+    if (do_db) {                                            // block-uniform
+      const char* q = smem_w + stage * STAGE_B + (dbc >> 6) * PLANE_B + (dbc & 7) * 2;
+      const int lc = (dbc & 63) >> 3;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int row = 32 * dbh + r;
+        const uint16_t v = *(const uint16_t*)(q + row * 128 + ((lc ^ (((row >> 1) & 1) << 2)) * 16));
+        dbacc += __uint_as_float((uint32_t)v << 16);
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {                        // 16 rows per k-step
       bf16x8 fa[2], fb[2];
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(const WgradParams
     }
     stage ^= 1;
   }
+  if (do_db && co0 + dbc < p.Cout) atomicAdd(p.db + co0 + dbc, dbacc);
   // D[row = co][col = ci]: lane holds ci = l31, co = (r&3) + 8*(r>>2) + 4*half of its 32x32 tile
   const int64_t K = (int64_t)p.Cin * p.ntaps;
 #pragma unroll
@@ -681,7 +698,9 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
     static const bool use_tr = [] { const char* e = getenv("MMD_WGRAD_TR"); return !(e && e[0] == '0'); }();
     // measured (tools/wgrad_bench.py, batch 8): 3x3 ds1 128->128 436 -> 372 us, ds2 256->256 405 -> 251, ds4 384->384 240 -> 180, ds8 130 -> 110;
     // the 1x1 / k=3 convs lose what the separate colsum launch costs (1x1 ds1: 82 -> 127 us), so they stay on the older kernel
-    if (use_tr && ntaps >= 9 && M < (1 << 24) && (int64_t)M * lddy * 2 < 0x7fffffffLL && (int64_t)M * ldx * 2 < 0x7fffffffLL) {
+    // round 6: the bias gradient rides in the kernel (no colsum launch), so every tap count uses it; MMD_WGRAD_TR=9: the 9-tap convs only
+    static const int tr_min_taps = [] { const char* e = getenv("MMD_WGRAD_TR"); return e && e[0] == '9' ? 9 : 1; }();
+    if (use_tr && ntaps >= tr_min_taps && M < (1 << 24) && (int64_t)M * lddy * 2 < 0x7fffffffLL && (int64_t)M * ldx * 2 < 0x7fffffffLL) {
       const size_t lds = 2 * 4 * 64 * 128;
       static bool attr_done[MMD_MAX_DEVICES] = {};
       bool& attr_set = attr_done[mmd_device_slot()];
@@ -690,7 +709,9 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
         if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv_wgrad: set LDS attr: %s", hipGetErrorString(e));
         attr_set = true;
       }
+      p.db = db;                                                 // column sums ride in the (tap 0, ci tile 0) blocks: no colsum launch
       hipLaunchKernelGGL(wgrad_tr_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), lds, st, p);
+      return mmd_check_launch("conv_wgrad");
     } else {
       p.db = db;                                                 // column sums ride in the (tap 0, ci tile 0) blocks: no colsum launch
       hipLaunchKernelGGL(wgrad128_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), 0, st, p);

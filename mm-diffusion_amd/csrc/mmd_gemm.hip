@@ -1329,15 +1329,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 template <int KS, int RF, int CC, int GNM, int STM>   // STM: output statistics 0 none / 1 quad records (compile
                                              // time: the runtime branches cost the K = 128 instance 30 spilled registers).  GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
                                              // normalisation in one kernel spill ~100 registers around the branch)
-__global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
+__global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
   constexpr int K = 64 * KS;                 // input channels
   constexpr int NCG = 4 * KS;                // 16-channel k-steps (one MFMA each)
   constexpr int BR = 128 * RF;               // rows per block: 4 waves x RF fragments of 32 rows
   constexpr int NA = CC / 32;                // 32-channel output sub-tiles per chunk
   constexpr int GP = CC / 32;                // weight DMA instructions per wave per 64-channel plane (CC / 8 row groups over 4 waves)
   constexpr int PLANE_B = CC * 128, STAGE_B = KS * PLANE_B;
-  constexpr bool DEFER = KS > 2;             // K = 128 has 1-4 chunks per block and needs the 16 registers for a third wave per SIMD
-  static_assert(RF == 2 || (CC == 32 && KS > 2), "one row fragment per wave: one sub-tile per chunk, deferred epilogue");
+  constexpr bool DEFER = KS > 2 || RF == 1;  // K = 128 / 256 with two fragments: 1-4 chunks per block, the 16 registers buy a third wave per SIMD
+  static_assert(RF == 2 || CC == 32, "one row fragment per wave: one sub-tile per chunk, deferred epilogue");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;                           // [2 stages][KS planes][CC rows][128 B], 16-byte chunks XOR-swizzled by (row >> 1) & 7
 
@@ -1648,7 +1648,14 @@ static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
       (p.ntaps == 1 && (p.taps[0] || p.taps[1] || p.taps[2])))
     return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): needs ntaps * Cin in {128, 256, 384, 512}, Cin %% 64 == 0, Cout %% %d == 0, "
                          "fused GroupNorm only for 1x1 convs with slices of >= %d rows (got Cin=%d ntaps=%d Cout=%d)", cc, 128 * rf, p.Cin, p.ntaps, p.Cout);
-  if (K == 128) return launch_conv1x1_strip<2, 2, 64>(p, st);
+  if (K == 128) {
+    // round 6: the ResBlock out conv of the ds1 levels (norm + SiLU + 1x1 + skip, 65536 / 25600 rows per sample) on 128-row blocks, four
+    // per CU, instead of 256-row blocks, three per CU - 1024 blocks on 768 slots ran 1.33 rounds.  Chosen by the layer's rows per
+    // SAMPLE (the record fold of a one-fragment wave differs in the last bit: the choice must not move with the batch size).
+    static const bool rf1 = [] { const char* e = getenv("MMD_STRIP_K128_RF1"); return e && e[0] == '1'; }();
+    if (rf1 && p.gn_a && p.gn_rows >= 16384 && p.ntaps == 1 && p.Cout % 32 == 0) return launch_conv1x1_strip<2, 1, 32>(p, st);
+    return launch_conv1x1_strip<2, 2, 64>(p, st);
+  }
   if (K == 256) return launch_conv1x1_strip<4, 2, 64>(p, st);
   if (K == 384) return launch_conv1x1_strip<6, 1, 32>(p, st);
   return launch_conv1x1_strip<8, 1, 32>(p, st);

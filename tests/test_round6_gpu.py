@@ -181,3 +181,47 @@ def test_aconv_column_slice_output_and_rejects(ops):
         ops.aconv(x, a, b, wp, None, N, L, dil, out=wide_x[:, :Cin])      # overlapping ranges of one buffer
     with pytest.raises(H.MMDError):
         ops.aconv(x[:N * 100], a, b, wp, None, N, 100, dil)                # samples shorter than a row block
+
+
+# --------------------------------------------------------------------------- row-strip GEMM, K = 128, one row fragment per wave (128-row blocks)
+_STRIP_RF1_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from mm_diffusion import ops
+N, L, C = 2, 16384, 128
+g = torch.Generator().manual_seed(5)
+x = (torch.randn(N * L, C, generator=g) * 1.3 + 0.2).to(torch.bfloat16).cuda()
+r = torch.randn(N * L, C, generator=g).to(torch.bfloat16).cuda()
+w = (torch.randn(C, C, generator=g) * 0.09).to(torch.bfloat16).cuda()
+bias = torch.randn(C, generator=g).cuda()
+gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.2 * torch.randn(C, generator=g)).cuda()
+geom = ops.Geom.per_sample(N, L)
+a, b = ops.gn_stats(x, gamma, beta, geom)
+rec = torch.zeros(N * L // 64, C // 4, 2, device="cuda")
+y = ops.gn_conv1x1(x, a, b, geom, True, w, bias, residual=r, tile=131, stats=rec)
+torch.cuda.synchronize()
+torch.save({"y": y.cpu(), "rec": rec.cpu()}, sys.argv[2])
+"""
+
+
+def test_strip_k128_one_fragment_instance_matches_the_two_fragment_one(tmp_path):
+    """conv1x1_strip_kernel<2, 1, 32> (MMD_STRIP_K128_RF1=1: 128-row blocks for the ds1 ResBlock out conv - norm + SiLU + 1x1 conv + skip +
+    statistics, unet:457-476) against <2, 2, 64>: Y bitwise equal (same K order, same epilogue arithmetic), the quad records equal up to the
+    order of the fp32 additions (a 64-row record is folded by a wave pair instead of one wave).  Each arm in its own interpreter: the
+    switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "arm.py"
+    script.write_text(_STRIP_RF1_SCRIPT)
+    outs = {}
+    for arm in ("0", "1"):
+        env = dict(os.environ, MMD_STRIP_K128_RF1=arm)
+        path = str(tmp_path / f"arm{arm}.pt")
+        subprocess.run([sys.executable, str(script), os.path.join(root, "mm-diffusion_amd"), path], check=True, env=env, timeout=600)
+        outs[arm] = torch.load(path)
+    assert torch.equal(outs["0"]["y"], outs["1"]["y"])
+    assert torch.allclose(outs["0"]["rec"], outs["1"]["rec"], rtol=1e-5, atol=1e-3)
+    yq = outs["1"]["y"].float().reshape(-1, 64, 32, 4)
+    assert torch.allclose(outs["1"]["rec"][..., 0], yq.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
