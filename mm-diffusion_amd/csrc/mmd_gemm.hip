@@ -1652,7 +1652,9 @@ static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
     // round 6: the ResBlock out conv of the ds1 levels (norm + SiLU + 1x1 + skip, 65536 / 25600 rows per sample) on 128-row blocks, four
     // per CU, instead of 256-row blocks, three per CU - 1024 blocks on 768 slots ran 1.33 rounds.  Chosen by the layer's rows per
     // SAMPLE (the record fold of a one-fragment wave differs in the last bit: the choice must not move with the batch size).
-    static const bool rf1 = [] { const char* e = getenv("MMD_STRIP_K128_RF1"); return e && e[0] == '1'; }();
+    // Same-call A/B (profiles/r06_lanes_width_aconv_call11.txt): the graded ResBlock 0.2042 -> 0.1990 ms, the step unchanged (10.85 / 10.84 ms).
+    // MMD_STRIP_K128_RF1=0: the two-fragment instance (A/B).
+    static const bool rf1 = [] { const char* e = getenv("MMD_STRIP_K128_RF1"); return !(e && e[0] == '0'); }();
     if (rf1 && p.gn_a && p.gn_rows >= 16384 && p.ntaps == 1 && p.Cout % 32 == 0) return launch_conv1x1_strip<2, 1, 32>(p, st);
     return launch_conv1x1_strip<2, 2, 64>(p, st);
   }

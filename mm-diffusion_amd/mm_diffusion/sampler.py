@@ -25,11 +25,15 @@ def unwrap_unet(model):
 
 
 def default_lanes(batch):
-    """Batch lanes of a sampling step (see GraphStepper): 1 unless MMD_LANES says otherwise.  Measured on MI355X at batch 4
-    (BASELINE configs[1]): 1 lane 15.53 ms / step, 2 lanes 15.37, 4 lanes 20.5 - the per-level kernels already occupy every CU
-    (LDS-limited residency), so a second lane's launches queue behind them instead of filling idle CUs."""
+    """Batch lanes of a sampling step (see GraphStepper).  MMD_LANES overrides.  Round 6: TWO lanes for batches of 4 and more (each
+    lane at least two samples).  Measured on MI355X at batch 4 (BASELINE configs[1]), same-call A/B on three boxes: 11.28 -> 11.09,
+    10.85 -> 10.77, 10.87 -> 10.79 ms per step with two lanes (profiles/r06_suite_and_lanes_call9.txt, r06_wgrad_strip_lanes_call10.txt,
+    r06_lanes_width_aconv_call11.txt); four lanes 15.0 ms (batch-1 launches fill a fraction of the chip and the 2 600 launches of a step
+    queue).  Round 2 had measured 15.53 / 15.37 / 20.5 ms for 1 / 2 / 4 lanes and kept one: the per-level kernels have become short
+    enough since that a second half-batch chain finds idle CUs beside the first one's latency-bound small levels.  The lanes are
+    independent engines: the trajectory does not depend on the lane count (bitwise, tests/test_lifetime_gpu.py)."""
     v = os.environ.get("MMD_LANES")
-    lanes = int(v) if v else 1
+    lanes = int(v) if v else (2 if batch >= 4 and batch % 2 == 0 else 1)
     return lanes if lanes >= 1 and batch % lanes == 0 else 1
 
 
@@ -40,7 +44,7 @@ class GraphStepper:
     streams; packed weights are shared) and its own captured graph; the lane graphs are launched on the lanes' private streams,
     forked from and joined to the caller's stream with events.  Every sample's trajectory is independent (GroupNorm / attention
     never mix batch elements, tests: batch sharding is bitwise exact), so the result is identical.  Noise and timestep buffers stay
-    full-batch (lanes read slices), so the RNG stream does not depend on `lanes`.  An option, not the default: see default_lanes."""
+    full-batch (lanes read slices), so the RNG stream does not depend on `lanes`.  Default: see default_lanes."""
 
     def __init__(self, diffusion, unet, batch, device, clip_denoised=True, use_graph=True, update="ddpm", eta=0.0, lanes=None):
         self.diff, self.unet, self.N = diffusion, unet, int(batch)

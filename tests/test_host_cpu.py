@@ -285,7 +285,7 @@ def test_default_lanes_and_bucket_partition():
     import torch
     from mm_diffusion.optim import FlatAdamW
     from mm_diffusion.sampler import default_lanes
-    assert default_lanes(4) == 1 and default_lanes(1) == 1
+    assert default_lanes(4) == 2 and default_lanes(8) == 2 and default_lanes(1) == 1 and default_lanes(2) == 1 and default_lanes(5) == 1
     g = torch.Generator().manual_seed(0)
     for nb in (1, 2, 4, 9):
         sizes = [int(v) for v in torch.randint(1, 5000, (23,), generator=g)]
