@@ -592,6 +592,7 @@ def main():
                    "ranks_seen": args.ranks_seen, "backend": args.backend},
         "model_tflops": steps_per_s * args.batch * MODEL_FLOPS_PER_PAIR / 1e12,
     }
+    timed_lanes = stepper.lanes
     if rank == 0 and not args.no_breakdown:
         if stepper.lanes > 1:      # per-kernel accounting on the unsplit batch-N plan (the shapes BASELINE.md grades), one stream, in order
             stepper = GraphStepper(diff, model, args.batch, device, clip_denoised=True, lanes=1)
@@ -639,20 +640,22 @@ def main():
             bound, unit, ach, peak = "hbm", "GB/s", a["bytes"] / (a["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS
         iso_ms = a["ms"] / max(a["calls"], 1)
         ach_iso = ach                          # from the isolated HIP-event replay of this run
-        ach_step = ach * iso_ms / in_step_ms if in_step_ms else None      # per-launch algorithmic work / the in-step launch time
+        # per-launch algorithmic work / the in-step launch time; with batch lanes the traced step's launches carry 1 / lanes of the work
+        # of the (unsplit) plan the breakdown replays
+        ach_step = ach * iso_ms / in_step_ms / timed_lanes if in_step_ms else None
         ach = ach_iso      # round 6: `frac` / `achieved` are THIS run's measurement; the in-step figure from the committed profile is a labelled side figure
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         res["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                            "frac_isolated": ach_iso / peak, "frac_in_step": (ach_step / peak) if ach_step is not None else None,
                            "frac_note": "frac = frac_isolated = this run's HIP-event replay of the family's launches on the launch stream; frac_in_step = the same work over the family's average launch inside the profiled step (profiles/kernel_stats.json: rocprofv3 kernel trace of this command, used only when its build id matches)",
-                           "mfma_frac_of_peak_in_step": (a["flops"] / max(a["calls"], 1) / (in_step_ms * 1e-3) / 1e12 / mfma_peak) if in_step_ms else None,
-                           "avg_launch_ms_in_step": in_step_ms, "avg_launch_ms_in_step_note": in_step_note or ("rocprofv3 kernel trace of this command, profiles/kernel_stats.json" if in_step_ms else "no profile of this build: frac is from the isolated replay"),
+                           "mfma_frac_of_peak_in_step": (a["flops"] / max(a["calls"], 1) / timed_lanes / (in_step_ms * 1e-3) / 1e12 / mfma_peak) if in_step_ms else None,
+                           "avg_launch_ms_in_step": in_step_ms, "in_step_batch_lanes": timed_lanes, "avg_launch_ms_in_step_note": in_step_note or ("rocprofv3 kernel trace of this command, profiles/kernel_stats.json" if in_step_ms else "no profile of this build: frac is from the isolated replay"),
                            "arithmetic_intensity_flop_per_B": ai, "ridge_flop_per_B": ridge,
                            "mfma_frac_of_peak": a["flops"] / (a["ms"] * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS),
                            "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": a["calls"], "avg_launch_ms": iso_ms,
                            "algorithmic_gflop_per_launch": a["flops"] / max(a["calls"], 1) / 1e9,
                            "algorithmic_MB_per_launch": a["bytes"] / max(a["calls"], 1) / 1e6,
-                           "hbm_frac_of_8TBs": a["bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS * (iso_ms / in_step_ms if in_step_ms else 1.0),
+                           "hbm_frac_of_8TBs": a["bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "share_of_step": a["ms"] / total_ms}
         res["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         hb = {k: v for k, v in agg.items() if v["flops"] == 0 and v["bytes"] > 0}
