@@ -621,7 +621,7 @@ def main():
             import re
             with open(os.path.join(ROOT, "profiles", "kernel_stats.json")) as f:
                 ks = json.load(f)
-            pat = {"conv_gemm<bf16,strip>": r"conv1x1_strip_kernel<\d+, \d+, \d+, 0, \d+>", "gn_conv1x1<bf16,strip>": r"conv1x1_strip_kernel<\d+, \d+, \d+, [12], \d+>",
+            pat = {"conv_gemm<bf16,strip>": r"conv1x1_strip(_res)?_kernel<\d+, \d+, \d+, 0, \d+>", "gn_conv1x1<bf16,strip>": r"conv1x1_strip(_res)?_kernel<\d+, \d+, \d+, [12], \d+>",
                    "conv_gemm<bf16,128glds>": r"conv_gemm_glds_kernel<.*, 2, (true|false)>", "conv_gemm<bf16,128ring>": r"conv_gemm_glds_kernel<.*, 4, (true|false)>",
                    "attn_fwd": r"attn_(dma|mfma|stage)_kernel", "vconv2d1d<bf16,gn>": r"vconv2d1d_kernel<[12]>", "gn_conv_gemm<bf16,256halo>": r"conv_gemm_halo16_kernel<true>"}.get(dom)
             if ks.get("build_id") != build_id():

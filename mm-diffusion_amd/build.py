@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libmmd.so")
 SOURCES = ["mmd_core.hip", "mmd_gemm.hip", "mmd_vconv.hip", "mmd_tattn.hip", "mmd_tconv.hip", "mmd_aconv.hip", "mmd_norm.hip", "mmd_attn.hip", "mmd_misc.hip", "mmd_bwd.hip", "mmd_attn_bwd.hip", "mmd_attn_bwd_mfma.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-inline-asm"]
 FLAGS += os.environ.get("MMD_EXTRA_CXXFLAGS", "").split()      # ablation builds (tools/*_bench.py), never set for the product
 # The library is built WITHOUT the packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32).  Measured on MI355X
 # (round 3, tools/determinism_mini.py): gn_small_kernel's packed accumulations came out slightly wrong in lanes 48-63 (high register of
@@ -81,6 +81,19 @@ def _check_no_packed_f32(path):
                            (len(bad), bad[0], path, " ".join(NO_PACKED_F32)))
 
 
+def _check_strip_asm(obj):
+    """The pipelined row-strip GEMM keeps in-flight residual rows in v[248:255] of kernels limited to 248 allocatable VGPRs; refuse the
+    build if any compiler-generated instruction of those kernels names one of the registers (tools/strip_asm_check.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("strip_asm_check", os.path.join(os.path.dirname(HERE), "tools", "strip_asm_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    chk.LLVM = _llvm_bin()
+    n, bad = chk.check(chk.disassemble(obj))
+    if n == 0 or bad:
+        raise RuntimeError("build check: conv1x1_strip_res_kernel: %d kernels checked, %d violations%s" % (n, len(bad), (": " + bad[0]) if bad else ""))
+
+
 def build(force=False, verbose=True):
     if not force and not _stale():
         return OUT
@@ -108,6 +121,7 @@ def build(force=False, verbose=True):
     try:
         subprocess.check_call(cmd)
         _check_no_packed_f32(tmp)            # raises: no half-checked library is left under the product's name ...
+        _check_strip_asm(os.path.join(HERE, "lib", "mmd_gemm.o"))
         os.replace(tmp, OUT)
     finally:
         if os.path.exists(tmp):              # ... and no rejected one next to it

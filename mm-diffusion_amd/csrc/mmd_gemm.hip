@@ -97,12 +97,20 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
 // exposed LDS round trips per K step.  With the 16 reads of a step issued first
 // and pinned there, every MFMA waits with a counted lgkmcnt and the LDS latency of read n + 1 hides under MFMA n.
 #define FRAG_FENCE() __builtin_amdgcn_sched_barrier(0)
+// A register that holds a LOAD result, used under a (divergent or uniform) branch, is 'maybe still pending' on the path that skips the use:
+// hipcc then waits vmcnt(0) again in front of its next use - behind stores issued meanwhile that means waiting for their acknowledgement
+// (an epilogue of 8 passes = 8 serialised store round trips).  Passing the registers through an empty asm once, after the wait, makes
+// them plain values.
+#define LAUNDER4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 
 // Padding taps / out-of-range rows read this zero page instead of branching around the load: every thread then issues a
 // STATIC number of global loads per K step, so the compiler can keep the newer register stage in flight with a counted
 // s_waitcnt vmcnt(N) (a load under a divergent branch forces vmcnt(0) and serialises the pipeline).
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) uint32_t g_zero_row[32] = {};      // 128 bytes: one K plane of a padding row (strip kernel)
+// where the strip kernel's rows past M store (never read): its stores are unconditional - a store behind a divergent branch costs
+// the straight-line epilogue its exact wait counts (the compiler re-waits, vmcnt(0), for loads 'pending' on the skipped path)
+__device__ __attribute__((aligned(16))) char g_store_sink[32768];
 
 
 template <typename T> struct Mma;
@@ -141,12 +149,28 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
         *(f32x4*)(sC + ml * LDC + col) = v;
       }
     }
-  __syncthreads();
   constexpr int CVN = BN / 8;          // 8-channel groups per row
   constexpr int RP = 256 / CVN;        // rows per pass
   constexpr int NREC = BM / 64;
   const int cg = tid % CVN, rr = tid / CVN;
   const int co = n0 + cg * 8;
+  // bf16: the residual rows of every pass are requested here, in front of the barrier (the pass loop used to load a row, wait, add,
+  // store: one serial HBM round trip per pass, and every wait also sat on the previous pass's store)
+  constexpr bool PRE = EPV == 8;
+  constexpr int PPR = 64 / RP;
+  u32x4 rres[PRE ? NREC * PPR : 1];
+  if (PRE && p.R) {
+#pragma unroll
+    for (int i = 0; i < NREC * PPR; ++i) {
+      const int m = m0 + (i / PPR) * 64 + rr + (i % PPR) * RP;
+      rres[i] = *(const u32x4*)((m < p.M && co < p.Cout) ? p.R + ((int64_t)m * p.ldr + co) * ES : (const char*)g_zero_page);
+    }
+  }
+  __syncthreads();
+  if (PRE && p.R) {
+#pragma unroll
+    for (int i = 0; i < NREC * PPR; ++i) LAUNDER4(rres[i]);
+  }
   float ssum[NREC][8], ssq[NREC][8];
 #pragma unroll
   for (int r = 0; r < NREC; ++r)
@@ -158,8 +182,9 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
     for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
 #pragma unroll
     for (int rec = 0; rec < NREC; ++rec) {
-#pragma unroll 2
-      for (int ml = rec * 64 + rr; ml < rec * 64 + 64; ml += RP) {
+#pragma unroll
+      for (int pp = 0; pp < PPR; ++pp) {
+        const int ml = rec * 64 + rr + pp * RP;
         const int m = m0 + ml;
         if (m >= p.M) break;
         float v[8];
@@ -171,7 +196,8 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16 (&
 #pragma unroll
           for (int h = 0; h < 8 / EPV; ++h) {
             float rf[EPV];
-            Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
+            if constexpr (PRE) Elt<T>::unpack(rres[rec * PPR + pp], rf);
+            else Elt<T>::unpack(*(const u32x4*)(p.R + ((int64_t)m * p.ldr + co + h * EPV) * ES), rf);
 #pragma unroll
             for (int j = 0; j < EPV; ++j) v[h * EPV + j] += rf[j];
           }
@@ -664,6 +690,12 @@ __global__ __launch_bounds__(256, (NS > 2 ? 1 : 2)) void conv_gemm_glds_kernel(c
   }
   compute(cur);
   __syncthreads();                                       // every wave is past its last operand read: sC may alias
+  if (p.R) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+      for (int h = 0; h < 8 / EPV; ++h) LAUNDER4(rres[ps][h]);
+  }
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -970,6 +1002,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_halo_kernel(const ConvGemmPa
   }
   compute((nit - 1) & 1, c & 1, t);
   __syncthreads();                                           // every wave is past its last operand read: sC may alias
+  if (p.R) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+      for (int h = 0; h < 8 / EPV; ++h) LAUNDER4(rres[ps][h]);
+  }
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -1238,6 +1276,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
   float bs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bs[j] = (p.bias && e_co < p.Cout) ? p.bias[e_co + j] : 0.f;
+  u32x4 rres[NPASS];                                          // residual rows of the epilogue passes: requested in front of the LAST step's MFMAs
+  auto row_of = [&](int ml) { return mframe + (int64_t)(h0 + (ml >> 4)) * p.D2 + w0 + (ml & 15); };
   if (GN) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (also the weights of steps 0 / 1: the loop's first waits are then no-ops)
     __builtin_amdgcn_s_barrier();
@@ -1254,6 +1294,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
       __builtin_amdgcn_s_barrier();                            // ... for every wave; every wave is past its fragment reads of the previous step
       asm volatile("" ::: "memory");
       const int wslot = (c * NT + t) % NWS;
+      if (t == NT - 1 && !more && p.R) {   // (the pass loop used to load a row, wait, add, store - a serial HBM round trip per pass; the loads
+        //                                    sit in front of this step's DMA group in the in-order queue and are drained by the final wait)
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+          rres[ps] = *(const u32x4*)(e_co < p.Cout ? p.R + (row_of(e_rr + ps * RP) * p.ldr + e_co) * ES : (const char*)g_zero_page);
+      }
       // the DMA group of this step: weights of the step after next into the slot the previous step left + one instruction for a later chunk
       auto group = [&](int i) {
         const int t2 = (t + 2) % NT, c2 = c + (t + 2) / NT;
@@ -1273,6 +1319,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                             // every wave is past its last operand read: sC may alias
+  if (p.R) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) LAUNDER4(rres[ps]);
+  }
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -1291,7 +1341,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int ml = e_rr + ps * RP;
-      const int64_t m = mframe + (int64_t)(h0 + (ml >> 4)) * p.D2 + w0 + (ml & 15);
+      const int64_t m = row_of(ml);
       float v[8];
       const f32x4 c0 = *(const f32x4*)(sC + ml * LDC + e_cg * 8);
       const f32x4 c1 = *(const f32x4*)(sC + ml * LDC + e_cg * 8 + 4);
@@ -1299,7 +1349,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
       for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bs[j]; v[4 + j] = c1[j] + bs[4 + j]; }
       if (p.R) {
         float rf[EPV];
-        Elt<T>::unpack(*(const u32x4*)(p.R + (m * p.ldr + e_co) * ES), rf);
+        Elt<T>::unpack(rres[ps], rf);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) v[j] += rf[j];
       }
@@ -1325,17 +1375,51 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 // recursive-halving butterfly over the 32 lanes of a half-wave), so launches that emit statistics are chosen by layer geometry,
 // never by timing (ops.strip_tile_pinned).
 // Grid = row strips x nsplit column ranges (nsplit fills the chip when M is small; results do not depend on it).
+// Round 6: (1) the weight DMA is issued through asm and every wait of the loop is explicit: with an LDS DMA the compiler KNOWS of in flight it
+// waits vmcnt(0) in front of every LDS read that might alias it (the bias reads of each epilogue unit = the acknowledgement of the store
+// before it; in straight-line code also the first fragment read behind the issue = the prefetch itself); (2) the residual operand is a
+// template parameter and rows past M store to a sink: no divergent branch in the epilogue; (3) the K >= 256 instances run a software
+// pipeline over the sub-tiles (see PIPE below): ds2 qkv 46.7 -> 39.1 us, ds4 qkv 30.2 -> 25.2 us (profiles/r06_strip_pipeline.txt).
 // (halfwave_total - the DPP fold of the quad statistics - lives in mmd_common.h: the fused VideoConv kernel shares it.)
-template <int KS, int RF, int CC, int GNM, int STM>   // STM: output statistics 0 none / 1 quad records (compile
+// The pipelined strip loop requests its residual pieces one block ahead and waits for them with exact counts.  A compiler-visible load would
+// be waited for by the compiler's count, which does not know the weight DMA (asm); an asm load with an OUTPUT operand is 'ready' as far as the
+// compiler knows, and it copies the registers (operand matching, loop edges) before the wait - measured: wrong results, a fault when the
+// destination was dead.  So the pieces live in registers the compiler never allocates: the kernels with a residual are limited to 248 VGPRs
+// (amdgpu_num_vgpr) and v[248:255] belong to these two statements; the second waits and unpacks into ordinary outputs.
+#define STRIP_RES_LOAD(J2, ptr)                                                                                              \
+  do {                                                                                                                       \
+    if ((J2) == 0) asm volatile("global_load_dwordx4 v[248:251], %0, off" :: "v"(ptr) : "v248", "v249", "v250", "v251");      \
+    else asm volatile("global_load_dwordx4 v[252:255], %0, off" :: "v"(ptr) : "v252", "v253", "v254", "v255");                \
+  } while (0)
+#define STRIP_RES_UNPACK_ASM(A, B, C, D)                                                                                     \
+  "s_waitcnt vmcnt(%8)\n\tv_lshlrev_b32 %0, 16, " A "\n\tv_and_b32 %1, 0xffff0000, " A "\n\tv_lshlrev_b32 %2, 16, " B "\n\tv_and_b32 %3, 0xffff0000, " B \
+  "\n\tv_lshlrev_b32 %4, 16, " C "\n\tv_and_b32 %5, 0xffff0000, " C "\n\tv_lshlrev_b32 %6, 16, " D "\n\tv_and_b32 %7, 0xffff0000, " D
+#define STRIP_RES_WAIT(J2, rf, n)                                                                                            \
+  do {                                                                                                                       \
+    if ((J2) == 0)                                                                                                           \
+      asm volatile(STRIP_RES_UNPACK_ASM("v248", "v249", "v250", "v251")                                                      \
+                   : "=v"(rf[0]), "=v"(rf[1]), "=v"(rf[2]), "=v"(rf[3]), "=v"(rf[4]), "=v"(rf[5]), "=v"(rf[6]), "=v"(rf[7]) : "n"(n));  \
+    else                                                                                                                     \
+      asm volatile(STRIP_RES_UNPACK_ASM("v252", "v253", "v254", "v255")                                                      \
+                   : "=v"(rf[0]), "=v"(rf[1]), "=v"(rf[2]), "=v"(rf[3]), "=v"(rf[4]), "=v"(rf[5]), "=v"(rf[6]), "=v"(rf[7]) : "n"(n));  \
+  } while (0)
+// s_waitcnt immediate of gfx9: vmcnt(n) lgkmcnt(0), expcnt untouched
+__host__ __device__ constexpr int wait_imm(int vm) { return (vm & 15) | ((vm >> 4) << 14) | 0x0070; }
+template <int KS, int RF, int CC, int GNM, int STM, bool HR>   // HR: residual operand (compile time: behind a runtime branch hipcc waits vmcnt(0) in
+                                             // front of EVERY use of the residual registers, i.e. for the acknowledgement of the store issued just before). STM: output statistics 0 none / 1 quad records (compile
                                              // time: the runtime branches cost the K = 128 instance 30 spilled registers).  GNM: 0 no GroupNorm, 1 fused affine, 2 fused affine + SiLU (compile time: two copies of the
                                              // normalisation in one kernel spill ~100 registers around the branch)
-__global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
+__device__ __forceinline__ void conv1x1_strip_body(const ConvGemmParams& p, const int nsplit) {
   constexpr int K = 64 * KS;                 // input channels
   constexpr int NCG = 4 * KS;                // 16-channel k-steps (one MFMA each)
   constexpr int BR = 128 * RF;               // rows per block: 4 waves x RF fragments of 32 rows
   constexpr int NA = CC / 32;                // 32-channel output sub-tiles per chunk
   constexpr int GP = CC / 32;                // weight DMA instructions per wave per 64-channel plane (CC / 8 row groups over 4 waves)
   constexpr int PLANE_B = CC * 128, STAGE_B = KS * PLANE_B;
+  // software-pipelined sub-tile loop (below): the instances whose launches run one workgroup per CU (K >= 256: the ds2 / ds4 / ds8 levels; the K = 128
+  // launches of the ds1 level put 3 - 4 workgroups on a CU and the hardware overlaps their waves).  K = 256 with a residual does not fit the
+  // register file (two accumulator sets + the rows' 128 operand registers + the residual pieces: ~45 spilled registers)
+  constexpr bool PIPE = KS >= 4 && !(KS == 4 && HR);
   constexpr bool DEFER = KS > 2 || RF == 1;  // K = 128 / 256 with two fragments: 1-4 chunks per block, the 16 registers buy a third wave per SIMD
   static_assert(RF == 2 || CC == 32, "one row fragment per wave: one sub-tile per chunk, deferred epilogue");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1370,26 +1454,33 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
     const int logical = pc ^ ((row >> 1) & 7);
     w_ptr[ih] = p.W + ((int64_t)(cbase + row) * K + logical * 8) * 2;
   }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)sW;
   auto issue = [&](int stage, int ci) {
     const int64_t off = (int64_t)ci * CC * K * 2;
 #pragma unroll
     for (int pl = 0; pl < KS; ++pl)
 #pragma unroll
       for (int ih = 0; ih < GP; ++ih)
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr[ih] + off + pl * 128),
-                                         (lptr_t)(sW + stage * STAGE_B + pl * PLANE_B + (ih * 4 + wave) * 1024), 16, 0, 0);
+        // asm, not __builtin_amdgcn_global_load_lds: with an LDS DMA the compiler KNOWS of in flight, it puts s_waitcnt vmcnt(0) in front of
+        // every LDS read that might alias it - the bias reads of each epilogue unit (= the acknowledgement of the store issued just
+        // before: four serialised store round trips per sub-tile) and, in straight-line code, the first weight fragment read after the
+        // issue (= the prefetch).  Untracked VMEM instructions only make the compiler's own counted waits conservative (in-order return).
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(w_ptr[ih] + off + pl * 128), "s"(lds0 + stage * STAGE_B + pl * PLANE_B + (ih * 4 + wave) * 1024) : "memory", "m0");
   };
 
   issue(0, 0);
   // the strip's activations: fragment f, k-step cg = 8 channels [16 cg + 8 half, +8) of row l31 - the B operand of the MFMA
   int rowc[RF];
   bool rok[RF];
+  char* yrow[RF];
   u32x4 xa[RF][NCG];
 #pragma unroll
   for (int f = 0; f < RF; ++f) {
     const int row = m0 + wave * (32 * RF) + f * 32 + l31;   // m0 + BR may pass M by less than one block: no overflow (M < 2^31 - 256)
     rok[f] = row < p.M;
-    rowc[f] = rok[f] ? row : p.M - 1;                    // tail rows read a valid row and are never stored
+    rowc[f] = rok[f] ? row : p.M - 1;                    // tail rows read a valid row and store to the sink
+    yrow[f] = rok[f] ? p.Y + (int64_t)row * p.ldy * 2 : g_store_sink;
     if (p.ntaps == 1) {                                  // block-uniform
       const char* ap = p.A + ((int64_t)rowc[f] * p.lda + half * 8) * 2;
 #pragma unroll
@@ -1445,8 +1536,10 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
 #pragma unroll
     for (int e = 0; e < KS; ++e) sGN[tid + 256 * e] = tv[e];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                       // chunk 0 landed; bias / affine tables visible
+  // (the builtin, not asm: the compiler's own scoreboard must see the wait, or it re-waits - vmcnt(0) - for 'pending' loads at their next
+  // use, which by then sits behind the next chunk's DMA issue)
+  __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();                          // chunk 0 landed; bias / affine tables visible
   if (gn) {
 #pragma unroll
     for (int f = 0; f < RF; ++f)
@@ -1476,6 +1569,206 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
   const int xsw = (l31 >> 1) & 7;
   const bool wave_ok = (int64_t)m0 + wave * (32 * RF) < p.M;      // wave-uniform: statistics records are whole waves (RF = 2)
   const int64_t rec = ((int64_t)m0 + wave * (32 * RF)) / 64;
+  if constexpr (PIPE) {
+    // ---- software pipeline over the 32-column sub-tiles (round 6).  Block s = the MFMAs of sub-tile s into one accumulator set with the
+    // epilogue of sub-tile s - 1 (the other set) between them: a lone wave per SIMD - the launches of one workgroup per CU - used to run
+    // the two back to back, the matrix pipe idle under ~300 epilogue VALU instructions per chunk and the VALU idle under 2048 MFMA cycles.
+    // Every vector-memory LOAD of the loop is asm (weight DMA, residual rows) and every wait explicit and counted: vmcnt retires in order,
+    // the stores are the only instructions the compiler tracks and nothing ever waits for them.
+    //   per epilogue unit (j2, f): [wait for the unit's residual piece] ... store, [request the same piece of the NEXT sub-tile into the
+    //   same registers]: VM_U instructions, so behind a residual request sit 2 (NU - 1) guaranteed instructions (+ D when a chunk's DMA
+    //   issue lies between) until its use one block later; behind a chunk's DMA NA * NU * VM_U until the chunk boundary.  The conditional
+    //   statistics stores only add to the real count: the waits get stricter by instructions that are old anyway.
+    constexpr int NU = 2 * RF, D = KS * GP, VM_U = HR ? 2 : 1;
+    const int NS = nchunk * NA;
+    f32x16 acc[2][RF];
+    static_assert(!HR || RF == 1, "two residual pieces in v[248:255]");
+    float erf[8];                                        // the unit's residual piece, unpacked
+    float keep[2][2][2];                                 // [block parity][j2][sum | sum of squares] of the last epilogue's records
+    const char* rrow[RF];
+    if constexpr (HR) {
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        rrow[f] = p.R + ((int64_t)rowc[f] * p.ldr + cbase + 8 * half) * 2;
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) STRIP_RES_LOAD(j2, rrow[f] + 32 * j2);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (sub-tile 0's residual: complete before the loop, its waits below are then no-ops)
+    }
+    // one MFMA of sub-tile s_: index i = (pl * 4 + c) * RF + f; the weight fragment of k-step (pl, c) is read PF k-steps ahead
+    constexpr int NM = KS * 4 * RF, NKS = KS * 4, PF = RF == 2 ? 1 : 2;
+    u32x4 fwr[PF + 1];
+    auto frag_read = [&](int s_, int ks) __attribute__((always_inline)) {
+      const int st = (s_ / NA) & 1, a = s_ % NA;
+      fwr[ks % (PF + 1)] = *(const u32x4*)(sW + st * STAGE_B + (a * 32 + l31) * 128 + (ks >> 2) * PLANE_B + (((2 * (ks & 3) + half) ^ xsw) * 16));
+    };
+    auto mfma_one = [&](int i, f32x16 (&ac)[RF]) __attribute__((always_inline)) {
+      const int ks = i / RF, f = i % RF;
+      if (ks == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac[f][r] = 0.f;
+      }
+      Mma<__bf16>::run(fwr[ks % (PF + 1)], xa[f][ks], ac[f]);
+    };
+    // the epilogue of a sub-tile as a list of steps of 3 - 8 VALU instructions each (all indices are constants after unrolling):
+    //   per j2, per f: four steps "pair q" (permlane swap, bias, residual), one step "pack, store, next residual request", four
+    //   statistics steps; per j2: four half-wave folds and one step that keeps / parks the record.
+    constexpr int SPU = 5 + (STM ? 4 : 0), PJ = RF * SPU + (STM ? 5 : 0), NSTEP = 2 * PJ;
+    float ev[8], eu[4], et[4];
+    u32x4 epk;
+    f32x4 eb[2][2];
+    auto epi_begin = [&](int s_) __attribute__((always_inline)) {
+      eb[0][0] = *(const f32x4*)(sBias + s_ * 32 + 8 * half);
+      eb[0][1] = *(const f32x4*)(sBias + s_ * 32 + 8 * half + 4);
+    };
+    auto epi_step = [&](int s_, f32x16 (&ac)[RF], float (&kp)[2][2], int t, bool dma_between, bool last) __attribute__((always_inline)) {
+      const int j2 = t / PJ, r = t % PJ;
+      const int cb = s_ * 32;
+      const int a = s_ % NA, par = (s_ / NA) & 1;
+      if (r == 0) {
+        if (j2 == 0) {
+          eb[1][0] = *(const f32x4*)(sBias + cb + 16 + 8 * half);
+          eb[1][1] = *(const f32x4*)(sBias + cb + 16 + 8 * half + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) eu[k] = 0.f;
+      }
+      if (r < RF * SPU) {
+        const int f = r / SPU, k = r % SPU;
+        if (k < 4) {
+          if (HR && k == 0) {
+            // last sub-tile (no MFMAs, no further requests): behind this unit's request sit the 2 (NU - 1 - u) instructions of the units
+            // behind it in the previous block and the u stores of this epilogue
+            if (last) STRIP_RES_WAIT(j2, erf, 2 * (NU - 1 - (j2 * RF + f)) + (j2 * RF + f));
+            else if (dma_between) STRIP_RES_WAIT(j2, erf, 2 * (NU - 1) + D);
+            else STRIP_RES_WAIT(j2, erf, 2 * (NU - 1));
+          }
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ac[f][8 * j2 + k]), __float_as_uint(ac[f][8 * j2 + 4 + k]), false, false);
+          ev[k] = __uint_as_float(sw[0]) + eb[j2][0][k];
+          ev[4 + k] = __uint_as_float(sw[1]) + eb[j2][1][k];
+          if constexpr (HR) {
+            ev[k] += erf[k];
+            ev[4 + k] += erf[4 + k];
+          }
+        } else if (k == 4) {
+          epk = Elt<__bf16>::pack(ev);
+          *(u32x4*)(yrow[f] + (cbase + cb + 16 * j2 + 8 * half) * 2) = epk;
+          if (HR && !last) STRIP_RES_LOAD(j2, rrow[f] + (cb + 32) * 2 + 32 * j2);
+        } else {                                         // statistics of the values as STORED: word q = values 2 q, 2 q + 1 of the lane's two quads
+          const int q = k - 5;
+          const float r0 = __uint_as_float(epk[q] << 16), r1 = __uint_as_float(epk[q] & 0xffff0000u);
+          eu[q >> 1] += r0;
+          eu[q >> 1] += r1;
+          eu[2 + (q >> 1)] += r0 * r0;
+          eu[2 + (q >> 1)] += r1 * r1;
+        }
+      } else {
+        const int h = r - RF * SPU;
+        if (h < 4) et[h] = halfwave_total(eu[h]);
+        else {
+          // lanes 16 / 17 of each half hold the (sum, sum of squares) of quad 0 / 1 of the lane group's 8 channels
+          kp[j2][0] = (l31 & 1) ? et[1] : et[0];
+          kp[j2][1] = (l31 & 1) ? et[3] : et[2];
+          if (RF == 1) {
+            // a wave holds HALF a record (32 rows): park the partial for the even wave of the pair, which adds (own + partner) behind the
+            // next chunk boundary; the buffer alternates with the chunk parity of the sub-tile.  Unconditional (lanes that hold nothing
+            // write a dump slot): a divergent branch here would cut the block's straight-line code in two
+            float* d = sRec + ((l31 >> 1) == 8 ? (((par * 4 + wave) * (NA * 2) + a * 2 + j2) * 2 + half) * 4 + (l31 & 1) * 2 : 128 + lane * 2);
+            d[0] = kp[j2][0];
+            d[1] = kp[j2][1];
+          }
+        }
+      }
+    };
+    // block: the MFMAs of sub-tile s_ into an, the epilogue steps of sub-tile s_ - 1 (from ap) spread evenly between them; sched_barrier
+    // pins the order (left alone hipcc issues the MFMAs back to back and the epilogue behind them)
+    auto block = [&](int s_, f32x16 (&an)[RF], f32x16 (&ap)[RF], float (&kp)[2][2], bool dma_between) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < PF; ++ks) frag_read(s_, ks);
+      epi_begin(s_ - 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i % RF == 0 && i / RF + PF < NKS) frag_read(s_, i / RF + PF);
+        mfma_one(i, an);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = NSTEP * i / NM; t < NSTEP * (i + 1) / NM; ++t) epi_step(s_ - 1, ap, kp, t, dma_between, false);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto mfma_sub = [&](int s_, f32x16 (&ac)[RF]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < PF; ++ks) frag_read(s_, ks);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i % RF == 0 && i / RF + PF < NKS) frag_read(s_, i / RF + PF);
+        mfma_one(i, ac);
+      }
+    };
+    auto epi = [&](int s_, f32x16 (&ac)[RF], float (&kp)[2][2], bool dma_between, bool last) __attribute__((always_inline)) {
+      epi_begin(s_);
+#pragma unroll
+      for (int t = 0; t < NSTEP; ++t) epi_step(s_, ac, kp, t, dma_between, last);
+    };
+    // the records of sub-tile s_: RF = 2 right behind its epilogue, RF = 1 behind the chunk boundary after it (partner's half from LDS)
+    auto commit = [&](int s_, float (&kp)[2][2]) __attribute__((always_inline)) {
+      if (STM == 1 && wave_ok && (RF == 2 || (wave & 1) == 0) && (l31 >> 1) == 8) {
+        const int a = s_ % NA, par = (s_ / NA) & 1;
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+          const int col = cbase + s_ * 32 + 16 * j2 + 8 * half;
+          float* d = p.stats + (rec * p.stats_ld + (col >> 2) + (l31 & 1)) * 2;
+          float o0 = 0.f, o1 = 0.f;
+          if (RF == 1) {
+            const float* o = sRec + ((((par * 4 + wave + 1) * (NA * 2) + a * 2 + j2) * 2 + half) * 4 + (l31 & 1) * 2);
+            o0 = o[0];
+            o1 = o[1];
+          }
+          d[0] = kp[j2][0] + o0;
+          d[1] = kp[j2][1] + o1;
+        }
+      }
+    };
+    // entering chunk c >= 1: its weights have landed for every wave, every wave is past its fragment reads of chunk c - 1
+    auto boundary = [&](int c) __attribute__((always_inline)) {
+      if (c == 1) __builtin_amdgcn_s_waitcnt(wait_imm((NA - 1) * NU * VM_U));      // (chunk 0's first block has no epilogue)
+      else __builtin_amdgcn_s_waitcnt(wait_imm(NA * NU * VM_U));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue((c + 1) & 1, c + 1 < nchunk ? c + 1 : nchunk - 1);      // (unconditional: the counts above assume it)
+    };
+    issue(1, nchunk > 1 ? 1 : 0);
+    mfma_sub(0, acc[0]);
+    for (int s1 = 1; s1 < NS; s1 += 2) {
+      if (NA == 1) {
+        boundary(s1);
+        if (RF == 1 && s1 >= 2) commit(s1 - 2, keep[1]);
+      }
+      block(s1, acc[1], acc[0], keep[0], NA == 1);
+      if (RF == 2) commit(s1 - 1, keep[0]);
+      if (s1 + 1 < NS) {
+        boundary((s1 + 1) / NA);
+        if (RF == 1) commit(s1 - 1, keep[0]);
+        block(s1 + 1, acc[0], acc[1], keep[1], true);
+        if (RF == 2) commit(s1, keep[1]);
+      }
+    }
+    // the last sub-tile's epilogue (its parity is uniform but not a constant)
+    auto tail = [&](f32x16 (&ac)[RF], float (&kp)[2][2], float (&kq)[2][2]) __attribute__((always_inline)) {
+      epi(NS - 1, ac, kp, false, true);
+      if (RF == 2) commit(NS - 1, kp);
+      if (RF == 1 && STM == 1) {                          // block-uniform
+        __builtin_amdgcn_s_waitcnt(wait_imm(63));        // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (NS >= 2) commit(NS - 2, kq);
+        commit(NS - 1, kp);
+      }
+    };
+    if ((NS - 1) & 1) tail(acc[1], keep[1], keep[0]);
+    else tail(acc[0], keep[0], keep[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the last boundary's weight DMA (a repeat of the last chunk) must not outlive the workgroup's LDS
+  } else {
   for (int ci = 0; ci < nchunk; ++ci) {
     const int st = ci & 1;
     if (ci + 1 < nchunk) issue(st ^ 1, ci + 1);         // next chunk's weights land under this chunk's MFMAs
@@ -1485,7 +1778,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
     for (int a = 0; a < NA; ++a) {
       const int cb = ci * CC + a * 32;                   // first column of the sub-tile inside this block's range
       u32x4 rres[RF][2];
-      if (p.R) {
+      if constexpr (HR) {
 #pragma unroll
         for (int f = 0; f < RF; ++f)
 #pragma unroll
@@ -1527,7 +1820,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
-          if (p.R) {
+          if constexpr (HR) {
             float rf[8];
             Elt<__bf16>::unpack(rres[f][j2], rf);
 #pragma unroll
@@ -1535,7 +1828,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
           }
           const u32x4 pk = Elt<__bf16>::pack(v);
           if (DEFER && a == NA - 1) outv[f][j2] = pk;
-          else if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = pk;
+          else *(u32x4*)(yrow[f] + col * 2) = pk;
           if (STM != 0) {                                // statistics of the values as STORED: the lane's 8 channels = two QUADS
             float rf[8];
             Elt<__bf16>::unpack(pk, rf);
@@ -1571,14 +1864,14 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                     // next chunk landed; every wave is past its reads of this stage
+    __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();                        // next chunk landed; every wave is past its reads of this stage
 #pragma unroll
     for (int j2 = 0; DEFER && j2 < 2; ++j2) {
       const int col = cbase + ci * CC + (NA - 1) * 32 + 16 * j2 + 8 * half;
 #pragma unroll
       for (int f = 0; f < RF; ++f)
-        if (rok[f]) *(u32x4*)(p.Y + ((int64_t)rowc[f] * p.ldy + col) * 2) = outv[f][j2];
+        *(u32x4*)(yrow[f] + col * 2) = outv[f][j2];
       if (RF == 1) {
         if (STM == 1 && wave_ok && (wave & 1) == 0 && (l31 >> 1) == 8) {
           const float* o = sRec + ((((ci & 1) * 4 + wave + 1) * (NA * 2) + (NA - 1) * 2 + j2) * 2 + half) * 4 + (l31 & 1) * 2;
@@ -1589,10 +1882,22 @@ __global__ __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2)) void conv1x
       }
     }
   }
+  }
 }
 
+#define STRIP_LAUNCH_BOUNDS __launch_bounds__(256, (KS <= 2 ? (RF == 1 ? 4 : 3) : 2))
 template <int KS, int RF, int CC, int GNM, int STM>
-static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
+__global__ STRIP_LAUNCH_BOUNDS void conv1x1_strip_kernel(const ConvGemmParams p, const int nsplit) {
+  conv1x1_strip_body<KS, RF, CC, GNM, STM, false>(p, nsplit);
+}
+// with a residual operand: v[248:255] are not the compiler's (STRIP_RES_LOAD / STRIP_RES_WAIT above)
+template <int KS, int RF, int CC, int GNM, int STM>
+__global__ STRIP_LAUNCH_BOUNDS __attribute__((amdgpu_num_vgpr(248))) void conv1x1_strip_res_kernel(const ConvGemmParams p, const int nsplit) {
+  conv1x1_strip_body<KS, RF, CC, GNM, STM, true>(p, nsplit);
+}
+
+template <int KS, int RF, int CC, int GNM, int STM, bool HR>
+static int launch_conv1x1_strip_res(const ConvGemmParams& p, hipStream_t st) {
   constexpr int BR = 128 * RF, STAGE_B = KS * CC * 128;
   const int rowblocks = cdiv(p.M, BR), nch = p.Cout / CC;
   // column split: the smallest divisor of the chunk count that gives the chip ONE block per CU (the strip's rows are then loaded nsplit
@@ -1620,12 +1925,19 @@ static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_strip_kernel<KS, RF, CC, GNM, STM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    const void* kfn = HR ? (const void*)conv1x1_strip_res_kernel<KS, RF, CC, GNM, STM> : (const void*)conv1x1_strip_kernel<KS, RF, CC, GNM, STM>;
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "conv1x1_strip: set LDS attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv1x1_strip_kernel<KS, RF, CC, GNM, STM>), dim3(rowblocks * nsplit), dim3(256), lds, st, p, nsplit);
+  if (HR) hipLaunchKernelGGL((conv1x1_strip_res_kernel<KS, RF, CC, GNM, STM>), dim3(rowblocks * nsplit), dim3(256), lds, st, p, nsplit);
+  else hipLaunchKernelGGL((conv1x1_strip_kernel<KS, RF, CC, GNM, STM>), dim3(rowblocks * nsplit), dim3(256), lds, st, p, nsplit);
   return mmd_check_launch("conv1x1_strip");
+}
+
+template <int KS, int RF, int CC, int GNM, int STM>
+static int launch_conv1x1_strip_mode(const ConvGemmParams& p, hipStream_t st) {
+  return p.R ? launch_conv1x1_strip_res<KS, RF, CC, GNM, STM, true>(p, st) : launch_conv1x1_strip_res<KS, RF, CC, GNM, STM, false>(p, st);
 }
 
 template <int KS, int RF, int CC, int STM>
@@ -1644,7 +1956,7 @@ static int launch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
 static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
   const int K = p.Cin * p.ntaps;
   const int rf = K <= 256 ? 2 : 1, cc = K <= 256 ? 64 : 32;
-  if ((K != 128 && K != 256 && K != 384 && K != 512) || p.Cin % 64 != 0 || p.Cout % cc != 0 || (p.gn_a && (p.ntaps != 1 || p.gn_rows < 128 * rf)) ||
+  if ((K != 128 && K != 256 && K != 384 && K != 512) || p.Cin % 64 != 0 || p.Cout % cc != 0 || p.Cout > 16384 || (p.gn_a && (p.ntaps != 1 || p.gn_rows < 128 * rf)) ||
       (p.ntaps == 1 && (p.taps[0] || p.taps[1] || p.taps[2])))
     return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): needs ntaps * Cin in {128, 256, 384, 512}, Cin %% 64 == 0, Cout %% %d == 0, "
                          "fused GroupNorm only for 1x1 convs with slices of >= %d rows (got Cin=%d ntaps=%d Cout=%d)", cc, 128 * rf, p.Cin, p.ntaps, p.Cout);

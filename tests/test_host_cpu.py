@@ -463,6 +463,34 @@ def test_profile_summarisers_on_a_synthetic_trace(tmp_path):
     assert abs(float(row[4]) - 1.7) < 1e-3                  # GHz(sum / 8)
 
 
+def test_strip_residual_registers_are_not_the_compilers():
+    """tools/strip_asm_check.py on the built object: the pipelined row-strip GEMM keeps its in-flight residual pieces in v[248:255] of the
+    kernels that are limited to 248 allocatable VGPRs; any other instruction naming one of them (a copy of a register whose load has not
+    landed: the failure mode measured in round 6, profiles/r06_strip_pipeline.txt) fails the build check.  Also on a synthetic listing."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("strip_asm_check", os.path.join(root, "tools", "strip_asm_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    good = """0000000000001000 <_Z24conv1x1_strip_res_kernelILi6ELi1ELi32ELi0ELi0EEv14ConvGemmParamsi>:
+\tglobal_load_dwordx4 v[248:251], v[2:3], off                // 000000001000: DC5C8000 F87F0002
+\tv_add_f32_e32 v1, v2, v3                                   // 000000001008: 02020702
+\ts_waitcnt vmcnt(2)                                         // 00000000100C: BF8C0F72
+\tv_lshlrev_b32_e32 v4, 16, v248                             // 000000001010: 2409F090
+\tv_and_b32_e32 v5, 0xffff0000, v248                         // 000000001014: 260BF0FF FFFF0000
+"""
+    n, bad = chk.check(good)
+    assert n == 1 and bad == []
+    n, bad = chk.check(good + "\tv_mov_b64_e32 v[6:7], v[248:249]                           // 00000000101C: 7E0C71F8\n")
+    assert n == 1 and len(bad) == 1 and "touches" in bad[0]
+    n, bad = chk.check(good.replace("\ts_waitcnt vmcnt(2)", "\ts_nop 0"))
+    assert len(bad) == 2 and all("without the wait" in b for b in bad)
+    obj = os.path.join(root, "mm-diffusion_amd", "lib", "mmd_gemm.o")
+    if os.path.exists(obj) and os.path.exists(os.path.join(chk.LLVM, "llvm-objdump")):
+        n, bad = chk.check(chk.disassemble(obj))
+        assert n == 12 and bad == [], bad[:3]
+
+
 def test_preserve_rng_restores_the_device_generator(monkeypatch):
     """_hip.preserve_rng (around plan building: the tile autotuner draws N(0,1) scratch data from torch's default device generator, which a
     seeded sampling loop must not see - profiles/r05_rccl_world1_and_rng.txt): a no-op for CPU devices, and for a device generator the state

@@ -35,7 +35,7 @@ def label_of(kernel_name):
     import re
     k = kernel_name
     fp32 = "<float" in k or re.search(r"kernelIf", k) is not None
-    m = re.search(r"conv1x1_strip_kernel(?:<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)|ILi\d+ELi\d+ELi\d+ELi(\d+)E)", k)
+    m = re.search(r"conv1x1_strip(?:_res)?_kernel(?:<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)|ILi\d+ELi\d+ELi\d+ELi(\d+)E)", k)
     if m:
         return "conv_gemm<bf16,strip>" if (m.group(1) or m.group(2)) == "0" else "gn_conv1x1<bf16,strip>"
     if fp32:

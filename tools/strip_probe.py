@@ -71,8 +71,8 @@ def main():
         r = torch.randn(M, Cout, device="cuda", generator=g).to(BF) if res else None
         y_old = torch.empty(M, Cout, device="cuda", dtype=BF)
         y_new = torch.full((M, Cout), float("nan"), device="cuda", dtype=BF)
-        rec_old = torch.zeros(M // 64, Cout, 2, device="cuda") if st else None
-        rec_new = torch.zeros(M // 64, Cout, 2, device="cuda") if st else None
+        rec_old = torch.zeros(M // 64, Cout // 4, 2, device="cuda") if st else None      # one record per 64 rows and quad of channels
+        rec_new = torch.zeros(M // 64, Cout // 4, 2, device="cuda") if st else None
         if gn is None or isinstance(gn, str):
             taps, dims = ops.TAPS_1, (1, 1, 1)
             if gn == "temporal":                             # D = (F, HW, 1), 16 frames
@@ -116,8 +116,8 @@ def main():
         err = float((y_new.float() - y_old.float()).norm() / y_old.float().norm())
         serr = ""
         if st:
-            yf = y_new.double().view(M // 64, 64, Cout)
-            ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
+            yf = y_new.double().view(M // 64, 64, Cout // 4, 4)
+            ref = torch.stack([yf.sum((1, 3)), (yf * yf).sum((1, 3))], dim=-1)
             serr = f" stats-err {float((rec_new.double() - ref).abs().max() / ref.abs().max()):.1e}"
         kk = Cin * (3 if isinstance(gn, str) else 1)
         nbytes = 2 * (M * Cin + M * Cout * (2 if res else 1))
