@@ -20,7 +20,7 @@ struct WgradParams {
   int torch_layout;
   int M, Cout, Cin, ntaps;
   int D0, D1, D2;
-  int rows_per_split;
+  int rows_per_split, splits, xcd_order;
   int taps[27 * 3];
 };
 
@@ -255,15 +255,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_bf16_kernel(const WgradParams
   const int wi = wave & 1, wj = wave >> 1;
   const int half = lane >> 5, l31 = lane & 31;
   const int ci_tiles = (p.Cin + 127) / 128;
-  const int kt_blk = blockIdx.y;
+  // round 6: XCD-aware block order.  The (co tile, ci tile, tap) blocks of one row split read the SAME rows of dY (per co tile) and of X
+  // (per ci tile, shifted by the tap): 9 - 27 blocks per split for the 3 x 3 convs.  Dispatched in grid order they land on all eight XCDs
+  // (workgroup id % 8) and every L2 fetches its own copy.  The grid is one-dimensional and padded to 8 x (blocks per split) x ceil(splits / 8):
+  // XCD k works through the splits k, k + 8, ..., the blocks of a split back to back on one L2 (1 - 3 MB of rows per split).
+  int kt_blk, co_blk, split;
+  {
+    const int nx = (p.Cout + 127) / 128, per = nx * ci_tiles * p.ntaps;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    split = p.xcd_order ? xcd + 8 * (j / per) : bid / per;
+    const int inner = p.xcd_order ? j % per : bid % per;
+    co_blk = inner % nx;
+    kt_blk = inner / nx;
+    if (split >= p.splits) return;                         // padding blocks (before any barrier)
+  }
   const int tap = kt_blk / ci_tiles, ci0 = (kt_blk % ci_tiles) * 128;
-  const int co0 = blockIdx.x * 128;
+  const int co0 = co_blk * 128;
   const int o0 = p.taps[tap * 3], o1 = p.taps[tap * 3 + 1], o2 = p.taps[tap * 3 + 2];
   const int D12 = p.D1 * p.D2;
   const int roff = o0 * D12 + o1 * p.D2 + o2;
   const bool shifted = (o0 | o1 | o2) != 0;
   const float rD2 = 1.f / (float)p.D2, rD1 = 1.f / (float)p.D1, rD0 = 1.f / (float)p.D0;
-  const int m_begin = blockIdx.z * p.rows_per_split;
+  const int m_begin = split * p.rows_per_split;
   const int m_end = min(m_begin + p.rows_per_split, p.M);
 
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -688,12 +701,37 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
   static const bool use128 = getenv("MMD_WGRAD_TILE64") == nullptr;      // A/B switch for tools/wgrad_bench.py
   if (use128 && dtype == MMD_BF16 && Cout >= 64 && Cin >= 64) {          // transposed-staging 128x128 kernel
     const int tiles = cdiv(Cout, 128) * cdiv(Cin, 128) * ntaps;
-    // blocks per launch: every split adds Cout*Cin*ntaps atomics on the same addresses, so pointwise convs (few tiles) get
-    // fewer, longer splits (measured: 512 blocks for 1x1, 1536 for 3-/9-tap convs; tools/wgrad_bench.py)
-    const int target = getenv("MMD_WGRAD_BLOCKS") ? atoi(getenv("MMD_WGRAD_BLOCKS")) : (torch_layout ? 512 : (ntaps > 1 ? 1536 : 512));
-    int splits = max(1, min(cdiv(M, 256), target / max(tiles, 1)));
-    p.rows_per_split = cdiv(cdiv(M, splits), 64) * 64;
-    splits = cdiv(M, p.rows_per_split);
+    // Row splits per launch.  Every split adds Cout * Cin * ntaps atomics on the same addresses; the blocks of a split share its rows of dY / X.
+    // Round 6 (XCD-aware block order in wgrad_tr_bf16_kernel: a split count that is a multiple of 8 gives every XCD whole splits, the blocks of
+    // a split back to back on ONE L2; other counts run in plain grid order): the candidates are what the block targets 256 ... 2048 give, and
+    // the choice is a three-term cost fitted to a sweep of the training shapes (profiles/r06_wgrad_xcd_order.txt: it picks the measured best
+    // or within 3 % of it on all 13): rounds of blocks on the 64 (per XCD) / 512 (chip) block slots x (rows per split + 300) + 40 x splits.
+    // MMD_WGRAD_BLOCKS: one fixed target (the sweep).
+    auto derive = [&](int target, int& sp, int& rps, int& xo) {
+      sp = max(1, min(cdiv(M, 256), target / max(tiles, 1)));
+      rps = cdiv(cdiv(M, sp), 64) * 64;
+      sp = cdiv(M, rps);
+      xo = 0;
+      for (int s8 = sp / 8 * 8; s8 >= 8; s8 -= 8) {
+        const int r = cdiv(cdiv(M, s8), 64) * 64;
+        if (cdiv(M, r) % 8 == 0) { rps = r; sp = cdiv(M, r); xo = 1; break; }
+      }
+    };
+    int splits = 1, xo = 0;
+    p.rows_per_split = M;
+    {
+      static const int env_target = getenv("MMD_WGRAD_BLOCKS") ? atoi(getenv("MMD_WGRAD_BLOCKS")) : 0;
+      static const int targets[] = {256, 384, 512, 768, 1024, 1536, 2048};
+      int64_t best = -1;
+      for (int t : targets) {
+        int sp, rps, x;
+        derive(env_target > 0 ? env_target : t, sp, rps, x);
+        const int64_t rounds = x ? cdiv((int64_t)tiles * (sp / 8), 64) : cdiv((int64_t)tiles * sp, 512);
+        const int64_t cost = rounds * (rps + 300) + 40 * (int64_t)sp;
+        if (best < 0 || cost < best) { best = cost; splits = sp; p.rows_per_split = rps; xo = x; }
+      }
+    }
+    p.xcd_order = xo;
     // DMA-staged kernel (round 3; MMD_WGRAD_TR=0: the transposed-staging kernel): 32-bit byte offsets, float-reciprocal row positions
     static const bool use_tr = [] { const char* e = getenv("MMD_WGRAD_TR"); return !(e && e[0] == '0'); }();
     // measured (tools/wgrad_bench.py, batch 8): 3x3 ds1 128->128 436 -> 372 us, ds2 256->256 405 -> 251, ds4 384->384 240 -> 180, ds8 130 -> 110;
@@ -710,7 +748,8 @@ extern "C" int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const voi
         attr_set = true;
       }
       p.db = db;                                                 // column sums ride in the (tap 0, ci tile 0) blocks: no colsum launch
-      hipLaunchKernelGGL(wgrad_tr_bf16_kernel, dim3(cdiv(Cout, 128), cdiv(Cin, 128) * ntaps, splits), dim3(256), lds, st, p);
+      p.splits = splits;
+      hipLaunchKernelGGL(wgrad_tr_bf16_kernel, dim3(p.xcd_order ? 8 * tiles * cdiv(splits, 8) : tiles * splits), dim3(256), lds, st, p);
       return mmd_check_launch("conv_wgrad");
     } else {
       p.db = db;                                                 // column sums ride in the (tap 0, ci tile 0) blocks: no colsum launch
