@@ -76,6 +76,26 @@ __device__ __forceinline__ u32x4 tr_frag(const char* tr, int row, int kt, int st
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
 
+// XCD-aware block order (round 6; the forward kernels' attn_block_coords, mmd_attn.hip): workgroups are dealt round-robin to the eight XCDs
+// by flat id and blockIdx.x (the query / key tile) is the fastest index, so the tiles of one (head, batch-group) land on eight different L2s
+// and each fetches the same K / V (dQ) or Q / dO (dK, dV) rows again.  Remapped so that all tiles of a (head, batch-group) share flat id % 8
+// and are adjacent in dispatch order.  Returns (tile, head, blockIdx.z-equivalent).
+__device__ __forceinline__ void bm_block_coords(int& tile, int& h, int& z) {
+  const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+  int hz;
+  if (((ny * nz) & 7) == 0 && nx > 1) {
+    const int f = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int k = f >> 3, r = f & 7;
+    tile = k % nx;
+    hz = r + 8 * (k / nx);
+  } else {
+    tile = blockIdx.x;
+    hz = blockIdx.y + ny * blockIdx.z;
+  }
+  h = hz % ny;
+  z = hz / ny;
+}
+
 // ============================================================================= dQ
 template <int D>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq_mfma_kernel(const AttnBwdMParams p) {
@@ -86,10 +106,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq_mfma_kerne
   char* sKt = smem + 128 * SK;              // [DT*32][TSTRIDE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y;
-  const int n = blockIdx.z / p.G, g = blockIdx.z % p.G;
+  int qtile, h, bz;
+  bm_block_coords(qtile, h, bz);
+  const int n = bz / p.G, g = bz % p.G;
   const int qcount = bm_qcount(p, g);
-  const int q0 = blockIdx.x * 128;
+  const int q0 = qtile * 128;
   if (q0 >= qcount) return;
   const int64_t q_row0 = (int64_t)n * p.q_rows_per_batch + (int64_t)g * p.q_per_group;
   const int64_t k_row0 = (int64_t)n * p.k_rows_per_batch;
@@ -220,9 +241,10 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkv_mfma_kern
   float* sD = sLse + 64;                             // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y, n = blockIdx.z;
+  int ktile, h, n;
+  bm_block_coords(ktile, h, n);
   const int k_mod = (int)p.k_rows_per_batch, kcount = p.win * p.k_per_group;
-  const int k0 = blockIdx.x * 128;
+  const int k0 = ktile * 128;
   if (k0 >= k_mod) return;
   const int kidx = k0 + wave * 32 + l31;
   const bool kok = kidx < k_mod;

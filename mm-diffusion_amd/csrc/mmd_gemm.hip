@@ -108,9 +108,6 @@ __device__ __forceinline__ void epilogue_stats(const ConvGemmParams& p, float (&
 // s_waitcnt vmcnt(N) (a load under a divergent branch forces vmcnt(0) and serialises the pipeline).
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) uint32_t g_zero_row[32] = {};      // 128 bytes: one K plane of a padding row (strip kernel)
-// where the strip kernel's rows past M store (never read): its stores are unconditional - a store behind a divergent branch costs
-// the straight-line epilogue its exact wait counts (the compiler re-waits, vmcnt(0), for loads 'pending' on the skipped path)
-__device__ __attribute__((aligned(16))) char g_store_sink[32768];
 
 
 template <typename T> struct Mma;
@@ -1386,10 +1383,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_halo16_kernel(const ConvGemm
 // compiler knows, and it copies the registers (operand matching, loop edges) before the wait - measured: wrong results, a fault when the
 // destination was dead.  So the pieces live in registers the compiler never allocates: the kernels with a residual are limited to 248 VGPRs
 // (amdgpu_num_vgpr) and v[248:255] belong to these two statements; the second waits and unpacks into ordinary outputs.
-#define STRIP_RES_LOAD(J2, ptr)                                                                                              \
+#define STRIP_RES_LOAD(J2, off, base)                                                                                        \
   do {                                                                                                                       \
-    if ((J2) == 0) asm volatile("global_load_dwordx4 v[248:251], %0, off" :: "v"(ptr) : "v248", "v249", "v250", "v251");      \
-    else asm volatile("global_load_dwordx4 v[252:255], %0, off" :: "v"(ptr) : "v252", "v253", "v254", "v255");                \
+    if ((J2) == 0) asm volatile("global_load_dwordx4 v[248:251], %0, %1" :: "v"(off), "s"(base) : "v248", "v249", "v250", "v251");  \
+    else asm volatile("global_load_dwordx4 v[252:255], %0, %1" :: "v"(off), "s"(base) : "v252", "v253", "v254", "v255");       \
   } while (0)
 #define STRIP_RES_UNPACK_ASM(A, B, C, D)                                                                                     \
   "s_waitcnt vmcnt(%8)\n\tv_lshlrev_b32 %0, 16, " A "\n\tv_and_b32 %1, 0xffff0000, " A "\n\tv_lshlrev_b32 %2, 16, " B "\n\tv_and_b32 %3, 0xffff0000, " B \
@@ -1473,14 +1470,18 @@ __device__ __forceinline__ void conv1x1_strip_body(const ConvGemmParams& p, cons
   // the strip's activations: fragment f, k-step cg = 8 channels [16 cg + 8 half, +8) of row l31 - the B operand of the MFMA
   int rowc[RF];
   bool rok[RF];
-  char* yrow[RF];
+  uint32_t yoff[RF], roff[RF];                            // byte offset of the lane's row (+ its half's 16 bytes) in Y / R: < 4 GB (dispatch)
   u32x4 xa[RF][NCG];
 #pragma unroll
   for (int f = 0; f < RF; ++f) {
     const int row = m0 + wave * (32 * RF) + f * 32 + l31;   // m0 + BR may pass M by less than one block: no overflow (M < 2^31 - 256)
     rok[f] = row < p.M;
-    rowc[f] = rok[f] ? row : p.M - 1;                    // tail rows read a valid row and store to the sink
-    yrow[f] = rok[f] ? p.Y + (int64_t)row * p.ldy * 2 : g_store_sink;
+    // rows past M compute row M - 1 once more - same operands, same bits - and STORE it there as well: the stores are unconditional (a
+    // store behind a divergent branch costs the straight-line epilogue its exact wait counts: the compiler re-waits, vmcnt(0), for loads
+    // 'pending' on the skipped path); uniform base + 32-bit lane offset: no per-lane 64-bit address arithmetic
+    rowc[f] = rok[f] ? row : p.M - 1;
+    yoff[f] = (uint32_t)rowc[f] * (uint32_t)(p.ldy * 2) + 16 * half;
+    roff[f] = (uint32_t)rowc[f] * (uint32_t)(p.ldr * 2) + 16 * half;
     if (p.ntaps == 1) {                                  // block-uniform
       const char* ap = p.A + ((int64_t)rowc[f] * p.lda + half * 8) * 2;
 #pragma unroll
@@ -1585,14 +1586,11 @@ __device__ __forceinline__ void conv1x1_strip_body(const ConvGemmParams& p, cons
     static_assert(!HR || RF == 1, "two residual pieces in v[248:255]");
     float erf[8];                                        // the unit's residual piece, unpacked
     float keep[2][2][2];                                 // [block parity][j2][sum | sum of squares] of the last epilogue's records
-    const char* rrow[RF];
     if constexpr (HR) {
 #pragma unroll
-      for (int f = 0; f < RF; ++f) {
-        rrow[f] = p.R + ((int64_t)rowc[f] * p.ldr + cbase + 8 * half) * 2;
+      for (int f = 0; f < RF; ++f)
 #pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2) STRIP_RES_LOAD(j2, rrow[f] + 32 * j2);
-      }
+        for (int j2 = 0; j2 < 2; ++j2) STRIP_RES_LOAD(j2, roff[f], p.R + (int64_t)(cbase + 16 * j2) * 2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (sub-tile 0's residual: complete before the loop, its waits below are then no-ops)
     }
     // one MFMA of sub-tile s_: index i = (pl * 4 + c) * RF + f; the weight fragment of k-step (pl, c) is read PF k-steps ahead
@@ -1652,8 +1650,8 @@ __device__ __forceinline__ void conv1x1_strip_body(const ConvGemmParams& p, cons
           }
         } else if (k == 4) {
           epk = Elt<__bf16>::pack(ev);
-          *(u32x4*)(yrow[f] + (cbase + cb + 16 * j2 + 8 * half) * 2) = epk;
-          if (HR && !last) STRIP_RES_LOAD(j2, rrow[f] + (cb + 32) * 2 + 32 * j2);
+          *(u32x4*)(p.Y + (int64_t)(cbase + cb + 16 * j2) * 2 + yoff[f]) = epk;
+          if (HR && !last) STRIP_RES_LOAD(j2, roff[f], p.R + (int64_t)(cbase + cb + 32 + 16 * j2) * 2);
         } else {                                         // statistics of the values as STORED: word q = values 2 q, 2 q + 1 of the lane's two quads
           const int q = k - 5;
           const float r0 = __uint_as_float(epk[q] << 16), r1 = __uint_as_float(epk[q] & 0xffff0000u);
@@ -1783,7 +1781,10 @@ __device__ __forceinline__ void conv1x1_strip_body(const ConvGemmParams& p, cons
         for (int f = 0; f < RF; ++f)
 #pragma unroll
           for (int j2 = 0; j2 < 2; ++j2)
-            rres[f][j2] = *(const u32x4*)(p.R + ((int64_t)rowc[f] * p.ldr + cbase + cb + 16 * j2 + 8 * half) * 2);
+            rres[f][j2] = *(const u32x4*)(p.R + (int64_t)(cbase + cb + 16 * j2) * 2 + roff[f]);
+        // (the requests stay in FRONT of the MFMAs: without the branch that used to sit here the scheduler sinks them to their first use -
+        // request, vmcnt(0), use - to save the registers: + 4 % on the ds1 out conv)
+        __builtin_amdgcn_sched_barrier(0);
       }
       f32x16 acc[RF];
 #pragma unroll
@@ -1828,7 +1829,7 @@ __device__ __forceinline__ void conv1x1_strip_body(const ConvGemmParams& p, cons
           }
           const u32x4 pk = Elt<__bf16>::pack(v);
           if (DEFER && a == NA - 1) outv[f][j2] = pk;
-          else *(u32x4*)(yrow[f] + col * 2) = pk;
+          else *(u32x4*)(p.Y + (int64_t)(cbase + cb + 16 * j2) * 2 + yoff[f]) = pk;
           if (STM != 0) {                                // statistics of the values as STORED: the lane's 8 channels = two QUADS
             float rf[8];
             Elt<__bf16>::unpack(pk, rf);
@@ -1871,7 +1872,7 @@ __device__ __forceinline__ void conv1x1_strip_body(const ConvGemmParams& p, cons
       const int col = cbase + ci * CC + (NA - 1) * 32 + 16 * j2 + 8 * half;
 #pragma unroll
       for (int f = 0; f < RF; ++f)
-        *(u32x4*)(yrow[f] + col * 2) = outv[f][j2];
+        *(u32x4*)(p.Y + (int64_t)(cbase + ci * CC + (NA - 1) * 32 + 16 * j2) * 2 + yoff[f]) = outv[f][j2];
       if (RF == 1) {
         if (STM == 1 && wave_ok && (wave & 1) == 0 && (l31 >> 1) == 8) {
           const float* o = sRec + ((((ci & 1) * 4 + wave + 1) * (NA * 2) + (NA - 1) * 2 + j2) * 2 + half) * 4 + (l31 & 1) * 2;
@@ -1956,7 +1957,8 @@ static int launch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
 static int dispatch_conv1x1_strip(const ConvGemmParams& p, hipStream_t st) {
   const int K = p.Cin * p.ntaps;
   const int rf = K <= 256 ? 2 : 1, cc = K <= 256 ? 64 : 32;
-  if ((K != 128 && K != 256 && K != 384 && K != 512) || p.Cin % 64 != 0 || p.Cout % cc != 0 || p.Cout > 16384 || (p.gn_a && (p.ntaps != 1 || p.gn_rows < 128 * rf)) ||
+  if ((K != 128 && K != 256 && K != 384 && K != 512) || p.Cin % 64 != 0 || p.Cout % cc != 0 ||
+      (int64_t)p.M * p.ldy * 2 >= 0xffffffffLL || (p.R && (int64_t)p.M * p.ldr * 2 >= 0xffffffffLL) || (p.gn_a && (p.ntaps != 1 || p.gn_rows < 128 * rf)) ||
       (p.ntaps == 1 && (p.taps[0] || p.taps[1] || p.taps[2])))
     return mmd_set_error(MMD_ERR_UNSUPPORTED, "conv_gemm tile 131 (strip): needs ntaps * Cin in {128, 256, 384, 512}, Cin %% 64 == 0, Cout %% %d == 0, "
                          "fused GroupNorm only for 1x1 convs with slices of >= %d rows (got Cin=%d ntaps=%d Cout=%d)", cc, 128 * rf, p.Cin, p.ntaps, p.Cout);
