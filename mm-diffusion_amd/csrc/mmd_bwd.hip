@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const char* __restri
         float dv = fd[e];
         if (act) {
           const float v = fx[e] * av[e] + bv[e];
-          const float sg = 1.f / (1.f + __expf(-v));
+          const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v));      // v_rcp_f32 (1 ulp), like silu_f of the forward: the IEEE division is ~10 more VALU instructions per element
           dv *= sg * (1.f + v * (1.f - sg));
         }
         P[e] += dv;
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const char* __restric
       float dv = fd[e];
       if (act) {
         const float v = fx[e] * av[e] + bv[e];
-        const float sg = 1.f / (1.f + __expf(-v));
+        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v));      // v_rcp_f32 (1 ulp), like silu_f of the forward: the IEEE division is ~10 more VALU instructions per element
         dv *= sg * (1.f + v * (1.f - sg));
       }
       out[e] = k1[e] * dv + k2[e] * fx[e] + k3[e];
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void silu_kernel(const char* __restrict__ x, c
     if (dy) Elt<T>::unpack(((const u32x4*)dy)[i], d);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      const float sg = 1.f / (1.f + __expf(-f[e]));
+      const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-f[e]));
       f[e] = dy ? d[e] * sg * (1.f + f[e] * (1.f - sg)) : f[e] * sg;
     }
     ((u32x4*)out)[i] = Elt<T>::pack(f);
