@@ -225,3 +225,40 @@ def test_strip_k128_one_fragment_instance_matches_the_two_fragment_one(tmp_path)
     assert torch.allclose(outs["0"]["rec"], outs["1"]["rec"], rtol=1e-5, atol=1e-3)
     yq = outs["1"]["y"].float().reshape(-1, 64, 32, 4)
     assert torch.allclose(outs["1"]["rec"][..., 0], yq.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("N,L,Cin,Cout,taps_kind", [
+    (16, 6400, 256, 384, "1x1"),          # 102400 rows, 6 tiles: XCD-aware order (a multiple of 8 row splits), several co / ci tiles
+    (8, 25600, 128, 128, "audio4"),       # 204800 rows, 3 taps of one tile: shifted rows with zero padding at every sample's ends
+    (3, 1600, 384, 256, "audio4"),        # 4800 rows: fewer than 8 splits - the plain grid order
+    (5, 12800, 128, 256, "1x1"),          # 64000 rows (not a multiple of the chunk grid), ragged last split
+])
+def test_wgrad_block_orders_match_torch(N, L, Cin, Cout, taps_kind):
+    """mmd_conv_wgrad (wgrad_tr_bf16_kernel) in its XCD-aware block order (round 6: the blocks of a row split on one XCD, split counts from a
+    cost model) and in the plain order it falls back to, against an fp64 torch reference of dW = dY^T gather(X) and db = colsum(dY) - every
+    (co tile, ci tile, tap, split) must be covered exactly once whatever the order."""
+    from mm_diffusion import ops
+    M = N * L
+    g = torch.Generator(device="cuda").manual_seed(M + Cin)
+    x = torch.randn(M, Cin, device="cuda", generator=g).to(torch.bfloat16)
+    dy = torch.randn(M, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    taps = ops.TAPS_1 if taps_kind == "1x1" else ops.taps_audio(4)
+    dims = (1, 1, 1) if taps_kind == "1x1" else (L, 1, 1)
+    dW = torch.zeros(Cout, Cin * len(taps), device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    ops.conv_wgrad(dy, x, dW, db, taps, dims)
+    xd, dyd = x.double(), dy.double()
+    ref = []
+    for (o0, _, _) in taps:
+        xs = torch.zeros_like(xd)
+        pos = torch.arange(M, device="cuda") % L if taps_kind != "1x1" else None
+        if o0 == 0:
+            xs = xd
+        else:
+            ok = (pos + o0 >= 0) & (pos + o0 < L)
+            src = (torch.arange(M, device="cuda") + o0).clamp(0, M - 1)
+            xs = torch.where(ok[:, None], xd[src], torch.zeros_like(xd))
+        ref.append(dyd.t() @ xs)
+    ref = torch.cat(ref, dim=1)
+    assert float((dW.double() - ref).norm() / ref.norm()) < 2e-6          # fp32 accumulation of exact bf16 products, atomics in any order
+    assert float((db.double() - dyd.sum(0)).norm() / dyd.sum(0).norm()) < 2e-6
