@@ -262,3 +262,47 @@ def test_wgrad_block_orders_match_torch(N, L, Cin, Cout, taps_kind):
     ref = torch.cat(ref, dim=1)
     assert float((dW.double() - ref).norm() / ref.norm()) < 2e-6          # fp32 accumulation of exact bf16 products, atomics in any order
     assert float((db.double() - dyd.sum(0)).norm() / dyd.sum(0).norm()) < 2e-6
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_strip_pipeline_random_shapes(seed):
+    """The software-pipelined row-strip instances (K = 256 without a residual, K = 384 / 512 with and without) on random shapes: odd and even
+    numbers of 32-column sub-tiles, one sub-tile per block (deep column splits of few rows), ragged last row blocks, residual, fused
+    GroupNorm (+ SiLU), statistics records - Y bitwise against the tiled kernels (tile 129; gn_apply + tile 129 for the fused norm), the
+    records against an fp64 reduction of the stored values."""
+    import random
+    from mm_diffusion import ops
+    rnd = random.Random(1000 + seed)
+    K = rnd.choice([256, 384, 512, 384, 512])
+    cc = 64 if K == 256 else 32
+    Cout = cc * rnd.randint(1, 20 if K == 256 else 40)
+    gn = rnd.random() < 0.5
+    stats = rnd.random() < 0.5
+    res = rnd.random() < 0.6
+    if gn:
+        S, Tn = rnd.randint(1, 5), 256 * rnd.randint(1, 12)
+        M = S * Tn
+    else:
+        M = 64 * rnd.randint(1, 300) if stats else rnd.randint(33, 20000)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = (torch.randn(M, K, device="cuda", generator=g) * 1.2 + 0.1).to(torch.bfloat16)
+    w = (torch.randn(Cout, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(M, Cout, device="cuda", generator=g).to(torch.bfloat16) if res else None
+    rec = torch.full((M // 64, Cout // 4, 2), 3.0, device="cuda") if stats else None
+    y = torch.full((M, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    if gn:
+        act = rnd.random() < 0.5
+        gamma, beta = 1 + 0.1 * torch.randn(K, device="cuda", generator=g), torch.randn(K, device="cuda", generator=g)
+        geom = ops.Geom.per_sample(S, Tn)
+        ga, gb = ops.gn_stats(x, gamma, beta, geom)
+        ops.gn_conv1x1(x, ga, gb, geom, act, w, b, residual=r, tile=131, out=y, stats=rec)
+        ref = ops.conv_gemm(ops.gn_apply(x, ga, gb, geom, act=act), w, b, residual=r, tile=129)
+    else:
+        ops.conv_gemm(x, w, b, residual=r, tile=131, out=y, stats=rec)
+        ref = ops.conv_gemm(x, w, b, residual=r, tile=129)
+    assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), (K, Cout, M, gn, stats, res)
+    if stats:
+        yf = y.double().view(M // 64, 64, Cout // 4, 4)
+        want = torch.stack([yf.sum((1, 3)), (yf * yf).sum((1, 3))], dim=-1)
+        assert float((rec.double() - want).abs().max() / want.abs().max()) < 2e-6, (K, Cout, M, gn, res)
