@@ -51,15 +51,16 @@ __device__ __forceinline__ uint32_t vc_pack2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, t);
 }
 
-template <int GNM>                                           // 0: plain conv, 1: fused input affine, 2: affine + SiLU
+template <int GNM, bool R2>                                  // GNM 0: plain conv, 1: fused input affine, 2: affine + SiLU; R2: two-slot weight ring
 __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) {
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   constexpr bool GN = GNM != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                                   // phase 1: [2 stages][576 rows][64 B]; phase 2: T [2 planes][288 rows][128 B]
-  char* sW = smem + 2 * VC_STAGE_B;                  // [3 slots][24 KB]
-  float* sGN = (float*)(smem + 2 * VC_STAGE_B + 3 * VC_WSLOT_B);   // [2 chunk parities][a (32) | b (32)]
+  constexpr int NSLOT = R2 ? 2 : 3;
+  char* sW = smem + 2 * VC_STAGE_B;                  // [NSLOT slots][24 KB]
+  float* sGN = (float*)(smem + 2 * VC_STAGE_B + NSLOT * VC_WSLOT_B);   // [2 chunk parities][a (32) | b (32)]
   float* sBias = sGN + 128;                          // [bias_s (128) | bias_t (128)]
   char* sDummy = (char*)(sBias + 256);               // 256 B: target of the DMA instructions that only keep the per-step count static
 
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int wc = wave & 1, wr = wave >> 1;
   int half = lane >> 5, l31 = lane & 31;
+  int par = 0;                                       // two-slot ring: the slot of the current patch's step 0
 
   // Persistent blocks (one per CU, grid = min(patches, CUs)): block b walks the patches L = b, b + grid, ... in the XCD-aware order
   // (consecutive patches - sharing halos - stay on one L2; L and b share their XCD while grid % 8 == 0).  While a patch's last two
@@ -214,10 +216,27 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   //   last chunk: J = 0 weights (3); J = 1 / J = 2 the temporal steps 0 / 1 (2 each)       tops: vmcnt(3), vmcnt(2), (temporal) vmcnt(2)
   // Norm slots (GN): 0, 1, 2 of the next stage in twelve quarters over the sub-steps of J = 1 and J = 2 (their pieces landed with
   // the top of J = 1), slots 3 (, 4) of THIS stage at J = 0 (rows hh 4..5: landed with this step's top wait, not read by the dh = -1 taps).
+  // Two-slot ring (R2: 121.75 KB of LDS instead of 145.75, so that a K = 128 row-strip / elementwise workgroup of another launch queue fits
+  // beside this one on the CU): the weights of step s + 1 go out FIRST in step s (into the slot step s - 1 left at this step's barrier;
+  // slot of a patch's step g = (par + g) & 1, par flips per patch when the step count is odd), the halo pieces behind them:
+  //   J = 0: weights of step s + 1 (3), then halo rows hh 0..3 of chunk c + 1 (3)          top of J = 1: vmcnt(3) - the weights landed
+  //   J = 1: weights of step s + 1 (3), halo rows hh 4..5 of chunk c + 1 (2)               top of J = 2: vmcnt(2)
+  //   J = 2: weights of step s + 1 (3), affine rows of chunk c + 2 (GN: 1)                 top of J = 0: vmcnt(GN)
+  //   last chunk: J = 0 / 1 weights (3); J = 2 temporal step 0 (2)                         tops: vmcnt(0)
+  // Norm slots (GN): a wave normalises only rows of its OWN DMA pieces (slot i = piece wave + 8 i), so slot 0 of the next stage starts in
+  // the middle of J = 1 behind a counted wait of this wave alone (vmcnt(2): the two weight pieces issued in front of it stay in flight),
+  // slots 1, 2 during J = 2 (two halves + four quarters), slots 3 (, 4) of THIS stage at J = 0 as before.
   auto spatial = [&](auto jtag, auto mtag, int c) {
     constexpr int J = decltype(jtag)::value;
     constexpr bool MORE = decltype(mtag)::value;
-    if constexpr (J == 0) {
+    if constexpr (R2) {
+      if constexpr (J == 0) {
+        if constexpr (GN) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if constexpr (!MORE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else if constexpr (J == 0) {
       if constexpr (GN) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     } else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
@@ -225,9 +244,22 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // ... for every wave; every wave is past its fragment reads of the previous step
     asm volatile("" ::: "memory");
-    const int s1n = c * 3 + J + 2;                         // the spatial step whose weights go out now (slot (J + 2) % 3: the previous step left it)
+    const int s1n = c * 3 + J + (R2 ? 1 : 2);              // the spatial step whose weights go out now (3-slot ring: slot (J + 2) % 3, the previous step left it)
+    const int slot_n = (par + c * 3 + J + 1) & 1;          // R2: its slot; this step reads slot_n ^ 1
     auto dma = [&](int k) {
-      if constexpr (J == 0 && MORE) {
+      if constexpr (R2) {
+        // this wave's halo pieces of chunk c + 1 (slot 0's rows among them) before its norm starts behind MFMA group 2: two weight pieces are
+        // newer (placed in FRONT of the third so that a reordering of the two statements could only over-wait)
+        if constexpr (GN && J == 1 && MORE) { if (k == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        if constexpr (J == 2 && !MORE) {
+          if (k < 2) issue_wt(slot_n, 0, k);
+        } else {
+          if (k < 3) issue_ws(slot_n, s1n, k);
+          else if constexpr (J == 0 && MORE) issue_h((c + 1) & 1, c + 1, k - 3);
+          else if constexpr (J == 1 && MORE) { if (k < 5) issue_h((c + 1) & 1, c + 1, k); }
+          else if constexpr (J == 2 && MORE) { if (GN && k == 3) { if (c + 2 < nchunk) issue_gn(c + 2); else dma_dummy(); } }
+        }
+      } else if constexpr (J == 0 && MORE) {
         if (k < 3) issue_h((c + 1) & 1, c + 1, k); else issue_ws(2, s1n, k - 3);
       } else if constexpr (J == 0) {
         if (k < 3) issue_ws(2, s1n, k);
@@ -249,12 +281,19 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
       if constexpr (J == 0) {                              // slot 3 in quarters (k = 0..3), slot 4 in halves (k = 4, 5; waves 0-3)
         if (k < 4) tr_piece(tstage, 3, k, 1);
         else if (wave < 4) tr_piece(tstage, 4, 2 * (k - 4), 2);
+      } else if constexpr (R2) {
+        if constexpr (J == 1) {                            // slot 0 in quarters over k = 2..5, behind this wave's own wait for its halo pieces (in dma(2))
+          if (k >= 2) tr_piece(tstage, 0, k - 2, 1);
+        } else {                                           // slot 1 in halves (k = 0, 1), slot 2 in quarters (k = 2..5)
+          if (k < 2) tr_piece(tstage, 1, 2 * k, 2);
+          else tr_piece(tstage, 2, k - 2, 1);
+        }
       } else {                                             // slots 0, 1, 2 in twelve quarters over the twelve sub-steps of J = 1, 2
         const int qq = (J - 1) * 6 + k;
         tr_piece(tstage, qq >> 2, qq & 3, 1);
       }
     };
-    const char* bW = sW + J * VC_WSLOT_B + wl1;            // ring slot of step 3 c + J = J
+    const char* bW = sW + (R2 ? slot_n ^ 1 : J) * VC_WSLOT_B + wl1;   // 3-slot ring: slot of step 3 c + J = J
     const char* bA[2];
     const int key = (ph + J) & 3;                          // halo rows hh = ph + 1 + dh
     const char* st = sA + (c & 1) * VC_STAGE_B + (J - 1) * (96 * 64) - 64;   // tap (dh, dw = -1)
@@ -306,8 +345,10 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   issue_first_halo();
 #pragma unroll
   for (int i = 0; i < 3; ++i) issue_ws(0, 0, i);
+  if constexpr (!R2) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) issue_ws(1, 1, i);
+    for (int i = 0; i < 3; ++i) issue_ws(1, 1, i);
+  }
 
   for (;;) {
   // Every lane / wave constant goes through an opaque copy once per patch: what is derived from them (fragment, slot and store
@@ -386,12 +427,15 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
   auto temporal = [&](auto stag) {
     constexpr int S2 = decltype(stag)::value;
     // the newest group in flight: the weights of step S2 + 1 (two pieces) - behind step 4 the first slab of the NEXT patch (three)
-    if constexpr (S2 < 5) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    // (two-slot ring: the only group in flight is this step's own weights)
+    if constexpr (R2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (S2 < 5) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     constexpr int tap = S2 >> 1, plane = S2 & 1;
-    const char* bW = sW + (S2 % 3) * VC_WSLOT_B + wl2;
+    const int slot_t = (par + nchunk + S2) & 1;              // R2: 3 nchunk spatial steps came first
+    const char* bW = sW + (R2 ? slot_t : S2 % 3) * VC_WSLOT_B + wl2;
     const char* bT = sA + plane * VC_TPLANE_B + tl2 + (tap - 1) * 2048;
     u32x4 fw[4][2], fa[4][2];
     auto rd = [&](int k) {
@@ -408,7 +452,13 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[k][a]), __builtin_bit_cast(bf16x8, fa[k][b]), acc[a][b], 0, 0, 0);
     };
     auto dma = [&](int k) {
-      if constexpr (S2 + 2 < 6) {
+      if constexpr (R2) {
+        if constexpr (S2 < 5) {
+          if (k < 2) issue_wt(slot_t ^ 1, S2 + 1, k);
+        } else {                                              // step 5: spatial slab 0 of the next patch (its slot 0 = this step's other slot)
+          if (has_next) issue_ws(slot_t ^ 1, 0, k); else dma_dummy();
+        }
+      } else if constexpr (S2 + 2 < 6) {
         if (k < 2) issue_wt((S2 + 2) % 3, S2 + 2, k);
       } else {                                              // steps 4 / 5: spatial slabs 0 / 1 of the next patch into slots 0 / 1 (three pieces)
         if (has_next) issue_ws(S2 - 4, S2 - 4, k); else dma_dummy();
@@ -485,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void vconv2d1d_kernel(const VConvParams p) 
     }
   if (!has_next) break;
   L += (int)gridDim.x;
+  par = (par + nchunk) & 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // trailing dummies
 }
@@ -550,22 +601,32 @@ extern "C" int mmd_vconv2d1d(const void* X, int64_t ldx, const float* gn_a, cons
   p.bias_s = bias_s; p.bias_t = bias_t; p.Y = (char*)Y; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin;
   p.gn_a = gn_a; p.gn_b = gn_b; p.gn_act = act; p.gn_S = S; p.gn_rows = rows_per_slice;
   p.stats = stats; p.stats_ld = stats_ld;
-  const size_t lds = 2 * VC_STAGE_B + 3 * VC_WSLOT_B + 512 + 1024 + 256;
+  // MMD_VCONV_RING=2 selects the two-slot weight ring (121.75 KB of LDS instead of 145.75: a K = 128 row-strip or elementwise workgroup of
+  // another launch queue fits beside it; weights one step ahead).  Bitwise equal, measured (profiles/r06_vconv_two_slot_ring.txt): the
+  // kernel alone + 1 ... 3 %, the step unchanged (11.09 vs 11.04 ms, three alternating runs each) - with 2 x 200 of a SIMD's 512 VGPRs
+  // held by this kernel's two waves only kernels of <= 112 VGPRs can join, LDS or not.  Default: three slots.
+  const char* ring_env = getenv("MMD_VCONV_RING");           // read per call (a launch plan is recorded once): tests flip it in-process
+  const bool ring2 = ring_env && atoi(ring_env) == 2;
+  const size_t lds = 2 * VC_STAGE_B + (ring2 ? 2 : 3) * VC_WSLOT_B + 512 + 1024 + 256;
   static bool attr_done[MMD_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mmd_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vconv2d1d_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vconv2d1d_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vconv2d1d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "vconv2d1d: set LDS attr: %s", hipGetErrorString(e));
+    const void* fns[6] = {(const void*)vconv2d1d_kernel<0, false>, (const void*)vconv2d1d_kernel<1, false>, (const void*)vconv2d1d_kernel<2, false>,
+                          (const void*)vconv2d1d_kernel<0, true>,  (const void*)vconv2d1d_kernel<1, true>,  (const void*)vconv2d1d_kernel<2, true>};
+    for (int i = 0; i < 6; ++i) {
+      const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * VC_STAGE_B + (i < 3 ? 3 : 2) * VC_WSLOT_B + 512 + 1024 + 256));
+      if (e != hipSuccess) return mmd_set_error(MMD_ERR_LAUNCH, "vconv2d1d: set LDS attr: %s", hipGetErrorString(e));
+    }
     attr_set = true;
   }
   int ncu = 0;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, mmd_device_slot()) != hipSuccess || ncu <= 0) ncu = 256;
   const int total = N * (H / 4) * (W / 4);
   const int grid = total < ncu ? total : ncu;               // persistent blocks, one per CU
-  if (!gn_a) hipLaunchKernelGGL(vconv2d1d_kernel<0>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
-  else if (act) hipLaunchKernelGGL(vconv2d1d_kernel<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(vconv2d1d_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  const int gnm = !gn_a ? 0 : (act ? 2 : 1);
+#define VC_LAUNCH(G, R) hipLaunchKernelGGL((vconv2d1d_kernel<G, R>), dim3(grid), dim3(512), lds, (hipStream_t)stream, p)
+  if (ring2) { if (gnm == 0) VC_LAUNCH(0, true); else if (gnm == 1) VC_LAUNCH(1, true); else VC_LAUNCH(2, true); }
+  else { if (gnm == 0) VC_LAUNCH(0, false); else if (gnm == 1) VC_LAUNCH(1, false); else VC_LAUNCH(2, false); }
+#undef VC_LAUNCH
   return mmd_check_launch("vconv2d1d");
 }

@@ -306,3 +306,36 @@ def test_strip_pipeline_random_shapes(seed):
         yf = y.double().view(M // 64, 64, Cout // 4, 4)
         want = torch.stack([yf.sum((1, 3)), (yf * yf).sum((1, 3))], dim=-1)
         assert float((rec.double() - want).abs().max() / want.abs().max()) < 2e-6, (K, Cout, M, gn, res)
+
+
+@pytest.mark.parametrize("gn", [None, "silu", "affine"])
+@pytest.mark.parametrize("N,H,W,Cin", [(1, 8, 8, 32), (2, 64, 72, 96), (1, 16, 16, 128), (3, 64, 64, 64), (1, 64, 64, 256), (4, 64, 64, 128), (2, 64, 64, 384)])
+def test_vconv_two_slot_ring_equals_three_slot_ring(gn, N, H, W, Cin):
+    """The fused VideoConv's two-slot weight ring (MMD_VCONV_RING=2, 121.75 KB of LDS, weights one step ahead, input norm re-timed) against the
+    three-slot ring (the default): output and statistics records bitwise equal - odd and even numbers of 32-channel chunks (the ring's
+    slot parity flips per patch when the step count is odd), one to nine patches per persistent block."""
+    import os
+    from mm_diffusion import ops
+    from test_vconv_gpu import make
+    x, ws, wt, bs, bt, a, b = make(N, H, W, Cin, seed=N * 1000 + Cin)
+    wf = ops.vconv_pack(ops.pack_conv_weight(ws.float(), torch.bfloat16), ops.pack_conv_weight(wt.float(), torch.bfloat16))
+    geom = ops.Geom.per_sample(N, 16 * H * W)
+    kw = {} if gn is None else dict(a=a, b=b, geom=geom, act=gn == "silu")
+    M = N * 16 * H * W
+    out = {}
+    old = os.environ.get("MMD_VCONV_RING")
+    try:
+        for ring in ("3", "2"):
+            os.environ["MMD_VCONV_RING"] = ring
+            rec = torch.full((M // 64, 32, 2), float("nan"), device="cuda")
+            y = ops.vconv2d1d(x, wf, bs, bt, N, 16, H, W, stats=rec, **kw)
+            torch.cuda.synchronize()
+            out[ring] = (y, rec)
+    finally:
+        if old is None:
+            os.environ.pop("MMD_VCONV_RING", None)
+        else:
+            os.environ["MMD_VCONV_RING"] = old
+    assert torch.isfinite(out["2"][0].float()).all()
+    assert torch.equal(out["2"][0].view(torch.int16), out["3"][0].view(torch.int16))
+    assert torch.equal(out["2"][1], out["3"][1])
