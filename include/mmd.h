@@ -118,6 +118,15 @@ int mmd_gn_conv1x1(int dtype, const void* A, int64_t lda, const float* gn_a, con
 int mmd_gn_small(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int S, int Tn, int inner, int64_t outer_stride,
                  int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, float eps, int act, void* stream);
 
+/* GroupNorm32(+FiLM)(+SiLU) of slices of a few hundred rows in ONE launch (nn.py:16-33; FiLM unet:457-470): one block per (group, slice),
+ * the group's Tn x C / 32 elements register-resident (Tn * C / 128 <= 4096), exact two-pass fp32 statistics.  Writes the fused affine
+ * a_out / b_out [S, C] (nullable pair: as mmd_gn_stats), the normalised tensor y (nullable: as mmd_gn_apply; act: 0 none, 1 SiLU), or
+ * both = mmd_gn_stats (two launches on multi-block slices) + mmd_gn_apply for the slices whose rows are no multiple of the 64-row
+ * producer records (the 400-row audio samples at ds8).  Geometry, film, mr_out as mmd_gn_stats; C % 128 == 0. */
+int mmd_gn_group(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int S, int Tn, int inner, int64_t outer_stride,
+                 int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, const float* film, int64_t film_ld,
+                 float eps, int act, float* a_out, float* b_out, float* mr_out, void* stream);
+
 /* hipMemsetAsync(ptr, 0, bytes) on the stream (a memset node of a captured plan). */
 int mmd_zero(void* ptr, int64_t bytes, void* stream);
 

@@ -549,6 +549,129 @@ extern "C" int mmd_gn_finalize_stats(const float* rec, int64_t rec_ld, int C, in
   return mmd_check_launch("gn_finalize_stats");
 }
 
+// ---- GroupNorm32(+FiLM)(+SiLU) of slices of a few hundred rows in ONE launch: block = one (group, slice), its Tn x cpg elements stay in
+// registers (at most 16 quads of 4 channels per thread), exact two-pass statistics (mean, then centred squares) in fp32 with fixed-order
+// block reductions, then either only the fused affine (a, b) - the consumer is a GEMM that normalises in its loader - or the
+// normalised tensor too.  For slices whose rows are not a multiple of the 64-row producer records (the 400-row audio samples at ds8:
+// mmd_gn_stats there is a partial launch + a finalize launch, then mmd_gn_apply).  The apply step is gn_apply's arithmetic.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_group_kernel(const char* __restrict__ x, int64_t ldx, char* __restrict__ y, int64_t ldy, int C,
+                                                       SliceGeom g, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ film, int64_t film_ld, float eps, int act,
+                                                       float* __restrict__ a_out, float* __restrict__ b_out, float* __restrict__ mr_out) {
+  constexpr int ES = sizeof(T), MAXI = 16;
+  __shared__ float s_red[2][4];
+  __shared__ float s_ab[2][64];
+  const int gi = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / GN_GROUPS, qpg = cpg / 4, items = g.Tn * qpg;
+  const int64_t base = slice_base(g, s);
+  const char* xg = x + (int64_t)gi * cpg * ES;
+  float f[MAXI][4];
+#pragma unroll
+  for (int j = 0; j < MAXI; ++j) {
+    const int i = tid + 256 * j;
+    if (i < items) {
+      const int r = i / qpg, k = i - r * qpg;
+      const char* q = xg + ((base + (int64_t)r * g.tstride) * ldx + 4 * k) * ES;
+      if constexpr (ES == 2) {
+        const u32x2 v = *(const u32x2*)q;
+        f[j][0] = __uint_as_float(v[0] << 16); f[j][1] = __uint_as_float(v[0] & 0xffff0000u);
+        f[j][2] = __uint_as_float(v[1] << 16); f[j][3] = __uint_as_float(v[1] & 0xffff0000u);
+      } else {
+        const f32x4 v = *(const f32x4*)q;
+        f[j][0] = v[0]; f[j][1] = v[1]; f[j][2] = v[2]; f[j][3] = v[3];
+      }
+    } else {
+      f[j][0] = f[j][1] = f[j][2] = f[j][3] = 0.f;
+    }
+  }
+  auto block_sum = [&](float v, int slot) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) s_red[slot][tid >> 6] = v;
+    __syncthreads();
+    return (s_red[slot][0] + s_red[slot][1]) + (s_red[slot][2] + s_red[slot][3]);
+  };
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXI; ++j) t += (f[j][0] + f[j][1]) + (f[j][2] + f[j][3]);
+  const float inv_cnt = 1.f / ((float)g.Tn * (float)cpg);
+  const float mean = block_sum(t, 0) * inv_cnt;
+  t = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXI; ++j)
+    if (tid + 256 * j < items) {
+      const float d0 = f[j][0] - mean, d1 = f[j][1] - mean, d2 = f[j][2] - mean, d3 = f[j][3] - mean;
+      t += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  const float var = block_sum(t, 1) * inv_cnt;
+  const float rstd = (float)(1.0 / sqrt((double)var + (double)eps));
+  if (tid < cpg) {
+    const int c = gi * cpg + tid;
+    float av = rstd * gamma[c];
+    float bv = beta[c] - mean * av;
+    if (film) {
+      const float sc = 1.f + film[(int64_t)s * film_ld + c];
+      av *= sc;
+      bv = bv * sc + film[(int64_t)s * film_ld + C + c];
+    }
+    if (a_out) {
+      a_out[(int64_t)s * C + c] = av;
+      b_out[(int64_t)s * C + c] = bv;
+    }
+    s_ab[0][tid] = av;
+    s_ab[1][tid] = bv;
+    if (mr_out && tid == 0) {
+      mr_out[((int64_t)s * GN_GROUPS + gi) * 2] = mean;
+      mr_out[((int64_t)s * GN_GROUPS + gi) * 2 + 1] = rstd;
+    }
+  }
+  if (!y) return;                                            // block-uniform
+  __syncthreads();
+  char* yg = y + (int64_t)gi * cpg * ES;
+#pragma unroll
+  for (int j = 0; j < MAXI; ++j) {
+    const int i = tid + 256 * j;
+    if (i < items) {
+      const int r = i / qpg, k = i - r * qpg;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w = f[j][e] * s_ab[0][4 * k + e] + s_ab[1][4 * k + e];
+        o[e] = act ? silu_f(w) : w;
+      }
+      char* q = yg + ((base + (int64_t)r * g.tstride) * ldy + 4 * k) * ES;
+      if constexpr (ES == 2) {
+        bf16x4 pk = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+        *(u32x2*)q = __builtin_bit_cast(u32x2, pk);
+      } else {
+        *(f32x4*)q = f32x4{o[0], o[1], o[2], o[3]};
+      }
+    }
+  }
+}
+
+extern "C" int mmd_gn_group(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int C, int S, int Tn, int inner, int64_t outer_stride,
+                            int64_t inner_stride, int64_t tstride, const float* gamma, const float* beta, const float* film, int64_t film_ld,
+                            float eps, int act, float* a_out, float* b_out, float* mr_out, void* stream) {
+  int rc = check_geom("gn_group", dtype, C, S, Tn, inner);
+  if (rc) return rc;
+  MMD_REQUIRE(x && gamma && beta && (y || a_out), "gn_group: null pointer (needs y or a_out / b_out)");
+  MMD_REQUIRE((a_out == nullptr) == (b_out == nullptr), "gn_group: a_out and b_out come together");
+  MMD_REQUIRE(C % 128 == 0 && C <= 2048, "gn_group: groups of whole channel quads, at most 2048 channels (C = %d)", C);
+  MMD_REQUIRE((int64_t)Tn * (C / 128) <= 4096, "gn_group: a (group, slice) of %d rows x %d channels does not fit one block's registers", Tn, C / 32);
+  const int eb = dtype == MMD_BF16 ? 2 : 4;
+  MMD_REQUIRE(((uintptr_t)x) % 16 == 0 && ldx % 4 == 0 && (!y || (((uintptr_t)y) % 16 == 0 && ldy % 4 == 0)), "gn_group: rows must be aligned to channel quads");
+  (void)eb;
+  SliceGeom g{S, Tn, inner, outer_stride, inner_stride, tstride};
+  if (dtype == MMD_BF16)
+    hipLaunchKernelGGL(gn_group_kernel<__bf16>, dim3(GN_GROUPS, S), dim3(256), 0, (hipStream_t)stream, (const char*)x, ldx, (char*)y, ldy, C, g, gamma,
+                       beta, film, film_ld, eps, act, a_out, b_out, mr_out);
+  else
+    hipLaunchKernelGGL(gn_group_kernel<float>, dim3(GN_GROUPS, S), dim3(256), 0, (hipStream_t)stream, (const char*)x, ldx, (char*)y, ldy, C, g, gamma,
+                       beta, film, film_ld, eps, act, a_out, b_out, mr_out);
+  return mmd_check_launch("gn_group");
+}
+
 extern "C" int mmd_gn_apply(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int S, int Tn,
                             int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
                             const float* b, int act, void* stream) {

@@ -37,6 +37,7 @@ _PROTOS = {
     "mmd_gn_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "mmd_gn_stats": (i32, [i32, vp, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, i64, f32, vp, vp, vp, vp, vp]),
     "mmd_gn_small": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, f32, i32, vp]),
+    "mmd_gn_group": (i32, [i32, vp, i64, vp, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, i64, f32, i32, vp, vp, vp, vp]),
     "mmd_gn_apply": (i32, [i32, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, i32, vp]),
     "mmd_add_rowbias": (i32, [i32, vp, i64, i64, i32, i64, vp, i64, vp]),
     "mmd_colsum_slices": (i32, [i32, vp, i64, i32, i64, i32, vp, i64, vp]),

@@ -225,6 +225,10 @@ class UNetEngine:
             # short slices (the temporal-attention norm: 16 frames of a pixel): one launch, one read of the tensor
             y = self._alloc(x.shape[0], C) if out is None else out
             return ops.gn_small(x, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), geom, act=act, out=y)
+        if ops.gn_group_ok(x, geom) and self._rec_ready(x, geom) is None:
+            # no producer records and a (group, slice) fits one block: statistics + apply in ONE launch (was partial | finalize | apply)
+            y = self._alloc(x.shape[0], C) if out is None else out
+            return ops.gn_group(x, self._f32(prefix + ".GroupNorm.weight"), self._f32(prefix + ".GroupNorm.bias"), geom, film=film, out=y, act=act)
         a, b = self._gn_affine(x, prefix, geom, film)
         y = self._alloc(x.shape[0], C) if out is None else out
         ops.gn_apply(x, a, b, geom, act=act, out=y)
@@ -241,6 +245,8 @@ class UNetEngine:
         rec = self._rec_ready(x, geom)
         if rec is not None:
             ops.gn_finalize_stats(rec, gamma, beta, geom, film=film, a=a, b=b)
+        elif ops.gn_group_ok(x, geom):
+            ops.gn_group(x, gamma, beta, geom, film=film, a=a, b=b)        # one launch (gn_stats: partial | finalize on multi-block slices)
         else:
             ws = self._alloc(ops.gn_workspace_bytes(x, geom) // 8, 1, torch.float64)
             ops.gn_stats(x, gamma, beta, geom, film=film, a=a, b=b, ws=ws)

@@ -198,6 +198,34 @@ def gn_small(x, gamma, beta, geom: Geom, act=False, out=None):
     return out
 
 
+# One-launch GroupNorm for slices of a few hundred rows (mmd_gn_group): used where a norm has NO producer-side records to finalize from
+# and its (group, slice) fits a block's registers - the 400-row audio samples at ds8 (400 % 64 != 0: gn_stats there is a partial
+# launch + a finalize launch, then gn_apply).  MMD_GN_GROUP=0 switches it off (A/B).
+_GN_GROUP = os.environ.get("MMD_GN_GROUP", "1") != "0"
+
+
+def gn_group_ok(x, geom: Geom):
+    C = x.shape[1]
+    return _GN_GROUP and C % 128 == 0 and C <= 2048 and geom.Tn * (C // 128) <= 4096 and x.stride(0) % 4 == 0
+
+
+def gn_group(x, gamma, beta, geom: Geom, film=None, a=None, b=None, out=None, act=False, mr=None):
+    """GroupNorm32(+FiLM)(+SiLU) in one launch (include/mmd.h: mmd_gn_group): the fused affine into a / b (both or neither), the
+    normalised tensor into out (or neither: then a / b are allocated) - gn_stats (+ gn_apply) for short slices."""
+    _chk2d(x)
+    C = x.shape[1]
+    if out is None and a is None:
+        a = alloc(geom.S, C, dtype=torch.float32, device=x.device)
+        b = alloc(geom.S, C, dtype=torch.float32, device=x.device)
+    if out is not None:
+        _chk2d(out)
+    _dispatch("mmd_gn_group", H.dt_of(x), x.data_ptr(), x.stride(0), H.ptr(out), 0 if out is None else out.stride(0), C, *geom.args(),
+              gamma.data_ptr(), beta.data_ptr(), H.ptr(film), 0 if film is None else film.stride(0), GN_EPS, 1 if act else 0,
+              H.ptr(a), H.ptr(b), H.ptr(mr),
+              meta=(f"gn_group[S={geom.S},Tn={geom.Tn},C={C}]", 0, (1 if out is None else 2) * geom.S * geom.Tn * C * x.element_size()))
+    return (a, b) if out is None else out
+
+
 def add_rowbias(x, e, rows_per_sample):
     _chk2d(x)
     _dispatch("mmd_add_rowbias", H.dt_of(x), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], rows_per_sample,

@@ -339,3 +339,44 @@ def test_vconv_two_slot_ring_equals_three_slot_ring(gn, N, H, W, Cin):
     assert torch.isfinite(out["2"][0].float()).all()
     assert torch.equal(out["2"][0].view(torch.int16), out["3"][0].view(torch.int16))
     assert torch.equal(out["2"][1], out["3"][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("S,Tn,C,pad,film,act", [(4, 400, 512, 0, False, True), (2, 400, 1024, 0, True, True), (2, 400, 896, 128, True, False),
+                                                  (3, 1024, 512, 0, False, True), (2, 100, 2048, 0, False, False), (5, 37, 128, 0, True, True),
+                                                  (1, 1600, 256, 64, False, True)])
+def test_gn_group_one_launch(dtype, S, Tn, C, pad, film, act):
+    """mmd_gn_group (GroupNorm32 (+FiLM) (+SiLU) of a few hundred rows per slice in one launch) against an fp64 torch GroupNorm of the
+    same slices, its affine against mmd_gn_stats', and its apply step bitwise against mmd_gn_apply fed with its own affine."""
+    from mm_diffusion import ops
+    g = torch.Generator(device="cuda").manual_seed(S * 1000 + Tn + C)
+    M = S * Tn
+    buf = (torch.randn(M, C + pad, device="cuda", generator=g) * 1.5 + 0.7).to(dtype)
+    x = buf[:, :C]
+    gamma = 1 + 0.2 * torch.randn(C, device="cuda", generator=g)
+    beta = 0.3 * torch.randn(C, device="cuda", generator=g)
+    fl = 0.3 * torch.randn(S, 2 * C, device="cuda", generator=g) if film else None
+    geom = ops.Geom.per_sample(S, Tn)
+    assert ops.gn_group_ok(x, geom)
+    a = torch.full((S, C), float("nan"), device="cuda")
+    b = torch.full((S, C), float("nan"), device="cuda")
+    y = torch.full((M, C), float("nan"), device="cuda", dtype=dtype)
+    ops.gn_group(x, gamma, beta, geom, film=fl, a=a, b=b, out=y, act=act)
+    a2, b2 = ops.gn_group(x, gamma, beta, geom, film=fl)                      # affine only
+    y3 = ops.gn_group(x, gamma, beta, geom, film=fl, out=torch.empty_like(y), act=act)   # tensor only
+    assert torch.equal(a, a2) and torch.equal(b, b2) and torch.equal(y, y3)
+    xd = x.double().view(S, Tn, 32, C // 32)
+    mean = xd.mean(dim=(1, 3), keepdim=True)
+    var = xd.var(dim=(1, 3), unbiased=False, keepdim=True)
+    ref = ((xd - mean) / torch.sqrt(var + 1e-5)).view(S, Tn, C) * gamma.double() + beta.double()
+    if film:
+        ref = ref * (1 + fl[:, None, :C].double()) + fl[:, None, C:].double()
+    if act:
+        ref = ref * torch.sigmoid(ref)
+    ref = ref.view(M, C)
+    err = float((y.double() - ref).norm() / ref.norm())
+    assert err < (4e-3 if dtype == torch.bfloat16 else 2e-6), err
+    a0, b0 = ops.gn_stats(x, gamma, beta, geom, film=fl)
+    assert float((a - a0).abs().max() / a0.abs().max()) < 2e-6 and float((b - b0).abs().max() / b0.abs().max()) < 1e-5
+    y1 = ops.gn_apply(x, a, b, geom, act=act)
+    assert torch.equal(y.view(torch.int16 if dtype == torch.bfloat16 else torch.int32), y1.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
