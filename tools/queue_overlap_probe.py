@@ -41,6 +41,7 @@ def cases():
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     side = [torch.cuda.Stream() for _ in range(4)]
+    keep = []          # graphs stay alive until the process ends (no graph / event destruction while anything may still replay)
     for name, fn in cases():
         for i in range(4):
             fn(i)
@@ -67,7 +68,7 @@ def main():
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
             line += f" | {chains} chain(s): {best * 1e6 / N:6.2f} us per launch"
-            del gr
+            keep.append((gr, cap))
         print(line, flush=True)
 
 
