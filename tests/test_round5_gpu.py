@@ -236,7 +236,9 @@ def test_round5_plan_switches_against_reference_fixture(tmp_path, cfg, keyset, t
         ea, eb, ab = rel_l2(a[k], ref), rel_l2(b[k], ref), rel_l2(a[k], b[k])
         print(f"{tag} bf16={bf16} {k}: on {ea:.3e} off {eb:.3e} on-vs-off {ab:.3e}")
         assert ea < bound and eb < bound
-        assert ab < (1.5e-2 if bf16 else 5e-6)
+        # bf16: the two plans are two independent roundings of the same network, each ~1.6e-2 from the fp32 reference on this small model,
+        # so they sit up to ~sqrt(2) x that apart (1.49e-2 ... 1.54e-2 measured, depending on which bitwise-different norm kernels a plan uses)
+        assert ab < (2.0e-2 if bf16 else 5e-6)
     assert int(a["nlaunch"]) < int(b["nlaunch"]) and int(a["nsync"]) < int(b["nsync"])
     na, nb = set(a["names"].tolist()), set(b["names"].tolist())
     if bf16:
