@@ -220,30 +220,37 @@ class GaussianDiffusion:
         return out
 
     # ------------------------------------------------------------------ p(x_{t-1} | x_t)
-    def _update(self, key, model_out, x, t, clip_denoised, noise=None, want=("sample",)):
-        """Run the fused update kernel for one stream; returns a dict with the requested outputs."""
+    def _update(self, key, model_out, x, t, clip_denoised, noise=None, want=("sample",), denoised_fn=None, start_x=False):
+        """Run the fused update kernel for one stream; returns a dict with the requested outputs.  denoised_fn (gd:263-268): the x_0
+        prediction goes through it BEFORE the clamp - one pass of the kernel for the unclamped prediction, the caller's function on that
+        tensor, then the kernel again with the processed tensor in the place of the model's mean channels, read as an x_0 prediction."""
+        if denoised_fn is not None:
+            raw = self._update(key, model_out, x, t, False, want=("pred_xstart",), start_x=start_x)["pred_xstart"]
+            x0 = denoised_fn(raw)
+            cd = 2 if x.dim() == 5 else 1
+            mo2 = model_out.float().clone()
+            mo2.narrow(cd, 0, x.shape[cd]).copy_(x0)
+            return self._update(key, mo2, x, t, clip_denoised, noise=noise, want=want, start_x=True)
         tab, _ = self.device_tables(x.device)
         F, C, HW = _geom(x)
         xs = x.float().contiguous()
         mo = model_out.float().contiguous()
         res = {k: th.empty_like(xs) for k in want}
         ops.ddpm_update(xs, mo, noise, res.get("sample"), tab, t.to(th.int64).contiguous(), F, C, HW,
-                        self._flags(clip_denoised), x0_out=res.get("pred_xstart"), mean_out=res.get("mean"),
+                        self._flags(clip_denoised) | (2 if start_x else 0), x0_out=res.get("pred_xstart"), mean_out=res.get("mean"),
                         logvar_out=res.get("log_variance"))
         return res
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         """gd:231-343.  Returns the same nested dict ({'mean','variance','log_variance','pred_xstart','model_predict'}
         each {'video','audio'})."""
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not supported by the fused update kernel")
         model_kwargs = model_kwargs or {}
         B = x["video"].shape[0]
         assert t.shape == (B,)
         video_output, audio_output = model(x["video"], x["audio"], self._scale_timesteps(t), **model_kwargs)
         out = {k: {} for k in ("mean", "variance", "log_variance", "pred_xstart", "model_predict")}
         for key, mo in (("video", video_output), ("audio", audio_output)):
-            r = self._update(key, mo, x[key], t, clip_denoised, want=("mean", "log_variance", "pred_xstart"))
+            r = self._update(key, mo, x[key], t, clip_denoised, want=("mean", "log_variance", "pred_xstart"), denoised_fn=denoised_fn)
             out["mean"][key], out["log_variance"][key], out["pred_xstart"][key] = r["mean"], r["log_variance"], r["pred_xstart"]
             out["variance"][key] = th.exp(r["log_variance"])
             out["model_predict"][key] = mo
@@ -252,9 +259,8 @@ class GaussianDiffusion:
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
         """One ancestral step (gd:415-474).  Like the reference, the `noise` argument is ignored and fresh N(0,1)
         noise is drawn for both streams (video first), also at t == 0."""
-        if cond_fn is not None or denoised_fn is not None:
-            raise NotImplementedError("cond_fn / denoised_fn: the reference's condition_mean raises for the multimodal dict "
-                                      "(gd:385 calls dict.float()); not built")
+        if cond_fn is not None:
+            raise NotImplementedError("cond_fn: the reference's condition_mean raises for the multimodal dict (gd:385 calls dict.float()); not built")
         model_kwargs = model_kwargs or {}
         video_output, audio_output = model(x["video"], x["audio"], self._scale_timesteps(t), **model_kwargs)
         noise = {"video": self._randn_like(x["video"]), "audio": self._randn_like(x["audio"])}
@@ -269,7 +275,7 @@ class GaussianDiffusion:
                 res["sample"][key], res["pred_start"][key] = s_, x0_
                 continue
             r = self._update(key, mo, x[key], t, clip_denoised, noise=noise[key].float().contiguous(),
-                             want=("sample", "pred_xstart"))
+                             want=("sample", "pred_xstart"), denoised_fn=denoised_fn)
             res["sample"][key], res["pred_start"][key] = r["sample"], r["pred_xstart"]
         return res
 
@@ -461,9 +467,10 @@ class GaussianDiffusion:
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, use_graph=True):
         """gd:523-582.  x_T is drawn on the CPU (video, then audio) and moved to the device like the reference;
-        every step then replays one captured hipGraph (U-Net plan + both fused updates)."""
-        if cond_fn is not None or denoised_fn is not None:
-            raise NotImplementedError("cond_fn / denoised_fn: see p_sample")
+        every step then replays one captured hipGraph (U-Net plan + both fused updates).  With a denoised_fn (a host callable on the x_0
+        prediction, gd:263-268) the steps are launched eagerly through p_sample."""
+        if cond_fn is not None:
+            raise NotImplementedError("cond_fn: see p_sample")
         device = self._sampling_device(device)
         video = th.randn(*shape["video"], device="cpu").to(device)
         audio = th.randn(*shape["audio"], device="cpu").to(device)
@@ -474,7 +481,7 @@ class GaussianDiffusion:
             indices = tqdm(indices)
         from .sampler import GraphStepper, unwrap_unet
         unet = unwrap_unet(model)
-        if use_graph and unet is not None and not (model_kwargs or {}):
+        if use_graph and unet is not None and not (model_kwargs or {}) and denoised_fn is None:
             stepper = GraphStepper(self, unet, shape["video"][0], device, clip_denoised)
             stepper.load(x["video"], x["audio"])
             try:
@@ -487,7 +494,7 @@ class GaussianDiffusion:
         for i in indices:
             t = th.tensor([i] * shape["video"][0], device=device)
             with th.no_grad():
-                out = self.p_sample(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+                out = self.p_sample(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
             yield out["sample"]
             x = out["sample"]
 

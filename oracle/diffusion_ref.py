@@ -106,8 +106,9 @@ def _ext(arr, t, ndim):
     return v.reshape(-1, *([1] * (ndim - 1)))
 
 
-def p_mean_variance(S: Schedule, out, x, t, cdim, clip=True):
-    """One stream of p_mean_variance: returns (mean, log_variance, pred_xstart)."""
+def p_mean_variance(S: Schedule, out, x, t, cdim, clip=True, denoised_fn=None):
+    """One stream of p_mean_variance: returns (mean, log_variance, pred_xstart).  denoised_fn (gd:263-268, process_xstart): applied to
+    the x_0 prediction BEFORE the clamp."""
     nd = x.dim()
     if S.learn_sigma:   # LEARNED_RANGE
         C = x.shape[cdim]
@@ -123,6 +124,8 @@ def p_mean_variance(S: Schedule, out, x, t, cdim, clip=True):
         x0 = out
     else:
         x0 = _ext(S.sqrt_recip_ac, t, nd) * x - _ext(S.sqrt_recipm1_ac, t, nd) * out
+    if denoised_fn is not None:
+        x0 = denoised_fn(x0)
     if clip:
         x0 = x0.clamp(-1, 1)
     mean = _ext(S.post_c1, t, nd) * x0 + _ext(S.post_c2, t, nd) * x

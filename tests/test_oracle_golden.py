@@ -301,3 +301,23 @@ def test_training_losses(tag, keyset, over):
     terms = dref.training_losses(S, model, x0, torch.from_numpy(g["t"]), noise)
     for k in ("loss", "mse_video", "mse_audio") + (("vb_video", "vb_audio") if over else ()):
         np.testing.assert_allclose(terms[k].numpy(), g[k], rtol=2e-4, atol=1e-6)
+
+
+def test_p_mean_variance_with_denoised_fn():
+    """oracle p_mean_variance(denoised_fn=...) against the reference's p_mean_variance / p_sample run with the same function on a stand-in
+    model (fixture pmv_denoised.npz, tools/gen_golden.py: gen_pmv_denoised): the function acts on the x_0 prediction BEFORE the clamp."""
+    g = gold("pmv_denoised")
+    S = dref.Schedule(respacing="10", learn_sigma=True)
+    t = torch.from_numpy(g["t"])
+    fn = lambda z: 0.5 * z + 0.1      # noqa: E731
+    for key, xk, ok, cdim in (("video", "xv", "vo", 2), ("audio", "xa", "ao", 1)):
+        x, o = torch.from_numpy(g[xk]), torch.from_numpy(g[ok])
+        for clip in (1, 0):
+            mean, logvar, x0 = dref.p_mean_variance(S, o, x, t, cdim, clip=bool(clip), denoised_fn=fn)
+            assert rel_l2(mean, g[f"mean_{key}_clip{clip}"]) < 1e-6
+            assert rel_l2(logvar, g[f"log_variance_{key}_clip{clip}"]) < 1e-6
+            assert rel_l2(x0, g[f"pred_xstart_{key}_clip{clip}"]) < 1e-6
+        mean, logvar, _ = dref.p_mean_variance(S, o, x, t, cdim, clip=True, denoised_fn=fn)
+        nz = (t != 0).float().reshape(-1, *([1] * (x.dim() - 1)))
+        noise = torch.from_numpy(g["noise_v" if key == "video" else "noise_a"])
+        assert rel_l2(mean + nz * torch.exp(0.5 * logvar) * noise, g[f"sample_{key}"]) < 1e-6

@@ -380,3 +380,32 @@ def test_gn_group_one_launch(dtype, S, Tn, C, pad, film, act):
     assert float((a - a0).abs().max() / a0.abs().max()) < 2e-6 and float((b - b0).abs().max() / b0.abs().max()) < 1e-5
     y1 = ops.gn_apply(x, a, b, geom, act=act)
     assert torch.equal(y.view(torch.int16 if dtype == torch.bfloat16 else torch.int32), y1.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+
+
+def test_denoised_fn_in_p_mean_variance_and_p_sample():
+    """denoised_fn (reference gd:263-268: applied to the x_0 prediction before the clamp) through the fused update kernel - the unclamped
+    prediction, the caller's function, then the kernel again reading the processed tensor as an x_0 prediction - against the reference
+    fixture pmv_denoised.npz (p_mean_variance with clip on / off, p_sample with the fixture's noise)."""
+    import numpy as np
+    from helpers import gold, rel_l2
+    from mm_diffusion import multimodal_script_util as msu
+    g = gold("pmv_denoised")
+    f = msu.model_and_diffusion_defaults()
+    f.update(timestep_respacing="10", learn_sigma=True)
+    diff = msu.create_gaussian_diffusion(steps=f["diffusion_steps"], learn_sigma=True, noise_schedule=f["noise_schedule"],
+                                         timestep_respacing="10")
+    dev = torch.device("cuda")
+    x = {"video": torch.from_numpy(g["xv"]).to(dev), "audio": torch.from_numpy(g["xa"]).to(dev)}
+    vo, ao = torch.from_numpy(g["vo"]).to(dev), torch.from_numpy(g["ao"]).to(dev)
+    t = torch.from_numpy(g["t"]).to(dev)
+    model = lambda v, a, ts, **kw: (vo, ao)      # noqa: E731
+    fn = lambda z: 0.5 * z + 0.1                  # noqa: E731
+    for clip in (1, 0):
+        out = diff.p_mean_variance(model, x, t, clip_denoised=bool(clip), denoised_fn=fn)
+        for k in ("mean", "log_variance", "pred_xstart"):
+            for key in ("video", "audio"):
+                assert rel_l2(out[k][key].cpu(), g[f"{k}_{key}_clip{clip}"]) < 1e-6, (k, key, clip)
+    noise = iter([torch.from_numpy(g["noise_v"]).to(dev), torch.from_numpy(g["noise_a"]).to(dev)])
+    diff.noise_source = lambda like: next(noise)
+    ps = diff.p_sample(model, x, t, clip_denoised=True, denoised_fn=fn)
+    assert rel_l2(ps["sample"]["video"].cpu(), g["sample_video"]) < 1e-6 and rel_l2(ps["sample"]["audio"].cpu(), g["sample_audio"]) < 1e-6

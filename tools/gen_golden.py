@@ -439,7 +439,34 @@ def gen_helpers():
          eps_from_xstart=diff._predict_eps_from_xstart(a, t, b))
 
 
+def gen_pmv_denoised():
+    """p_mean_variance / p_sample of the reference (gd:231-343, 415-474) with a denoised_fn (x -> 0.5 x + 0.1, applied before the clamp) on a
+    stand-in model that returns fixed random outputs: learned-range variance, respacing 10, clip on and off."""
+    f = flags("tiny", timestep_respacing="10", learn_sigma=True)
+    _, diff = msu.create_model_and_diffusion(**f)
+    g = th.Generator().manual_seed(91)
+    B = 3
+    x = {"video": th.randn(B, 4, 3, 6, 6, generator=g), "audio": th.randn(B, 1, 40, generator=g)}
+    vo, ao = th.randn(B, 4, 6, 6, 6, generator=g), th.randn(B, 2, 40, generator=g)
+    t = th.tensor([9, 0, 4])
+    model = lambda v, a, ts, **kw: (vo, ao)      # noqa: E731
+    fn = lambda z: 0.5 * z + 0.1                  # noqa: E731
+    arrs = dict(xv=x["video"], xa=x["audio"], vo=vo, ao=ao, t=t)
+    for clip in (True, False):
+        out = diff.p_mean_variance(model, x, t, clip_denoised=clip, denoised_fn=fn)
+        for k in ("mean", "log_variance", "pred_xstart"):
+            for key in ("video", "audio"):
+                arrs[f"{k}_{key}_clip{int(clip)}"] = out[k][key]
+    th.manual_seed(92)
+    ps = diff.p_sample(model, x, t, clip_denoised=True, denoised_fn=fn)
+    th.manual_seed(92)
+    arrs["noise_v"], arrs["noise_a"] = th.randn_like(x["video"]), th.randn_like(x["audio"])
+    arrs["sample_video"], arrs["sample_audio"] = ps["sample"]["video"], ps["sample"]["audio"]
+    save("pmv_denoised", **arrs)
+
+
 ALL = {
+    "pmv_denoised": gen_pmv_denoised,
     "tables": gen_tables,
     "keys": gen_keys,
     "blocks": gen_blocks,
