@@ -448,6 +448,27 @@ def test_profile_summarisers_on_a_synthetic_trace(tmp_path):
     line = [ln for ln in txt.splitlines() if "conv1x1_strip_kernel<8, 1, 32, 0, 0> | 131072x1x1" in ln][0].split()
     assert float(line[0]) == 1.0 and float(line[2]) == 12.0 and float(line[3]) == 12.0          # one launch per step, 12 us average and minimum
     assert any("conv1x1_strip_kernel<8, 1, 32, 0, 0> | 65536x1x1" in ln for ln in txt.splitlines())   # the same kernel, another shape: its own row
+    # two batch lanes whose updates end 3 ms apart (round 6): the step is delimited by the noise draw, not by clustered update end times
+    rows2, t, did = [hdr], 1_000_000, 0
+    for step in range(5):
+        seq = [(1, "void at::native::(anonymous namespace)::distribution_elementwise_grid_stride_kernel<float, 4, normal>(long)", 524288, 5_000, 0),
+               (1, "void at::native::(anonymous namespace)::distribution_elementwise_grid_stride_kernel<float, 4, normal>(long)", 102400, 3_000, 0)]
+        for lane, q in ((0, 1), (1, 2)):
+            seq += [(q, "gn_finalize_rec_kernel(float const*, long)", 8192, 4_000, 0), (q, "ddpm_update_kernel(DdpmParams)", 4096, 2_000, 3_000_000 * lane)]
+        for q, name, grid, dur, wait in seq:
+            did += 1
+            t += wait
+            rows2.append(f'"KERNEL_DISPATCH","Agent 2",{q},0,1,{did},7,"{name}",{did},{t},{t + dur},0,0,64,0,32,256,1,1,{grid},1,1')
+            t += dur + 1_000
+        t += 500_000
+    trace2 = tmp_path / "kt2_kernel_trace.csv"
+    trace2.write_text("\n".join(rows2) + "\n")
+    out3 = tmp_path / "by_shape2.txt"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kt_by_shape.py"), str(trace2), str(out3), "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt2 = out3.read_text()
+    fin = [ln for ln in txt2.splitlines() if "gn_finalize_rec_kernel" in ln][0].split()
+    assert "last 3 replayed steps" in txt2 and float(fin[0]) == 2.0                          # both lanes' launches belong to ONE step
     # clock summary: 1.7 GHz x 8 XCCs x the dispatch's wall time in the counter
     pmc = tmp_path / "pmc"
     pmc.mkdir()

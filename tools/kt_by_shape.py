@@ -25,18 +25,27 @@ def main():
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), g(r, "Queue_Id"), r["Kernel_Name"],
                   "x".join(g(r, f"Grid_Size_{a}", g(r, f"Grid_Size{a}", "?")) for a in "XYZ"), g(r, "Workgroup_Size_X", g(r, "Workgroup_Size", "?")),
                   g(r, "LDS_Block_Size", g(r, "LDS_Block_Size_v", "?"))) for r in rows), key=lambda e: e[0])
-    marks = [e[1] for e in ev if "ddpm_update" in e[3]]
-    clusters = []
-    for t in sorted(marks):
-        if clusters and t - clusters[-1][-1] < 2_000_000:
-            clusters[-1].append(t)
-        else:
-            clusters.append([t])
-    ends = [c[-1] for c in clusters]
+    # step boundaries.  With batch lanes a step ends with one fused update per lane and chain, and under the profiler the lanes finish
+    # milliseconds apart (round 6: the old 2 ms clustering of the update kernels' end times cut every two-lane step in two - the tables of
+    # that round's first profile calls are per LANE-step).  The step's noise draw runs once per step on the origin stream before the lanes
+    # fork: the start of the larger of its two launches (torch's normal_ kernel) delimits the steps; without one, the old clustering.
+    noise = [e for e in ev if "at::native" in e[3] and ("normal" in e[3] or "distribution" in e[3])]
+    if noise:
+        big = max(int(e[4].split("x")[0]) if e[4].split("x")[0].isdigit() else 0 for e in noise)
+        ends = sorted(e[0] for e in noise if e[4].split("x")[0].isdigit() and int(e[4].split("x")[0]) == big)
+    else:
+        marks = [e[1] for e in ev if "ddpm_update" in e[3]]
+        clusters = []
+        for t in sorted(marks):
+            if clusters and t - clusters[-1][-1] < 2_000_000:
+                clusters[-1].append(t)
+            else:
+                clusters.append([t])
+        ends = [c[-1] for c in clusters]
     if len(ends) < steps + 1:
         steps = max(1, len(ends) - 1)
     t0, t1 = ends[-steps - 1], ends[-1]
-    sel = [e for e in ev if t0 < e[0] and e[1] <= t1]
+    sel = [e for e in ev if t0 <= e[0] and e[0] < t1]
     wall = (t1 - t0) / steps / 1e3
     agg = defaultdict(list)
     for s, e, q, name, grid, wg, lds in sel:

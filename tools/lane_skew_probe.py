@@ -59,6 +59,12 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e3 / K
 
+    def alone(r):
+        for _ in range(K):
+            H.call("mmd_graph_launch", st.graphs[r], streams[r])
+
+    for r in range(lanes):
+        print(f"lane {r} ALONE (its graph replayed K times, the other lane idle): {min(timed(alone, r) for _ in range(2)):.3f} ms per lane-step", flush=True)
     base = min(timed(joined) for _ in range(2))
     print(f"K = {K} steps, {lanes} lanes; joined (product schedule, inputs frozen): {base:.3f} ms per step", flush=True)
     for rep in range(3):
