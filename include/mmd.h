@@ -293,10 +293,12 @@ int mmd_loss_terms(const float* x0, const float* xt, const float* model_out, con
 int mmd_conv_wgrad(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, float* db, int M, int Cout, int Cin,
                    int ntaps, const int* taps, int D0, int D1, int D2, int torch_layout, void* stream);
 /* Re-pack every conv weight in ONE launch after an optimizer step.  descs_dev: device array of n records
- *   { const float* src; void* fwd; void* bwd; int Cout, Cin, nt; int block_start; }   (block_start = running sum of ceil(Cout*Cin*nt / 2048))
+ *   { const float* src; void* fwd; void* bwd; int Cout, Cin, nt; int block_start; }   (block_start = running sum of mmd_pack_blocks(Cout, Cin, nt):
+ *   one workgroup per tile of 32 output x (216 / nt) input channels x all taps, staged through LDS so that both operands are written in runs; nt <= 27)
  * src fp32 [Cout][Cin][nt] (torch conv layout) -> fwd [Cout][nt*Cin] (mmd_conv_gemm operand of the forward conv) and
  * bwd [Cin][nt*Cout] (operand of the data-gradient conv), both in `dtype`.  mmd_conv_wgrad with torch_layout = 1 accumulates
  * dW directly in [Cout][Cin][nt], i.e. straight into the parameter's .grad. */
+int mmd_pack_blocks(int Cout, int Cin, int nt);     /* workgroups of one record (-1: unsupported tap count) */
 int mmd_pack_conv_weights(int dtype, const void* descs_dev, int n, int total_blocks, void* stream);
 /* Gradient counterpart, once per step: for every record (same struct; src = the parameter's fp32 .grad [Cout][Cin][nt], fwd = an
  * fp32 packed accumulation buffer [Cout][nt*Cin] that mmd_conv_wgrad filled with coalesced atomics) grad += packed, packed = 0. */

@@ -888,49 +888,106 @@ extern "C" int mmd_adamw_step(float* p, const float* g, float* m, float* v, floa
 struct PackDesc {
   const float* src; void* fwd; void* bwd;
   int Cout, Cin, nt;
-  int block_start;                 // first block of this weight; blocks cover 2048 source elements each
+  int block_start;                 // first block of this weight; a block covers a tile of 32 output x 16 input channels x all taps
 };
+// Round 6: tiles through LDS.  The first version walked 2048 consecutive source elements per block and stored each one twice with 2-byte
+// stores Cin / Cout elements apart, behind a nine-deep dependent binary search of the descriptor table per block (2.07 ms per step for
+// the 133 M parameters = 0.39 TB/s of traffic that should take 0.2 ms).  A tile of 32 co x (216 / nt) ci x nt taps is read as 32 contiguous
+// runs, then written as runs of consecutive ci per (co, tap) into the forward operand and runs of 32 consecutive co per (ci, tap) into
+// the data-gradient operand; no integer division in the loops; the descriptor of a block is found by ONE parallel pass over the table.
+#define PK_CO 32
+#define PK_ROW 216
+#define PK_NT_MAX 27
+__host__ __device__ __forceinline__ int pack_ci_tile(int nt) { const int c = PK_ROW / nt; return c >= 16 ? (c & ~15) : c; }
+__device__ __forceinline__ PackDesc pack_find(const PackDesc* __restrict__ descs, int n, int* s_cnt) {
+  if (threadIdx.x == 0) *s_cnt = 0;
+  __syncthreads();
+  int local = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) local += descs[i].block_start <= (int)blockIdx.x ? 1 : 0;   // block_start ascends
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(s_cnt, local);
+  __syncthreads();
+  return descs[*s_cnt - 1];
+}
+struct PackTile { int co0, ci0, nco, nci, nt, run; };
+__device__ __forceinline__ PackTile pack_tile(const PackDesc& d) {
+  const int ct = pack_ci_tile(d.nt);
+  const int tiles_ci = (d.Cin + ct - 1) / ct;
+  const int tb = (int)blockIdx.x - d.block_start;
+  PackTile t;
+  t.co0 = (tb / tiles_ci) * PK_CO;
+  t.ci0 = (tb % tiles_ci) * ct;
+  t.nco = min(PK_CO, d.Cout - t.co0);
+  t.nci = min(ct, d.Cin - t.ci0);
+  t.nt = d.nt;
+  t.run = t.nci * d.nt;
+  return t;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ descs, int n) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {                // last descriptor whose block_start <= blockIdx.x
-    const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  __shared__ float sT[PK_CO][PK_ROW + 1];
+  __shared__ int s_cnt;
+  const PackDesc d = pack_find(descs, n, &s_cnt);
+  const PackTile t = pack_tile(d);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = wave; c < t.nco; c += 4) {
+    const float* sp = d.src + ((int64_t)(t.co0 + c) * d.Cin + t.ci0) * t.nt;
+    for (int r = lane; r < t.run; r += 64) sT[c][r] = sp[r];
   }
-  const PackDesc d = descs[lo];
-  const int64_t total = (int64_t)d.Cout * d.Cin * d.nt;
-  const int64_t e0 = (int64_t)((int)blockIdx.x - d.block_start) * 2048;
-  for (int64_t e = e0 + threadIdx.x; e < min(e0 + 2048, total); e += 256) {
-    const int tap = (int)(e % d.nt), ci = (int)((e / d.nt) % d.Cin), co = (int)(e / ((int64_t)d.nt * d.Cin));
-    const float v = d.src[e];
-    Elt<T>::st(d.fwd, (int64_t)co * d.nt * d.Cin + (int64_t)tap * d.Cin + ci, v);
-    Elt<T>::st(d.bwd, (int64_t)ci * d.nt * d.Cout + (int64_t)tap * d.Cout + co, v);
-  }
+  __syncthreads();
+  // forward operand [Cout][nt * Cin]: lanes along ci; a tile narrower than a wave (16 ci at nine taps) puts 64 / nci taps side by side
+  const int tstep = t.nci >= 64 ? 1 : 64 / t.nci, lt = lane / t.nci, lci = lane - lt * t.nci, cstep = tstep > 1 ? t.nci : 64;
+  if (lt < tstep)
+    for (int c = wave; c < t.nco; c += 4)
+      for (int tap = lt; tap < t.nt; tap += tstep) {
+        const int64_t base = (int64_t)(t.co0 + c) * t.nt * d.Cin + (int64_t)tap * d.Cin + t.ci0;
+        for (int ci = lci; ci < t.nci; ci += cstep) Elt<T>::st(d.fwd, base + ci, sT[c][ci * t.nt + tap]);
+      }
+  const int c = lane & 31, h = lane >> 5;                      // data-gradient operand [Cin][nt * Cout]: lanes along co, two taps per wave pass
+  if (c < t.nco)
+    for (int ci = wave; ci < t.nci; ci += 4)
+      for (int tap = h; tap < t.nt; tap += 2)
+        Elt<T>::st(d.bwd, (int64_t)(t.ci0 + ci) * t.nt * d.Cout + (int64_t)tap * d.Cout + t.co0 + c, sT[c][ci * t.nt + tap]);
 }
 // Reverse direction for the gradients: wgrad accumulates with COALESCED atomics in the packed layout [Cout][nt*Cin] (fp32, `fwd` of
 // the record); once per step this adds every packed gradient into the parameter's .grad ([Cout][Cin][nt], `src` of the record,
 // written here) and clears the packed buffer for the next step.  (Atomics straight into the torch layout are strided by nt
-// floats: 18 64-byte segments per wave instruction instead of 2.)
+// floats: 18 64-byte segments per wave instruction instead of 2.)  Same tiles as the weight pack: packed runs of consecutive ci per
+// (co, tap) in, .grad runs of nci x nt floats per co out.
 __global__ __launch_bounds__(256) void unpack_grads_kernel(const PackDesc* __restrict__ descs, int n) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const PackDesc d = descs[lo];
-  const int64_t total = (int64_t)d.Cout * d.Cin * d.nt;
-  const int64_t e0 = (int64_t)((int)blockIdx.x - d.block_start) * 2048;
+  __shared__ float sT[PK_CO][PK_ROW + 1];
+  __shared__ int s_cnt;
+  const PackDesc d = pack_find(descs, n, &s_cnt);
+  const PackTile t = pack_tile(d);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* grad = const_cast<float*>(d.src);
   float* packed = (float*)d.fwd;
-  for (int64_t e = e0 + threadIdx.x; e < min(e0 + 2048, total); e += 256) {      // e walks the PACKED layout (coalesced reads)
-    const int ci = (int)(e % d.Cin), tap = (int)((e / d.Cin) % d.nt), co = (int)(e / ((int64_t)d.nt * d.Cin));
-    const float v = packed[e];
-    packed[e] = 0.f;
-    grad[((int64_t)co * d.Cin + ci) * d.nt + tap] += v;
+  const int tstep = t.nci >= 64 ? 1 : 64 / t.nci, lt = lane / t.nci, lci = lane - lt * t.nci, cstep = tstep > 1 ? t.nci : 64;
+  if (lt < tstep)
+    for (int c = wave; c < t.nco; c += 4)
+      for (int tap = lt; tap < t.nt; tap += tstep) {
+        float* pp = packed + (int64_t)(t.co0 + c) * t.nt * d.Cin + (int64_t)tap * d.Cin + t.ci0;
+        for (int ci = lci; ci < t.nci; ci += cstep) {
+          sT[c][ci * t.nt + tap] = pp[ci];
+          pp[ci] = 0.f;
+        }
+      }
+  __syncthreads();
+  for (int c = wave; c < t.nco; c += 4) {
+    float* gp = grad + ((int64_t)(t.co0 + c) * d.Cin + t.ci0) * t.nt;
+    for (int r = lane; r < t.run; r += 64) gp[r] += sT[c][r];
   }
 }
+
+extern "C" int mmd_pack_blocks(int Cout, int Cin, int nt) {
+  if (Cout <= 0 || Cin <= 0 || nt <= 0 || nt > PK_NT_MAX) return -1;
+  const int ct = pack_ci_tile(nt);
+  return ((Cout + PK_CO - 1) / PK_CO) * ((Cin + ct - 1) / ct);
+}
+
 extern "C" int mmd_unpack_conv_grads(const void* descs_dev, int n, int total_blocks, void* stream) {
-  MMD_REQUIRE(descs_dev && n > 0 && total_blocks > 0, "unpack_conv_grads: bad argument");
+  MMD_REQUIRE(descs_dev && n > 0 && total_blocks > 0, "unpack_conv_grads: bad argument");      // (descriptors: at most 27 taps, mmd_pack_blocks blocks each)
   hipLaunchKernelGGL(unpack_grads_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n);
   return mmd_check_launch("unpack_conv_grads");
 }

@@ -92,6 +92,7 @@ _PROTOS = {
     "mmd_bilinear_concat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_bilinear_concat_rows": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "mmd_pack_conv_weights": (i32, [i32, vp, i32, i32, vp]),
+    "mmd_pack_blocks": (i32, [i32, i32, i32]),
     "mmd_unpack_conv_grads": (i32, [vp, i32, i32, vp]),
     "mmd_loss_terms_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     "mmd_silu": (i32, [i32, vp, vp, vp, i64, vp]),

@@ -16,6 +16,14 @@ class _PackDesc(ctypes.Structure):
                 ("nt", ctypes.c_int), ("block_start", ctypes.c_int)]
 
 
+def _pack_blocks(Cout, Cin, nt):
+    """Workgroups of one weight in mmd_pack_conv_weights / mmd_unpack_conv_grads (tiles of 32 x (216 / taps) channels x all taps)."""
+    n = H.lib().mmd_pack_blocks(int(Cout), int(Cin), int(nt))
+    if n <= 0:
+        raise H.MMDError(f"conv weight [{Cout}, {Cin}, {nt} taps]: more taps than the pack kernels stage")
+    return n
+
+
 class WeightPacker:
     """Keeps the GEMM-operand copies of every conv weight (forward [Cout, tap*Cin] and data-gradient [Cin, tap*Cout], in the
     activation dtype) current with ONE kernel launch per optimizer step (mmd_pack_conv_weights) and publishes them as
@@ -42,7 +50,7 @@ class WeightPacker:
             descs[i] = _PackDesc(p.data_ptr(), self.fwd.data_ptr() + off * es, self.bwd.data_ptr() + off * es, Cout, Cin, nt, blocks)
             p._mmd_packed = (self.fwd[off:off + p.numel()].view(Cout, nt * Cin), self.bwd[off:off + p.numel()].view(Cin, nt * Cout))
             off += p.numel()
-            blocks += (p.numel() + 2047) // 2048
+            blocks += _pack_blocks(Cout, Cin, nt)
         self.blocks = blocks
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
         self.descs = raw.to(dev)
@@ -57,7 +65,7 @@ class WeightPacker:
             gdescs[i] = _PackDesc(p.grad.data_ptr(), self.gpacked.data_ptr() + off * 4, None, Cout, Cin, nt, blocks)
             p._mmd_wgrad = self.gpacked[off:off + p.numel()].view(Cout, nt * Cin)
             off += p.numel()
-            blocks += (p.numel() + 2047) // 2048
+            blocks += _pack_blocks(Cout, Cin, nt)
         self.gdescs = torch.frombuffer(bytearray(bytes(gdescs)), dtype=torch.uint8).to(dev)
         # the same descriptors grouped by gradient bucket (block_start relative to the bucket's first block)
         self.bucket_descs = {}
@@ -68,7 +76,7 @@ class WeightPacker:
             for j, i in enumerate(idx):
                 d = gdescs[i]
                 sub[j] = _PackDesc(d.src, d.fwd, d.bwd, d.Cout, d.Cin, d.nt, blocks)
-                blocks += (d.Cout * d.Cin * d.nt + 2047) // 2048
+                blocks += _pack_blocks(d.Cout, d.Cin, d.nt)
             self.bucket_descs[bk] = (torch.frombuffer(bytearray(bytes(sub)), dtype=torch.uint8).to(dev), len(idx), blocks)
 
     def fold_grads(self, bucket=None):

@@ -409,3 +409,45 @@ def test_denoised_fn_in_p_mean_variance_and_p_sample():
     diff.noise_source = lambda like: next(noise)
     ps = diff.p_sample(model, x, t, clip_denoised=True, denoised_fn=fn)
     assert rel_l2(ps["sample"]["video"].cpu(), g["sample_video"]) < 1e-6 and rel_l2(ps["sample"]["audio"].cpu(), g["sample_audio"]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_weight_pack_and_grad_unpack_tiles(dtype):
+    """mmd_pack_conv_weights / mmd_unpack_conv_grads on LDS tiles (32 output x (216 / taps) input channels x all taps): every conv weight of a
+    mixed list - edge tiles, 1 / 3 / 9 / 27 taps, 1 and 3 input / output channels like the stems and heads - against torch permutes, the
+    packed gradient accumulators folded into .grad (+=) and cleared."""
+    from mm_diffusion.optim import WeightPacker
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(128, 3, 3, 3, 3), (3, 128, 3, 3, 3), (128, 1, 3), (2, 128, 3), (256, 384, 3, 3), (40, 24, 3), (512, 512, 1), (33, 17, 1, 3, 3), (384, 640, 3)]
+    params = []
+    for sh in shapes:
+        p = torch.randn(*sh, device="cuda", generator=g).requires_grad_(True)
+        p.grad = torch.randn(*sh, device="cuda", generator=g)
+        params.append(p)
+    bias = torch.randn(7, device="cuda").requires_grad_(True)          # not a conv weight: ignored by the packer
+    bias.grad = torch.zeros(7, device="cuda")
+    wp = WeightPacker(params + [bias], dtype)
+    for p in params:
+        Cout, Cin = p.shape[0], p.shape[1]
+        nt = p.numel() // (Cout * Cin)
+        w = p.detach().reshape(Cout, Cin, nt)
+        fwd, bwd = p._mmd_packed
+        assert torch.equal(fwd, w.permute(0, 2, 1).reshape(Cout, nt * Cin).to(dtype)), tuple(p.shape)
+        assert torch.equal(bwd, w.permute(1, 2, 0).reshape(Cin, nt * Cout).to(dtype)), tuple(p.shape)
+    want = []
+    for p in params:
+        Cout, Cin = p.shape[0], p.shape[1]
+        nt = p.numel() // (Cout * Cin)
+        acc = torch.randn(Cout, nt * Cin, device="cuda", generator=g)
+        p._mmd_wgrad.copy_(acc)
+        want.append(p.grad.clone() + acc.view(Cout, nt, Cin).permute(0, 2, 1).reshape(p.shape))
+    wp.fold_grads()
+    for p, w in zip(params, want):
+        assert torch.equal(p.grad, w), tuple(p.shape)
+        assert not p._mmd_wgrad.any()
+    # a weight changed in place is re-packed by refresh()
+    with torch.no_grad():
+        params[4].mul_(0.5)
+    wp.refresh()
+    w = params[4].detach().reshape(256, 384, 9)
+    assert torch.equal(params[4]._mmd_packed[0], w.permute(0, 2, 1).reshape(256, 9 * 384).to(dtype))
