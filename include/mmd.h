@@ -309,6 +309,13 @@ int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t ld
                int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a, const float* b,
                const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld, int act, float* dgamma,
                float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream);
+/* The same with a CALLER-KEPT workspace whose first S*C*2 floats are zero on entry; they are zero again on exit (the parameter stage
+ * clears what it read), so the fill launch in front of every norm's backward is gone (243 per training step, mtu:280-330).  One
+ * workspace per stream; zero it once after allocation. */
+int mmd_gn_bwd_ws0(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C, int S,
+                   int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a, const float* b,
+                   const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld, int act, float* dgamma,
+                   float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream);
 /* Attention backward for every attention of the model (strided + windowed row descriptor, see mmd_attn_bwd.hip). */
 int mmd_attn_bwd(int dtype, const void* Q, int64_t ldq, int q_off, const void* KV, int64_t ldkv, int k_off, int v_off, const void* O,
                  int64_t ldo, const void* dO, int64_t lddo, void* dQ, int64_t lddq, int dq_off, void* dKV, int64_t lddkv, int dk_off,

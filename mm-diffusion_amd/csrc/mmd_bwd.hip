@@ -536,15 +536,19 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const char* __restri
 }
 
 // stage 2: parameter / FiLM gradients and the per-(slice, group) means m1, m2   (one block per slice)
-__global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restrict__ PQ, int C, int Tn, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void gn_bwd_params_kernel(float* __restrict__ PQ, int C, int Tn, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ film, int64_t film_ld,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dfilm,
-                                                            int64_t dfilm_ld, float* __restrict__ m12) {
+                                                            int64_t dfilm_ld, float* __restrict__ m12, int rezero) {
   __shared__ float s_g1[1024], s_g2[1024];
   const int s = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / 32;
   for (int c = tid; c < C; c += 256) {
     const float P = PQ[((int64_t)s * C + c) * 2], Q = PQ[((int64_t)s * C + c) * 2 + 1];
+    if (rezero) {                        // mmd_gn_bwd_ws0: the accumulators go back to zero for the next call on this workspace
+      PQ[((int64_t)s * C + c) * 2] = 0.f;
+      PQ[((int64_t)s * C + c) * 2 + 1] = 0.f;
+    }
     const float sc1 = film ? 1.f + film[(int64_t)s * film_ld + c] : 1.f;
     const float gc = sc1 * gamma[c];
     s_g1[c] = gc * P;
@@ -803,10 +807,10 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, in
 // GroupNorm(+FiLM)(+SiLU) backward.  a, b [S,C] and mr [S,32,2] (mean, rstd) come from the forward mmd_gn_stats.
 // dgamma / dbeta fp32 [C] are ACCUMULATED (caller zeroes); dfilm (nullable) [S, >= 2C] receives (dscale | dshift);
 // workspace: (S*C*2 + S*64) floats, zeroed by this call.
-extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C,
-                          int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
-                          const float* b, const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld,
-                          int act, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream) {
+static int gn_bwd_impl(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C,
+                       int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
+                       const float* b, const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld,
+                       int act, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream, bool ws0) {
   const int epv = dtype == MMD_BF16 ? 8 : 4;
   MMD_REQUIRE(dtype == MMD_BF16 || dtype == MMD_F32, "gn_bwd: bad dtype");
   MMD_REQUIRE(x && dy && dx && a && b && mr && gamma && beta && dgamma && dbeta && workspace, "gn_bwd: null pointer");
@@ -817,8 +821,10 @@ extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy,
   float* m12 = workspace + (int64_t)S * C * 2;
   // zeroed by a kernel, not hipMemsetAsync: memset nodes of a captured graph were observed to lose their ordering against the
   // neighbouring kernel nodes on replay (train_graph.py), a fill kernel is an ordinary node of the chain
-  hipLaunchKernelGGL(zero_f32_kernel, dim3(ew_grid_b((int64_t)S * C * 2)), dim3(256), 0, st, PQ, (int64_t)S * C * 2);
-  if (int zrc = mmd_check_launch("gn_bwd_zero")) return zrc;
+  if (!ws0) {
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(ew_grid_b((int64_t)S * C * 2)), dim3(256), 0, st, PQ, (int64_t)S * C * 2);
+    if (int zrc = mmd_check_launch("gn_bwd_zero")) return zrc;
+  }
   const int rpp = max(1, 256 / (C / epv));
   int R = 4 * rpp;
   while ((int64_t)S * cdiv(Tn, R) > 1280 && R < 1024) R *= 2;
@@ -829,8 +835,8 @@ extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy,
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, C, g, a, b, mr, act, R, PQ);
   int rc = mmd_check_launch("gn_bwd_reduce");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(S), dim3(256), 0, st, (const float*)PQ, C, Tn, gamma, beta, film, film_ld, dgamma, dbeta, dfilm,
-                     dfilm_ld, m12);
+  hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(S), dim3(256), 0, st, PQ, C, Tn, gamma, beta, film, film_ld, dgamma, dbeta, dfilm,
+                     dfilm_ld, m12, ws0 ? 1 : 0);
   rc = mmd_check_launch("gn_bwd_params");
   if (rc) return rc;
   int R3 = 4 * rpp;
@@ -844,6 +850,23 @@ extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy,
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid3, dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, (char*)dx, lddx, C, g,
                        a, b, mr, (const float*)m12, gamma, film, film_ld, act, R3);
   return mmd_check_launch("gn_bwd_apply");
+}
+
+extern "C" int mmd_gn_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C,
+                          int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
+                          const float* b, const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld,
+                          int act, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream) {
+  return gn_bwd_impl(dtype, x, ldx, dy, lddy, dx, lddx, rows, C, S, Tn, inner, outer_stride, inner_stride, tstride, a, b, mr, gamma, beta, film,
+                     film_ld, act, dgamma, dbeta, dfilm, dfilm_ld, workspace, stream, false);
+}
+// The same with a workspace the CALLER keeps: its first S * C * 2 floats are zero on entry and zero again on exit (the parameter stage
+// clears what it has read), so a training step's 243 norms do not pay a fill launch each.  One workspace per stream.
+extern "C" int mmd_gn_bwd_ws0(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int64_t rows, int C,
+                              int S, int Tn, int inner, int64_t outer_stride, int64_t inner_stride, int64_t tstride, const float* a,
+                              const float* b, const float* mr, const float* gamma, const float* beta, const float* film, int64_t film_ld,
+                              int act, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* workspace, void* stream) {
+  return gn_bwd_impl(dtype, x, ldx, dy, lddy, dx, lddx, rows, C, S, Tn, inner, outer_stride, inner_stride, tstride, a, b, mr, gamma, beta, film,
+                     film_ld, act, dgamma, dbeta, dfilm, dfilm_ld, workspace, stream, true);
 }
 
 // out = silu(x) (dy == NULL) or dy * silu'(x); contiguous buffers of n elements (n % (16/elsize) == 0)

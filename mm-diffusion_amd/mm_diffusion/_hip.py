@@ -74,6 +74,7 @@ _PROTOS = {
     "mmd_loss_terms": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     "mmd_conv_wgrad": (i32, [i32, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, vp]),
     "mmd_gn_bwd": (i32, [i32, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp]),
+    "mmd_gn_bwd_ws0": (i32, [i32, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp]),
     "mmd_attn_bwd": (i32, [i32, vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32,
                            i32, i64, i64, i64, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp]),
     "mmd_timestep_embedding": (i32, [vp, i32, i32, i32, vp, vp]),

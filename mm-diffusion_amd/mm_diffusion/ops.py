@@ -1048,11 +1048,26 @@ def conv_wgrad(dy, x, dW, db, taps, dims, torch_layout=False):
               meta=("conv_wgrad", 2 * dy.shape[0] * dy.shape[1] * x.shape[1] * nt, 0))
 
 
+# GroupNorm backward workspaces kept zero between calls (mmd_gn_bwd_ws0): one per (device, launch stream, size); MMD_GN_BWD_WS0=0 = the
+# per-call workspace with its fill launch (A/B)
+_GN_BWD_WS0 = os.environ.get("MMD_GN_BWD_WS0", "1") != "0"
+_gn_bwd_ws = {}
+
+
 def gn_bwd(x, dy, dx, geom: Geom, a, b, mr, gamma, beta, film, act, dgamma, dbeta, dfilm):
     _chk2d(x), _chk2d(dy), _chk2d(dx)
     C = x.shape[1]
-    ws = torch.empty(geom.S * C * 2 + geom.S * 64, dtype=torch.float32, device=x.device)
-    _dispatch("mmd_gn_bwd", H.dt_of(x), x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), dx.data_ptr(), dx.stride(0),
+    n = geom.S * C * 2 + geom.S * 64
+    if _GN_BWD_WS0 and _recorder is None:
+        key = (str(x.device), H.stream_handle(), n)
+        ws = _gn_bwd_ws.get(key)
+        if ws is None:
+            ws = _gn_bwd_ws[key] = torch.zeros(n, dtype=torch.float32, device=x.device)
+        entry = "mmd_gn_bwd_ws0"
+    else:
+        ws = torch.empty(n, dtype=torch.float32, device=x.device)
+        entry = "mmd_gn_bwd"
+    _dispatch(entry, H.dt_of(x), x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), dx.data_ptr(), dx.stride(0),
               x.shape[0], C, *geom.args(), a.data_ptr(), b.data_ptr(), mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
               H.ptr(film), 0 if film is None else film.stride(0), 1 if act else 0, dgamma.data_ptr(), dbeta.data_ptr(),
               H.ptr(dfilm), 0 if dfilm is None else dfilm.stride(0), ws.data_ptr(), meta=("gn_bwd", 0, 3 * x.numel() * x.element_size()))

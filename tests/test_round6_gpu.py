@@ -451,3 +451,31 @@ def test_weight_pack_and_grad_unpack_tiles(dtype):
     wp.refresh()
     w = params[4].detach().reshape(256, 384, 9)
     assert torch.equal(params[4]._mmd_packed[0], w.permute(0, 2, 1).reshape(256, 9 * 384).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gn_bwd_with_a_kept_zero_workspace(dtype, monkeypatch):
+    """mmd_gn_bwd_ws0 (the workspace stays zero between calls: no fill launch per norm) against mmd_gn_bwd on the same inputs, called
+    three times in a row on ONE kept workspace (different inputs each time: a stale accumulator would show), and the workspace is zero
+    again afterwards."""
+    from mm_diffusion import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    S, Tn, C = 3, 640, 256
+    geom = ops.Geom.per_sample(S, Tn)
+    gamma, beta = 1 + 0.1 * torch.randn(C, device="cuda", generator=g), 0.2 * torch.randn(C, device="cuda", generator=g)
+    film = 0.2 * torch.randn(S, 2 * C, device="cuda", generator=g)
+    for it in range(3):
+        x = (torch.randn(S * Tn, C, device="cuda", generator=g) * (1 + it) + 0.3).to(dtype)
+        dy = torch.randn(S * Tn, C, device="cuda", generator=g).to(dtype)
+        mr = torch.empty(S, 32, 2, device="cuda")
+        a, b = ops.gn_stats(x, gamma, beta, geom, film=film, mr=mr)
+        outs = []
+        for ws0 in (False, True):
+            monkeypatch.setattr(ops, "_GN_BWD_WS0", ws0)
+            dx = torch.full_like(x, float("nan"))
+            dgam, dbet, dfilm = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(S, 2 * C, device="cuda")
+            ops.gn_bwd(x, dy, dx, geom, a, b, mr, gamma, beta, film, True, dgam, dbet, dfilm)
+            outs.append((dx.float(), dgam, dbet, dfilm))
+        for u, v in zip(outs[0], outs[1]):
+            assert float((u - v).norm() / v.norm()) < (2e-3 if dtype == torch.bfloat16 else 1e-5), it      # (atomic accumulation order differs run to run)
+    assert ops._gn_bwd_ws and all(not w[: w.numel() - 64 * 3].any() for k, w in ops._gn_bwd_ws.items() if k[2] == S * C * 2 + S * 64)
