@@ -540,10 +540,12 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(float* __restrict__ 
                                                             const float* __restrict__ beta, const float* __restrict__ film, int64_t film_ld,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dfilm,
                                                             int64_t dfilm_ld, float* __restrict__ m12, int rezero) {
-  __shared__ float s_g1[1024], s_g2[1024];
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const int cpg = C / 32;
-  for (int c = tid; c < C; c += 256) {
+  // round 6: grid (4, S) - a block owns 8 groups = 8 cpg <= 256 channels, one per thread (it was one block per slice looping over C)
+  __shared__ float s_g1[256], s_g2[256];
+  const int s = blockIdx.y, g0 = blockIdx.x * 8, tid = threadIdx.x;
+  const int cpg = C / 32, nch = 8 * cpg;
+  if (tid < nch) {
+    const int c = g0 * cpg + tid;
     const float P = PQ[((int64_t)s * C + c) * 2], Q = PQ[((int64_t)s * C + c) * 2 + 1];
     if (rezero) {                        // mmd_gn_bwd_ws0: the accumulators go back to zero for the next call on this workspace
       PQ[((int64_t)s * C + c) * 2] = 0.f;
@@ -551,8 +553,8 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(float* __restrict__ 
     }
     const float sc1 = film ? 1.f + film[(int64_t)s * film_ld + c] : 1.f;
     const float gc = sc1 * gamma[c];
-    s_g1[c] = gc * P;
-    s_g2[c] = gc * Q;
+    s_g1[tid] = gc * P;
+    s_g2[tid] = gc * Q;
     atomicAdd(dgamma + c, sc1 * Q);
     atomicAdd(dbeta + c, sc1 * P);
     if (dfilm) {
@@ -561,12 +563,12 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(float* __restrict__ 
     }
   }
   __syncthreads();
-  if (tid < 32) {
+  if (tid < 8) {
     float a1 = 0.f, a2 = 0.f;
     for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a1 += s_g1[c]; a2 += s_g2[c]; }
     const float cnt = (float)Tn * (float)cpg;
-    m12[((int64_t)s * 32 + tid) * 2] = a1 / cnt;
-    m12[((int64_t)s * 32 + tid) * 2 + 1] = a2 / cnt;
+    m12[((int64_t)s * 32 + g0 + tid) * 2] = a1 / cnt;
+    m12[((int64_t)s * 32 + g0 + tid) * 2 + 1] = a2 / cnt;
   }
 }
 
@@ -835,7 +837,7 @@ static int gn_bwd_impl(int dtype, const void* x, int64_t ldx, const void* dy, in
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const char*)x, ldx, (const char*)dy, lddy, C, g, a, b, mr, act, R, PQ);
   int rc = mmd_check_launch("gn_bwd_reduce");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(S), dim3(256), 0, st, PQ, C, Tn, gamma, beta, film, film_ld, dgamma, dbeta, dfilm,
+  hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(4, S), dim3(256), 0, st, PQ, C, Tn, gamma, beta, film, film_ld, dgamma, dbeta, dfilm,
                      dfilm_ld, m12, ws0 ? 1 : 0);
   rc = mmd_check_launch("gn_bwd_params");
   if (rc) return rc;
